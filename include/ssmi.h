@@ -1,0 +1,252 @@
+/*
+ * ssmi.h - C ABI of libssmi.so: hand-written HIP (gfx950 / CDNA4) kernels for the training hot path of
+ * jnissin/semantic-segmentation (ENet-style encoder-decoders, custom pooling layers, class-weighted
+ * pixelwise cross-entropy, confusion-matrix metrics, Adam/SGD).
+ *
+ * The reference has no native/FFI boundary: its operator API is Python/Keras and the arithmetic lives in
+ * TensorFlow kernels.  Each entry point below therefore cites the reference call site (path relative to the
+ * reference checkout) whose TensorFlow/Keras op it replaces.
+ *
+ * Conventions
+ *   - every function returns an ssmi_status (0 = OK, negative = error); ssmi_last_error() gives the text of
+ *     the calling thread's last failure.
+ *   - all tensor arguments are DEVICE pointers owned by the caller, dense NHWC unless a leading-dimension
+ *     argument says otherwise, float32 unless the name says otherwise.
+ *   - every call is asynchronous and ordered on the hipStream_t passed as `stream` (void*, may be NULL for
+ *     the default stream).  No entry point allocates or frees device memory; scratch space is passed in as
+ *     `ws` and sized by the matching *_workspace_bytes() query.
+ *   - the library holds no global mutable state except the per-thread error string.
+ */
+#ifndef SSMI_H_
+#define SSMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t ssmi_status;
+enum {
+  SSMI_OK = 0,
+  SSMI_E_INVALID_ARG = -1,
+  SSMI_E_SHAPE = -2,
+  SSMI_E_UNSUPPORTED = -3,
+  SSMI_E_HIP = -4,
+  SSMI_E_WORKSPACE = -5
+};
+
+const char* ssmi_last_error(void);
+int32_t ssmi_version(void);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Convolutions.  Kernel layout HWIO = [kh][kw][cin][cout] (Keras Conv2D).  Cross-correlation.
+ * The descriptor always describes the FORWARD convolution x[n,h,w,cin] -> y[n,ho,wo,cout]:
+ *   y[n,oy,ox,co] = bias[co] + sum_{ky,kx,ci} x[n, oy*stride + ky*dil - pad_t, ox*stride + kx*dil - pad_l, ci] * w[ky,kx,ci,co]
+ * with out-of-range x read as zero.  pad_t/pad_l are the TF "SAME" pad_before values (0 for VALID);
+ * ssmi_same_pad() computes them.  x_ld / y_ld are the element strides between consecutive pixels of x / y
+ * (>= cin / cout) so that a convolution can read or write a channel slice of a wider tensor (the concat of
+ * the initial block, src/models.py:1063).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct ssmi_conv_desc {
+  int32_t n, h, w, cin;
+  int32_t ho, wo, cout;
+  int32_t kh, kw;
+  int32_t stride;
+  int32_t dil;
+  int32_t pad_t, pad_l;
+  int32_t x_ld, y_ld;
+} ssmi_conv_desc;
+
+/* TF SAME padding rule: out = ceil(in/stride); total = max((out-1)*stride + (k-1)*dil + 1 - in, 0);
+ * before = total/2.  Host-only helper. */
+ssmi_status ssmi_same_pad(int32_t in, int32_t k, int32_t stride, int32_t dil, int32_t* out, int32_t* pad_before);
+
+/* Keras Conv2D forward (src/models.py:1056-1060, 1090-1096, 1105-1133, 1142-1147).  bias may be NULL. */
+ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                            void* stream);
+/* Gradient w.r.t. x (tf.gradients through Conv2D).  dx[n,h,w,cin] (pixel stride x_ld) is fully overwritten:
+ * dx = conv_bwd_data(dy, w) + (add ? add : 0), where `add` (nullable) has the layout of dx.  The `add` operand
+ * carries the gradient of the block's skip branch (src/models.py:1171). */
+ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
+                                 void* stream);
+/* Gradient w.r.t. the kernel (and bias when dbias != NULL).  dw/dbias are overwritten.  Deterministic
+ * two-stage reduction through `ws`. */
+size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                   void* ws, size_t ws_bytes, void* stream);
+
+/* Keras Conv2DTranspose(padding='same', strides=s) (src/models.py:1244-1250, 1311-1317, 1556-1562, 1620-1626) =
+ * gradient of the SAME forward convolution described by `d`:
+ *   tconv input  xt[n, ho, wo, cout],  tconv output yt[n, h, w, cin] (h = ho*stride, w = wo*stride),
+ *   kernel (kh, kw, tconv_out = cin, tconv_in = cout)  -- the Keras Conv2DTranspose kernel layout, which is the
+ *   HWIO layout of the forward convolution `d`.  bias has cin entries (nullable). */
+ssmi_status ssmi_conv2d_transpose_fwd(const ssmi_conv_desc* d, const float* xt, const float* w, const float* bias,
+                                      float* yt, void* stream);
+ssmi_status ssmi_conv2d_transpose_bwd_data(const ssmi_conv_desc* d, const float* dyt, const float* w, float* dxt,
+                                           void* stream);
+size_t ssmi_conv2d_transpose_bwd_weight_workspace_bytes(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const float* xt, const float* dyt, float* dw,
+                                             float* dbias, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * BatchNormalization(axis=-1, momentum, epsilon) + activation (src/models.py:1064-1065, 1100-1101, ...).
+ * act: 0 = none, 1 = PReLU(shared_axes=[1,2]) with per-channel alpha, 2 = LeakyReLU(slope).
+ * ---------------------------------------------------------------------------------------------------- */
+enum { SSMI_ACT_NONE = 0, SSMI_ACT_PRELU = 1, SSMI_ACT_LEAKY = 2 };
+
+/* Training-phase statistics of x[npix, c] (pixel stride ld): save_mean, save_invstd = 1/sqrt(biased_var + eps),
+ * and the Keras moving-average update  moving <- momentum*moving + (1-momentum)*batch  (momentum is the weight of
+ * the OLD value; the reference uses 0.1).  unbiased_moving != 0 feeds the Bessel-corrected variance into the moving
+ * update (tf.nn.fused_batch_norm behaviour).  moving_* may be NULL (no update). */
+size_t ssmi_bn_workspace_bytes(int64_t npix, int32_t c);
+ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
+                                int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+/* Inference phase: save_mean = moving_mean, save_invstd = 1/sqrt(moving_var + eps). */
+ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_var, int32_t c, float eps,
+                                float* save_mean, float* save_invstd, void* stream);
+/* y = act(gamma * (x - mean) * invstd + beta).  x and y dense [npix, c] (x pixel stride ld_x). */
+ssmi_status ssmi_bn_act_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, int32_t act, const float* alpha, float slope, float* y, int64_t npix,
+                            int32_t c, void* stream);
+/* Backward of the above in the training phase (statistics are functions of x):
+ *   dx (pixel stride ld_x), dgamma, dbeta, dalpha (PReLU only) are overwritten. */
+ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                            float* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                            size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Bottleneck merge (src/models.py:1150-1172, 1265-1296, 1594-1607): one fused pass for
+ *   out = PReLU_alpha( dropscale[n,c] * BN3(main) + other' )
+ * other_mode selects other':
+ *   0  identity           other[n,h,w,c]
+ *   1  channel zero-pad   other[n,h,w,c_other], zeros for channels >= c_other      (MaxPooling2D + ZeroPadding2D branch)
+ *   2  nearest 2x upsample of BN_o(other[n,h/2,w/2,c])                             (UpSampling2D branch)
+ *   3  MaxUnpooling2D of BN_o(other[n,h/2,w/2,c]) with idx[n,h/2,w/2,c]            (window-local int32 indices)
+ * drop (nullable) is the SpatialDropout2D keep/scale table [n,c] (0 or 1/(1-rate)).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct ssmi_merge_desc {
+  int32_t n, h, w, c;
+  int32_t other_mode;
+  int32_t c_other;
+} ssmi_merge_desc;
+
+typedef struct ssmi_bn_params {
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+} ssmi_bn_params;
+
+ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
+                           const float* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
+                           float* out, void* stream);
+/* Backward.  Outputs (all overwritten):
+ *   dmain   [n,h,w,c]   gradient w.r.t. the raw `main` tensor (through dropout and BN3, training phase)
+ *   dsum    [n,h,w,c]   gradient w.r.t. the pre-activation sum (= gradient of the identity / padded skip branch)
+ *   dother_bn [n,h/2,w/2,c] (modes 2,3 only) gradient w.r.t. BN_o's OUTPUT (2x2 sum / gather of dsum); the caller
+ *                       pushes it through ssmi_bn_act_bwd(act = none) to reach the other-branch convolution
+ *   dgamma3, dbeta3, dalpha  parameter gradients */
+size_t ssmi_merge_workspace_bytes(const ssmi_merge_desc* d);
+ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const float* main, const ssmi_bn_params* bn3,
+                           const float* drop, const float* other, const ssmi_bn_params* bn_other, const int32_t* idx,
+                           const float* alpha, float* dmain, float* dsum, float* dother_bn, float* dgamma3,
+                           float* dbeta3, float* dalpha, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Pooling family.
+ * ---------------------------------------------------------------------------------------------------- */
+/* tf.nn.max_pool_with_argmax(ksize 2x2, strides 2, SAME) as wrapped by MaxPoolingWithArgmax2D
+ * (src/layers/pooling.py:43-49) and, with idx == NULL, Keras MaxPooling2D 2x2 (src/models.py:1062,1159; identical
+ * values for even h,w).  Window scanned h then w, strict '>' so the first maximum wins; index =
+ * (iy*w + ix)*c + ch inside the image; windows are clipped at the border.
+ * y has pixel stride y_ld (>= c).  idx_i32 and idx_f32 (the reference returns float32 indices) are nullable,
+ * dense [n,ho,wo,c]. */
+ssmi_status ssmi_maxpool_argmax_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
+                                    int32_t* idx_i32, float* idx_f32, void* stream);
+/* Gradient routing to the argmax position (gather form over the input grid, no atomics):
+ *   dx[n,iy,ix,ch] (+)= (idx[n,iy/2,ix/2,ch] == (iy*w+ix)*c+ch) ? dy[n,iy/2,ix/2,ch] : 0
+ * dy has pixel stride dy_ld.  accumulate != 0 adds into dx. */
+ssmi_status ssmi_maxpool_argmax_bwd(const float* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, float* dx, int32_t accumulate, void* stream);
+/* MaxUnpooling2D (src/layers/pooling.py:71-103): y[n, idx] += x, zeros elsewhere; x,idx [n,h,w,c] -> y [n,2h,2w,c].
+ * General tf.scatter_nd semantics (any in-range index, duplicates sum) : memset + atomic scatter. */
+ssmi_status ssmi_maxunpool_fwd(const float* x, const int32_t* idx, int32_t n, int32_t h, int32_t w, int32_t c, float* y,
+                               void* stream);
+/* Same result for window-local indices (those produced by ssmi_maxpool_argmax_fwd): pure gather over the output,
+ * no memset, no atomics. */
+ssmi_status ssmi_maxunpool_local_fwd(const float* x, const int32_t* idx, int32_t n, int32_t h, int32_t w, int32_t c,
+                                     float* y, void* stream);
+/* Gradient of scatter_nd w.r.t. the values: dx[n,h,w,c] = dy[n, idx[n,h,w,c]]. */
+ssmi_status ssmi_maxunpool_bwd(const float* dy, const int32_t* idx, int32_t n, int32_t h, int32_t w, int32_t c,
+                               float* dx, void* stream);
+/* float32 <-> int32 index views (the reference moves indices as float32, src/layers/pooling.py:48,78). */
+ssmi_status ssmi_idx_f32_to_i32(const float* src, int32_t* dst, int64_t count, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Loss + metrics.
+ * ---------------------------------------------------------------------------------------------------- */
+/* _segmentation_sparse_weighted_pixelwise_crossentropy_loss (src/losses.py:243-265) fused with its gradient, the
+ * prediction argmax (src/metrics.py:259) and the streaming confusion matrix (src/metrics.py:89-130, 355-378):
+ *   loss   = (1/npix) * sum_p w[p] * (logsumexp(z[p,:]) - z[p, label[p]])
+ *   dlogits[p,k] = grad_scale * w[p]/npix * (softmax(z[p,:])[k] - [k == label[p]])        (dlogits nullable)
+ *   cm[label[p], argmax_k z[p,k]] += 1 for p < npix_metrics with label[p] not in ignore_mask   (cm int64, nullable, accumulated)
+ * loss_out is a device float, overwritten.  ignore_mask bit k set <=> class k ignored (num_classes <= 64).
+ * Labels outside [0, num_classes) are an error in TensorFlow; here they contribute nothing and set *bad_labels
+ * (device int32, nullable) to the count seen.  Deterministic loss reduction through ws. */
+size_t ssmi_softmax_xent_workspace_bytes(int64_t npix);
+ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                      int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
+                                      int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                      int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream);
+/* Host-side derivations from a confusion matrix (rows = labels): tf.metrics.accuracy / mean_per_class_accuracy /
+ * mean_iou as used by src/metrics.py:276-352, and the reference's own numpy definitions
+ * (src/scripts/calculate_metrics_from_cfms.py:12-53) which drop ignored classes before averaging.
+ * out[0]=accuracy, out[1]=tf mean_per_class_accuracy, out[2]=tf mean_iou (classes with non-zero denominator),
+ * out[3]=tf mean_iou over all classes, out[4]=script mpca, out[5]=script miou. */
+ssmi_status ssmi_metrics_from_cm(const int64_t* cm_host, int32_t num_classes, uint64_t ignore_mask, double* out6);
+
+/* ------------------------------------------------------------------------------------------------------
+ * Optimizers over a flat parameter arena (src/keras_extensions/extended_optimizers.py:35-67, 117-162).
+ * `step` points at a 16-byte device block: an int64 holding Keras' `iterations` (value before the update) followed
+ * by 8 bytes of scratch in which the library keeps the step's effective learning rate.  The call increments the
+ * counter on the device, so a captured graph can be replayed.  lr_scale (nullable) is a per-ELEMENT table implementing lr_scalers.
+ * grad_scale multiplies every gradient first (1/world_size after a sum all-reduce).
+ * ---------------------------------------------------------------------------------------------------- */
+ssmi_status ssmi_adam_step(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,
+                           int64_t* step, float lr, float beta_1, float beta_2, float epsilon, float decay,
+                           float grad_scale, const float* lr_scale, void* stream);
+ssmi_status ssmi_sgd_step(float* params, const float* grads, float* moments, int64_t count, int64_t* step, float lr,
+                          float momentum, float decay, int32_t nesterov, float grad_scale, const float* lr_scale,
+                          void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * SpatialDropout2D keep/scale table (src/models.py:1151,1267): mask[i] = (u_i >= rate) ? 1/(1-rate) : 0 with
+ * u_i from Philox4x32-10 keyed by (seed, *step_counter, stream_id, i).  step_counter is a device int64 (read
+ * only; the optimizer kernel advances it), so replayed graphs draw fresh masks every step.
+ * ---------------------------------------------------------------------------------------------------- */
+ssmi_status ssmi_dropout_mask(float* mask, int64_t count, float rate, uint64_t seed, const int64_t* step_counter,
+                              uint32_t stream_id, void* stream);
+
+/* Utility kernels. */
+ssmi_status ssmi_fill_f32(float* dst, float value, int64_t count, void* stream);
+ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, void* stream);
+ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * HIP graph capture of a whole training step (replaces the one tf.Session.run per step of
+ * ExtendedModel.train_on_batch, src/keras_extensions/extended_model.py:1002).
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct ssmi_graph ssmi_graph;
+ssmi_status ssmi_graph_begin_capture(void* stream);
+ssmi_status ssmi_graph_end_capture(void* stream, ssmi_graph** out);
+ssmi_status ssmi_graph_launch(ssmi_graph* g, void* stream);
+ssmi_status ssmi_graph_destroy(ssmi_graph* g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSMI_H_ */

@@ -1,0 +1,385 @@
+"""CPU oracle: the ENet encoder-decoders of the reference's src/models.py restated on top of
+oracle/tf_keras_ops.py (PyTorch CPU, NHWC, autograd for the backward pass).
+
+TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py cpu_baseline).
+PARITY UNPINNED: the reference holds no test vectors for this path; see tf_keras_ops.py.
+
+Weights are a flat dict  "{layer_name}/{kernel|bias|gamma|beta|moving_mean|moving_variance|alpha}"
+in Keras layouts (Conv2D kernel HWIO, Conv2DTranspose kernel (kh,kw,out,in), PReLU alpha (1,1,C)).
+
+Topologies follow:
+  enet-naive-upsampling : src/models.py:1054-1319
+  enet-max-unpooling    : src/models.py:1360-1628
+Deviation kept on purpose: the naive decoder's second PReLU is named `_prelu_2`
+(the reference names both `_prelu_1`, src/models.py:1231,1254, which Keras rejects).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import tf_keras_ops as K
+
+ENC_PATTERN = [("1", {}), ("2", {"dilated": 2}), ("3", {"asymmetric": 5}), ("4", {"dilated": 4}),
+               ("5", {}), ("6", {"dilated": 8}), ("7", {"asymmetric": 5}), ("8", {"dilated": 16})]
+
+
+# --------------------------------------------------------------------------------------
+# weight specification, in layer-creation order of the reference builders
+# --------------------------------------------------------------------------------------
+
+def _conv(spec, name, kh, kw, cin, cout, bias):
+    spec.append((name + "/kernel", (kh, kw, cin, cout), "he_normal", kh * kw * cin))
+    if bias:
+        spec.append((name + "/bias", (cout,), "zeros", 0))
+
+
+def _tconv(spec, name, kh, kw, cin, cout):
+    # Keras Conv2DTranspose kernel: (kh, kw, out, in); he_normal fan_in = kh*kw*in (as Keras computes
+    # it for this layout: receptive field * shape[-2]... kept simple: kh*kw*cin)
+    spec.append((name + "/kernel", (kh, kw, cout, cin), "he_normal", kh * kw * cin))
+    spec.append((name + "/bias", (cout,), "zeros", 0))
+
+
+def _bn(spec, name, c):
+    spec.append((name + "/gamma", (c,), "ones", 0))
+    spec.append((name + "/beta", (c,), "zeros", 0))
+    spec.append((name + "/moving_mean", (c,), "zeros", 0))
+    spec.append((name + "/moving_variance", (c,), "ones", 0))
+
+
+def _prelu(spec, name, c):
+    spec.append((name + "/alpha", (1, 1, c), "zeros", 0))
+
+
+def _enc_bottleneck_spec(spec, p, cin, cout, downsample=False, asymmetric=0, dilated=0):
+    internal = cout // 4
+    s = 2 if downsample else 1
+    _conv(spec, p + "_proj_conv2d_1", s, s, cin, internal, False)
+    _bn(spec, p + "_bnorm_1", internal)
+    _prelu(spec, p + "_prelu_1", internal)
+    if asymmetric:
+        _conv(spec, p + "_aconv2d_1", 1, asymmetric, internal, internal, False)
+        _conv(spec, p + "_aconv2d_2", asymmetric, 1, internal, internal, True)
+    elif dilated:
+        _conv(spec, p + "_dconv2d", 3, 3, internal, internal, True)
+    else:
+        _conv(spec, p + "_conv2d_1", 3, 3, internal, internal, True)
+    _bn(spec, p + "_bnorm_2", internal)
+    _prelu(spec, p + "_prelu_2", internal)
+    _conv(spec, p + "_proj_conv2d_2", 1, 1, internal, cout, False)
+    _bn(spec, p + "_bnorm_3", cout)
+    _prelu(spec, p + "_prelu_3", cout)
+
+
+def _dec_bottleneck_spec(spec, p, cin, cout, upsample, variant):
+    internal = cout // 4
+    _conv(spec, p + "_proj_conv2d_1", 1, 1, cin, internal, False)
+    _bn(spec, p + "_bnorm_1", internal)
+    _prelu(spec, p + "_prelu_1", internal)
+    if upsample:
+        _tconv(spec, p + "_tconv2d_1", 3, 3, internal, internal)
+    else:
+        _conv(spec, p + "_conv2d_1", 3, 3, internal, internal, True)
+    _bn(spec, p + "_bnorm_2", internal)
+    _prelu(spec, p + "_prelu_2", internal)
+    _conv(spec, p + "_proj_conv2d_2", 1, 1, internal, cout, False)
+    has_other = (cin != cout) or upsample
+    if variant == "naive":
+        _bn(spec, p + "_bnorm_3", cout)
+        if has_other:
+            _conv(spec, p + "_other_conv2d", 1, 1, cin, cout, False)
+            _bn(spec, p + "_other_bnorm_1", cout)
+    else:
+        if has_other:
+            _conv(spec, p + "_other_conv2d", 1, 1, cin, cout, False)
+            _bn(spec, p + "_other_bnorm_1", cout)
+        _bn(spec, p + "_bnorm_3", cout)
+    _prelu(spec, p + "_prelu_3", cout)
+
+
+def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str, int]]:
+    """[(key, shape, initializer, fan_in)] in layer-creation order."""
+    if model_name == "enet-naive-upsampling":
+        variant = "naive"
+    elif model_name == "enet-max-unpooling":
+        variant = "unpool"
+    else:
+        raise ValueError("Unknown model name: {}".format(model_name))
+    spec: list = []
+    spec.append(("initial_block_conv2d/kernel", (3, 3, 3, 13), "glorot_uniform", 0))
+    spec.append(("initial_block_conv2d/bias", (13,), "zeros", 0))
+    if variant == "naive":
+        _bn(spec, "initial_block_bnorm", 16)
+        _prelu(spec, "initial_block_prelu", 16)
+    _enc_bottleneck_spec(spec, "en_bn_1.0", 16, 64, downsample=True)
+    for i in range(4):
+        _enc_bottleneck_spec(spec, "en_bn_1.{}".format(i + 1), 64, 64)
+    _enc_bottleneck_spec(spec, "en_bn_2.0", 64, 128, downsample=True)
+    for stage in (2, 3):
+        for suffix, kw in ENC_PATTERN:
+            _enc_bottleneck_spec(spec, "en_bn_{}.{}".format(stage, suffix), 128, 128, **kw)
+    _dec_bottleneck_spec(spec, "de_bn_4.0", 128, 64, True, variant)
+    _dec_bottleneck_spec(spec, "de_bn_4.1", 64, 64, False, variant)
+    _dec_bottleneck_spec(spec, "de_bn_4.2", 64, 64, False, variant)
+    _dec_bottleneck_spec(spec, "de_bn_5.0", 64, 16, True, variant)
+    _dec_bottleneck_spec(spec, "de_bn_5.1", 16, 16, False, variant)
+    spec.append(("logits/kernel", (2, 2, num_classes, 16), "he_normal", 2 * 2 * 16))
+    spec.append(("logits/bias", (num_classes,), "zeros", 0))
+    return spec
+
+
+def init_weights(model_name: str, num_classes: int, seed: int = 14874, perturb: bool = False,
+                 dtype=np.float64) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic initial weights.  `perturb=True` also randomises BN gamma/beta, PReLU alpha, biases
+    and moving statistics so that parity tests exercise every term (Keras defaults are 1/0/0)."""
+    rng = np.random.RandomState(seed)
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for key, shape, init, fan_in in weight_spec(model_name, num_classes):
+        if init == "he_normal":
+            w = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif init == "glorot_uniform":
+            kh, kw, cin, cout = shape
+            lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+            w = rng.uniform(-lim, lim, size=shape)
+        elif init == "ones":
+            w = np.ones(shape)
+            if perturb:
+                if key.endswith("moving_variance"):
+                    w = rng.uniform(0.5, 1.5, size=shape)
+                else:
+                    w = rng.uniform(0.7, 1.3, size=shape)
+        else:
+            w = np.zeros(shape)
+            if perturb:
+                if key.endswith("alpha"):
+                    w = rng.uniform(0.05, 0.3, size=shape)
+                else:
+                    w = rng.uniform(-0.2, 0.2, size=shape)
+        out[key] = np.ascontiguousarray(w.astype(dtype))
+    return out
+
+
+def dropout_layer_rates(model_name: str) -> "OrderedDict[str, Tuple[float, int]]":
+    """{sdrop layer name: (rate, channels)} in creation order."""
+    out: "OrderedDict[str, Tuple[float, int]]" = OrderedDict()
+    out["en_bn_1.0_sdrop2d_1"] = (0.01, 64)
+    for i in range(4):
+        out["en_bn_1.{}_sdrop2d_1".format(i + 1)] = (0.01, 64)
+    out["en_bn_2.0_sdrop2d_1"] = (0.1, 128)
+    for stage in (2, 3):
+        for suffix, _ in ENC_PATTERN:
+            out["en_bn_{}.{}_sdrop2d_1".format(stage, suffix)] = (0.1, 128)
+    if model_name == "enet-naive-upsampling":
+        for nm, c in (("de_bn_4.0", 64), ("de_bn_4.1", 64), ("de_bn_4.2", 64), ("de_bn_5.0", 16), ("de_bn_5.1", 16)):
+            out[nm + "_sdrop2d_1"] = (0.1, c)
+    return out
+
+
+def make_dropout_masks(model_name: str, batch: int, seed: int, dtype=np.float64):
+    rng = np.random.RandomState(seed)
+    masks = OrderedDict()
+    for name, (rate, c) in dropout_layer_rates(model_name).items():
+        keep = rng.uniform(size=(batch, c)) >= rate
+        masks[name] = (keep.astype(dtype) / (1.0 - rate))
+    return masks
+
+
+# --------------------------------------------------------------------------------------
+# forward graph
+# --------------------------------------------------------------------------------------
+
+class _Ctx:
+    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect):
+        self.p = params
+        self.training = training
+        self.drop = drop_masks or {}
+        self.bn_stats: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.acts: Dict[str, torch.Tensor] = {} if collect else None
+
+    def keep(self, name, t):
+        if self.acts is not None:
+            self.acts[name] = t
+        return t
+
+    def conv(self, name, x, stride=1, dil=1, padding="same"):
+        return self.keep(name, K.conv2d(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride, dil, padding))
+
+    def tconv(self, name, x, stride=2):
+        return self.keep(name, K.conv2d_transpose(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride))
+
+    def bn(self, name, x):
+        g, b = self.p[name + "/gamma"], self.p[name + "/beta"]
+        if self.training:
+            y, mean, var = K.batch_norm_train(x, g, b)
+            self.bn_stats[name] = (mean.detach(), var.detach())
+        else:
+            y = K.batch_norm_infer(x, g, b, self.p[name + "/moving_mean"], self.p[name + "/moving_variance"])
+        return self.keep(name, y)
+
+    def prelu(self, name, x):
+        return self.keep(name, K.prelu(x, self.p[name + "/alpha"].reshape(-1)))
+
+    def sdrop(self, name, x):
+        if self.training and name in self.drop:
+            return K.spatial_dropout(x, self.drop[name])
+        return x
+
+
+def _enc_bottleneck(c: _Ctx, x, cout, p, downsample=False, asymmetric=0, dilated=0, want_idx=False):
+    s = 2 if downsample else 1
+    e = c.conv(p + "_proj_conv2d_1", x, stride=s, padding="valid")
+    e = c.prelu(p + "_prelu_1", c.bn(p + "_bnorm_1", e))
+    if asymmetric:
+        e = c.conv(p + "_aconv2d_1", e)
+        e = c.conv(p + "_aconv2d_2", e)
+    elif dilated:
+        e = c.conv(p + "_dconv2d", e, dil=dilated)
+    else:
+        e = c.conv(p + "_conv2d_1", e)
+    e = c.prelu(p + "_prelu_2", c.bn(p + "_bnorm_2", e))
+    e = c.conv(p + "_proj_conv2d_2", e, padding="valid")
+    e = c.sdrop(p + "_sdrop2d_1", c.bn(p + "_bnorm_3", e))
+    other, idx = x, None
+    if downsample:
+        if want_idx:
+            other, idx = K.max_pool_with_argmax(other)
+            c.keep(p + "_other_pool2d/argmax", idx)
+        else:
+            other = K.max_pool_2x2(other)
+        other = K.channel_zero_pad(other, cout)
+    out = c.prelu(p + "_prelu_3", e + other)
+    return (out, idx) if want_idx and downsample else out
+
+
+def _dec_bottleneck(c: _Ctx, x, cout, p, upsample, variant, idx=None):
+    cin = x.shape[3]
+    d = c.conv(p + "_proj_conv2d_1", x, padding="valid")
+    d = c.prelu(p + "_prelu_1", c.bn(p + "_bnorm_1", d))
+    d = c.tconv(p + "_tconv2d_1", d) if upsample else c.conv(p + "_conv2d_1", d)
+    d = c.prelu(p + "_prelu_2", c.bn(p + "_bnorm_2", d))
+    d = c.conv(p + "_proj_conv2d_2", d)
+    if variant == "naive":
+        d = c.sdrop(p + "_sdrop2d_1", c.bn(p + "_bnorm_3", d))
+    other = x
+    if cin != cout or upsample:
+        other = c.bn(p + "_other_bnorm_1", c.conv(p + "_other_conv2d", other))
+        if upsample:
+            other = K.upsample_nn2(other) if variant == "naive" else K.max_unpool(other, idx)
+    if variant != "naive":
+        d = c.bn(p + "_bnorm_3", d)
+    return c.prelu(p + "_prelu_3", d + other)
+
+
+def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch.Tensor, training: bool = True,
+                 drop_masks=None, collect: bool = False):
+    """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
+    ctx.acts the named intermediate tensors when collect=True."""
+    variant = "naive" if model_name == "enet-naive-upsampling" else "unpool"
+    if model_name not in ("enet-naive-upsampling", "enet-max-unpooling"):
+        raise ValueError("Unknown model name: {}".format(model_name))
+    c = _Ctx(params, training, drop_masks, collect)
+    idx_stack = []
+    conv = c.conv("initial_block_conv2d", images, stride=2)
+    if variant == "naive":
+        x = torch.cat([conv, K.max_pool_2x2(images)], dim=3)
+        x = c.prelu("initial_block_prelu", c.bn("initial_block_bnorm", x))
+    else:
+        pooled, idx0 = K.max_pool_with_argmax(images)
+        c.keep("initial_block_pool2d/argmax", idx0)
+        idx_stack.append(idx0)
+        x = torch.cat([conv, pooled], dim=3)
+    c.keep("initial_block", x)
+    want = variant == "unpool"
+    r = _enc_bottleneck(c, x, 64, "en_bn_1.0", downsample=True, want_idx=want)
+    x = r[0] if want else r
+    if want:
+        idx_stack.append(r[1])
+    for i in range(4):
+        x = _enc_bottleneck(c, x, 64, "en_bn_1.{}".format(i + 1))
+    r = _enc_bottleneck(c, x, 128, "en_bn_2.0", downsample=True, want_idx=want)
+    x = r[0] if want else r
+    if want:
+        idx_stack.append(r[1])
+    for stage in (2, 3):
+        for suffix, kw in ENC_PATTERN:
+            x = _enc_bottleneck(c, x, 128, "en_bn_{}.{}".format(stage, suffix), **kw)
+    c.keep("encoder", x)
+    x = _dec_bottleneck(c, x, 64, "de_bn_4.0", True, variant, idx_stack.pop() if want else None)
+    x = _dec_bottleneck(c, x, 64, "de_bn_4.1", False, variant)
+    x = _dec_bottleneck(c, x, 64, "de_bn_4.2", False, variant)
+    x = _dec_bottleneck(c, x, 16, "de_bn_5.0", True, variant, idx_stack.pop() if want else None)
+    x = _dec_bottleneck(c, x, 16, "de_bn_5.1", False, variant)
+    logits = c.tconv("logits", x)
+    return logits, c
+
+
+TRAINABLE_SUFFIXES = ("/kernel", "/bias", "/gamma", "/beta", "/alpha")
+
+
+def trainable_keys(model_name: str, num_classes: int) -> List[str]:
+    return [k for k, _, _, _ in weight_spec(model_name, num_classes) if k.endswith(TRAINABLE_SUFFIXES)]
+
+
+def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images: np.ndarray, labels: np.ndarray,
+               pixel_weights: np.ndarray, drop_masks=None, dtype=torch.float64, collect=False,
+               adam: Optional[dict] = None, adam_state: Optional[dict] = None, ignore_classes=(0,)):
+    """One supervised training step exactly as the reference assembles it
+    (src/trainers.py:2436-2440: total = 1*loss + 0*mean(0*logits)):
+    forward (training phase) -> weighted CE -> gradients -> BN moving-average updates -> optional Adam.
+    Returns dict(loss, logits, grads{key}, new_weights{key}, cm, acts)."""
+    num_classes = weights["logits/bias"].shape[0]
+    params = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
+    tkeys = trainable_keys(model_name, num_classes)
+    for k in tkeys:
+        params[k].requires_grad_(True)
+    x = torch.tensor(images, dtype=dtype)
+    masks = {k: torch.tensor(v, dtype=dtype) for k, v in (drop_masks or {}).items()}
+    logits, ctx = enet_forward(model_name, params, x, True, masks, collect)
+    lab = torch.tensor(labels.astype(np.int64))
+    w = torch.tensor(pixel_weights, dtype=dtype)
+    loss = K.segmentation_cce_lambda_loss(logits, lab, w, 0)
+    if collect:
+        logits.retain_grad()
+    grads = torch.autograd.grad(loss, [params[k] for k in tkeys] + ([logits] if collect else []), allow_unused=True)
+    gdict = {k: (g.detach().numpy() if g is not None else np.zeros_like(weights[k])) for k, g in zip(tkeys, grads)}
+    new_w = OrderedDict((k, np.array(v)) for k, v in weights.items())
+    for name, (mean, var) in ctx.bn_stats.items():
+        new_w[name + "/moving_mean"] = K.bn_moving_update(torch.tensor(weights[name + "/moving_mean"], dtype=dtype), mean).numpy()
+        new_w[name + "/moving_variance"] = K.bn_moving_update(torch.tensor(weights[name + "/moving_variance"], dtype=dtype), var).numpy()
+    if adam is not None:
+        st = adam_state if adam_state is not None else {"iterations": 0, "m": {}, "v": {}}
+        ps = [torch.tensor(weights[k], dtype=dtype) for k in tkeys]
+        gs = [torch.tensor(gdict[k], dtype=dtype) for k in tkeys]
+        ms = [st["m"].get(k, torch.zeros_like(p)) for k, p in zip(tkeys, ps)]
+        vs = [st["v"].get(k, torch.zeros_like(p)) for k, p in zip(tkeys, ps)]
+        K.adam_step(ps, gs, ms, vs, st["iterations"], **adam)
+        for k, p, m, v in zip(tkeys, ps, ms, vs):
+            new_w[k] = p.numpy()
+            st["m"][k], st["v"][k] = m, v
+        st["iterations"] += 1
+    cm = K.confusion_matrix_np(labels, logits.detach().numpy(), num_classes, ignore_classes)
+    out = dict(loss=float(loss.detach()), logits=logits.detach().numpy(), grads=gdict, new_weights=new_w, cm=cm)
+    if collect:
+        out["acts"] = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in ctx.acts.items()}
+        out["dlogits"] = grads[-1].detach().numpy()
+    return out
+
+
+def synthetic_batch(batch: int, height: int, width: int, num_classes: int = 24, seed: int = 14874, block: int = 32,
+                    class_weights: Optional[np.ndarray] = None):
+    """Synthetic inputs of the shape the reference's generator emits (src/generators.py:1742-1766):
+    images f32 ~ N(0,1); labels int32 constant over `block`x`block` tiles; per-pixel weights = w[labels]."""
+    rng = np.random.RandomState(seed)
+    images = rng.standard_normal((batch, height, width, 3)).astype(np.float32)
+    bh, bw = -(-height // block), -(-width // block)
+    coarse = rng.randint(0, num_classes, size=(batch, bh, bw)).astype(np.int32)
+    labels = np.repeat(np.repeat(coarse, block, axis=1), block, axis=2)[:, :height, :width].copy()
+    if class_weights is None:
+        class_weights = np.ones(num_classes, dtype=np.float32)
+        class_weights[0] = 0.0
+    weights = class_weights.astype(np.float32)[labels]
+    return images, labels, weights

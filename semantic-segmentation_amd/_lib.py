@@ -1,0 +1,126 @@
+"""ctypes binding of libssmi.so (the C ABI declared in include/ssmi.h).
+
+The library is the only compute path: importing this module without a built libssmi.so raises, and there is no
+CPU fallback.  Device memory, streams and process groups come from PyTorch-ROCm; nothing torch-typed crosses the ABI
+(only raw device pointers, sizes and the hipStream_t handle).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssmi.so")
+
+
+class SsmiError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n", "h", "w", "cin", "ho", "wo", "cout", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "x_ld", "y_ld")]
+
+
+class MergeDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "c", "other_mode", "c_other")]
+
+
+class BnParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("mean", "invstd", "gamma", "beta")]
+
+
+_vp, _i32, _i64, _f32, _u64, _u32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
+_PD = C.POINTER(ConvDesc)
+_PM = C.POINTER(MergeDesc)
+_PB = C.POINTER(BnParams)
+
+# name -> (restype, argtypes); status-returning functions are wrapped to raise SsmiError
+_PROTOS = {
+    "ssmi_last_error": (C.c_char_p, []),
+    "ssmi_version": (_i32, []),
+    "ssmi_same_pad": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "ssmi_conv2d_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_bwd_data": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_bwd_weight_workspace_bytes": (_sz, [_PD]),
+    "ssmi_conv2d_bwd_weight": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_conv2d_transpose_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_transpose_bwd_data": (_i32, [_PD, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_transpose_bwd_weight_workspace_bytes": (_sz, [_PD]),
+    "ssmi_conv2d_transpose_bwd_weight": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_bn_workspace_bytes": (_sz, [_i64, _i32]),
+    "ssmi_bn_train_stats": (_i32, [_vp, _i64, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_bn_infer_stats": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "ssmi_bn_act_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _i32, _vp]),
+    "ssmi_bn_act_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
+                               _sz, _vp]),
+    "ssmi_merge_fwd": (_i32, [_PM, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp]),
+    "ssmi_merge_workspace_bytes": (_sz, [_PM]),
+    "ssmi_merge_bwd": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_maxpool_argmax_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "ssmi_maxpool_argmax_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "ssmi_maxunpool_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_maxunpool_local_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_maxunpool_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_idx_f32_to_i32": (_i32, [_vp, _vp, _i64, _vp]),
+    "ssmi_softmax_xent_workspace_bytes": (_sz, [_i64]),
+    "ssmi_softmax_xent_fwd_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _i64, _u64, _vp, _vp, _vp, _sz,
+                                         _vp]),
+    "ssmi_metrics_from_cm": (_i32, [_vp, _i32, _u64, C.POINTER(C.c_double)]),
+    "ssmi_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "ssmi_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _i32, _f32, _vp, _vp]),
+    "ssmi_dropout_mask": (_i32, [_vp, _i64, _f32, _u64, _vp, _u32, _vp]),
+    "ssmi_fill_f32": (_i32, [_vp, _f32, _i64, _vp]),
+    "ssmi_upsample_nn2x_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_upsample_nn2x_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_graph_begin_capture": (_i32, [_vp]),
+    "ssmi_graph_end_capture": (_i32, [_vp, C.POINTER(_vp)]),
+    "ssmi_graph_launch": (_i32, [_vp, _vp]),
+    "ssmi_graph_destroy": (_i32, [_vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+_NOT_STATUS = {"ssmi_last_error", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+               "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
+               "ssmi_softmax_xent_workspace_bytes"}
+
+
+class _Lib:
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise SsmiError(
+                "libssmi.so not found at {} - build it with `make -C semantic-segmentation_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback".format(path))
+        # torch must be imported first so that libamdhip64 resolves to the copy PyTorch-ROCm already loaded
+        import torch  # noqa: F401
+        self._dll = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        self.raw = {}
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(self._dll, name)
+            fn.restype = res
+            fn.argtypes = args
+            self.raw[name] = fn
+            short = name[len("ssmi_"):]
+            setattr(self, short, fn if name in _NOT_STATUS else self._checked(fn, name))
+
+    def _checked(self, fn, name):
+        last_error = self._dll.ssmi_last_error
+        last_error.restype = C.c_char_p
+
+        def call(*a):
+            st = fn(*a)
+            if st != 0:
+                raise SsmiError("{} failed ({}): {}".format(name, st, (last_error() or b"").decode()))
+            return st
+        call.__name__ = name
+        return call
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib(LIB_PATH)
+    return _lib

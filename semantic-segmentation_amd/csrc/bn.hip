@@ -1,0 +1,564 @@
+// BatchNormalization (+PReLU / LeakyReLU) forward/backward and the fused bottleneck merge.
+// All kernels stream NHWC tensors with 16-byte accesses: thread i handles channels [4*(i % C4), +4) of pixel i / C4,
+// so consecutive lanes touch consecutive 16-byte chunks.  Per-channel reductions use a fixed (thread, block) ->
+// partial-sum mapping followed by a double-precision finalize kernel (deterministic).
+#include "common.h"
+
+namespace ssmi {
+
+static constexpr int kMaxRedBlocks = 1024;
+
+static inline int red_blocks(int64_t npix, int c4) {
+  const int ppi = 256 / c4;
+  int64_t b = ceil_div64(npix, (int64_t)ppi * 8);
+  if (b > kMaxRedBlocks) b = kMaxRedBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// block-level reduction of NV float4 accumulators over the threads that share a channel group.
+// sm must hold 256 * NV float4.  Result for channel group c4 is returned by thread tid == c4 (tid < C4).
+template <int NV>
+__device__ __forceinline__ void block_reduce_groups(f32x4 (&v)[NV], f32x4* sm, int c4n, int ppi, bool active) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sm[k * 256 + tid] = active ? v[k] : f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if (tid < c4n) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < ppi; ++q) s += sm[k * 256 + q * c4n + tid];
+      v[k] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// statistics
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int64_t npix, int c4n, int ld,
+                                                        float* __restrict__ part) {
+  __shared__ f32x4 sm[2 * 256];
+  const int ppi = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const bool active = pl < ppi;
+  f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (active) {
+    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
+      const f32x4 a = ld4(x + p * ld + c4 * 4);
+      v[0] += a;
+      v[1] += a * a;
+    }
+  }
+  block_reduce_groups<2>(v, sm, c4n, ppi, active);
+  if (threadIdx.x < c4n) {
+    const int c = c4n * 4;
+    st4(part + ((int64_t)blockIdx.x * 2 + 0) * c + threadIdx.x * 4, v[0]);
+    st4(part + ((int64_t)blockIdx.x * 2 + 1) * c + threadIdx.x * 4, v[1]);
+  }
+}
+
+__global__ void bn_stats_final(const float* __restrict__ part, int nblocks, int c, int64_t npix, float eps,
+                               float momentum, int unbiased, float* __restrict__ moving_mean,
+                               float* __restrict__ moving_var, float* __restrict__ save_mean,
+                               float* __restrict__ save_invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    s += (double)part[((int64_t)b * 2 + 0) * c + ch];
+    ss += (double)part[((int64_t)b * 2 + 1) * c + ch];
+  }
+  const double n = (double)npix;
+  const double mean = s / n;
+  double var = ss / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  save_mean[ch] = (float)mean;
+  save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
+  if (moving_mean) moving_mean[ch] = momentum * moving_mean[ch] + (1.f - momentum) * (float)mean;
+  if (moving_var) {
+    const double mv = (unbiased && npix > 1) ? var * n / (n - 1.0) : var;
+    moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)mv;
+  }
+}
+
+__global__ void bn_infer_stats_kernel(const float* __restrict__ mm, const float* __restrict__ mv, int c, float eps,
+                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  save_mean[ch] = mm[ch];
+  save_invstd[ch] = 1.f / sqrtf(mv[ch] + eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// activation helpers
+// ------------------------------------------------------------------------------------------------
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float z, float a) {
+  if (ACT == SSMI_ACT_NONE) return z;
+  return z > 0.f ? z : a * z;  // PReLU: a = alpha[c]; Leaky: a = slope
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad(float z, float a) {
+  if (ACT == SSMI_ACT_NONE) return 1.f;
+  return z > 0.f ? 1.f : (z < 0.f ? a : 0.f);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ alpha,
+                                                         float slope, float* __restrict__ y, int64_t total4, int c4n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 xv = ld4(x + p * ld + c);
+    const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    f32x4 a = {slope, slope, slope, slope};
+    if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
+    st4(y + i * 4, o);
+  }
+}
+
+// backward pass 1: per-channel sums of dz, dz*xhat and (PReLU) dy*min(z,0)
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, int ld,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ alpha, float slope, int64_t npix,
+                                                         int c4n, float* __restrict__ part) {
+  __shared__ f32x4 sm[3 * 256];
+  const int ppi = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const bool active = pl < ppi;
+  const int c = c4 * 4;
+  f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (active) {
+    const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    f32x4 a = {slope, slope, slope, slope};
+    if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
+      const f32x4 xv = ld4(x + p * ld + c);
+      const f32x4 d = ld4(dy + (p * c4n + c4) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (xv[j] - m[j]) * is[j];
+        const float z = g[j] * xh + b[j];
+        const float dz = d[j] * act_grad<ACT>(z, a[j]);
+        v[0][j] += dz;
+        v[1][j] += dz * xh;
+        if (ACT == SSMI_ACT_PRELU) v[2][j] += d[j] * (z < 0.f ? z : 0.f);
+      }
+    }
+  }
+  block_reduce_groups<3>(v, sm, c4n, ppi, active);
+  if (threadIdx.x < c4n) {
+    const int cc = c4n * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st4(part + ((int64_t)blockIdx.x * 3 + k) * cc + threadIdx.x * 4, v[k]);
+  }
+}
+
+// finalize: parameter gradients + coefficients for the apply pass: coef[0]=gamma*invstd, coef[1]=mean(dz), coef[2]=mean(dz*xhat)
+__global__ void bn_bwd_final(const float* __restrict__ part, int nblocks, int c, int64_t npix,
+                             const float* __restrict__ gamma, const float* __restrict__ invstd,
+                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha,
+                             float* __restrict__ coef) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    s0 += (double)part[((int64_t)b * 3 + 0) * c + ch];
+    s1 += (double)part[((int64_t)b * 3 + 1) * c + ch];
+    s2 += (double)part[((int64_t)b * 3 + 2) * c + ch];
+  }
+  if (dbeta) dbeta[ch] = (float)s0;
+  if (dgamma) dgamma[ch] = (float)s1;
+  if (dalpha) dalpha[ch] = (float)s2;
+  coef[ch] = gamma[ch] * invstd[ch];
+  coef[c + ch] = (float)(s0 / (double)npix);
+  coef[2 * c + ch] = (float)(s1 / (double)npix);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ld,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        const float* __restrict__ alpha, float slope,
+                                                        const float* __restrict__ coef, float* __restrict__ dx,
+                                                        int64_t total4, int c4n) {
+  const int cc = c4n * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 xv = ld4(x + p * ld + c);
+    const f32x4 d = ld4(dy + i * 4);
+    const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+    const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
+    f32x4 a = {slope, slope, slope, slope};
+    if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xv[j] - m[j]) * is[j];
+      const float z = g[j] * xh + b[j];
+      const float dz = d[j] * act_grad<ACT>(z, a[j]);
+      o[j] = k1[j] * (dz - m1[j] - xh * m2[j]);
+    }
+    st4(dx + p * ld + c, o);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bottleneck merge
+// ------------------------------------------------------------------------------------------------
+struct MergeArgs {
+  int n, h, w, c, mode, c_other;
+  const float* main;
+  const float *mean3, *invstd3, *gamma3, *beta3;
+  const float* drop;
+  const float* other;
+  const float *mean_o, *invstd_o, *gamma_o, *beta_o;
+  const int32_t* idx;
+  const float* alpha;
+};
+
+// pre-activation sum s and (optionally) the BN3 intermediates for element group (p, c..c+3)
+template <int MODE>
+__device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, int64_t p, int c, f32x4& xh3, f32x4& dropv) {
+  const int64_t hw = (int64_t)a.h * a.w;
+  const int n_ = (int)(p / hw);
+  const f32x4 mv = ld4(a.main + p * a.c + c);
+  const f32x4 m = ld4(a.mean3 + c), is = ld4(a.invstd3 + c), g = ld4(a.gamma3 + c), b = ld4(a.beta3 + c);
+  dropv = f32x4{1.f, 1.f, 1.f, 1.f};
+  if (a.drop) dropv = ld4(a.drop + (int64_t)n_ * a.c + c);
+  f32x4 s;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xh3[j] = (mv[j] - m[j]) * is[j];
+    s[j] = (g[j] * xh3[j] + b[j]) * dropv[j];
+  }
+  if (MODE == 0) {
+    s += ld4(a.other + p * a.c + c);
+  } else if (MODE == 1) {
+    if (c < a.c_other) s += ld4(a.other + p * a.c_other + c);
+  } else {
+    const int rem = (int)(p - (int64_t)n_ * hw);
+    const int y = rem / a.w, x = rem % a.w;
+    const int h2 = a.h >> 1, w2 = a.w >> 1;
+    const int64_t q = ((int64_t)n_ * h2 + (y >> 1)) * w2 + (x >> 1);
+    const f32x4 ov = ld4(a.other + q * a.c + c);
+    const f32x4 mo = ld4(a.mean_o + c), iso = ld4(a.invstd_o + c), go = ld4(a.gamma_o + c), bo = ld4(a.beta_o + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = go[j] * ((ov[j] - mo[j]) * iso[j]) + bo[j];
+    if (MODE == 3) {
+      const int4 iv = *reinterpret_cast<const int4*>(a.idx + q * a.c + c);
+      const int flat = (y * a.w + x) * a.c + c;
+      o[0] = (iv.x == flat) ? o[0] : 0.f;
+      o[1] = (iv.y == flat + 1) ? o[1] : 0.f;
+      o[2] = (iv.z == flat + 2) ? o[2] : 0.f;
+      o[3] = (iv.w == flat + 3) ? o[3] : 0.f;
+    }
+    s += o;
+  }
+  return s;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, float* __restrict__ out, int64_t total4, int c4n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    f32x4 xh3, dv;
+    const f32x4 s = merge_sum<MODE>(a, p, c, xh3, dv);
+    const f32x4 al = ld4(a.alpha + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = s[j] > 0.f ? s[j] : al[j] * s[j];
+    st4(out + i * 4, o);
+  }
+}
+
+// backward pass 1: dsum = dout * prelu'(s); partial sums of dz = dsum*drop, dz*xhat3 and dout*min(s,0)
+template <int MODE>
+__global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const float* __restrict__ dout,
+                                                        float* __restrict__ dsum, int64_t npix, int c4n,
+                                                        float* __restrict__ part) {
+  __shared__ f32x4 sm[3 * 256];
+  const int ppi = 256 / c4n;
+  const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  const bool active = pl < ppi;
+  const int c = c4 * 4;
+  f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (active) {
+    const f32x4 al = ld4(a.alpha + c);
+    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
+      f32x4 xh3, dv;
+      const f32x4 s = merge_sum<MODE>(a, p, c, xh3, dv);
+      const f32x4 d = ld4(dout + (p * c4n + c4) * 4);
+      f32x4 ds;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ds[j] = d[j] * (s[j] > 0.f ? 1.f : (s[j] < 0.f ? al[j] : 0.f));
+        const float dz = ds[j] * dv[j];
+        v[0][j] += dz;
+        v[1][j] += dz * xh3[j];
+        v[2][j] += d[j] * (s[j] < 0.f ? s[j] : 0.f);
+      }
+      st4(dsum + (p * c4n + c4) * 4, ds);
+    }
+  }
+  block_reduce_groups<3>(v, sm, c4n, ppi, active);
+  if (threadIdx.x < c4n) {
+    const int cc = c4n * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) st4(part + ((int64_t)blockIdx.x * 3 + k) * cc + threadIdx.x * 4, v[k]);
+  }
+}
+
+// backward pass 2: dmain = gamma3*invstd3 * (dsum*drop - mean(dz) - xhat3*mean(dz*xhat3))
+__global__ __launch_bounds__(256) void merge_bwd_apply(const float* __restrict__ dsum, const float* __restrict__ main,
+                                                       const float* __restrict__ mean3, const float* __restrict__ invstd3,
+                                                       const float* __restrict__ drop, const float* __restrict__ coef,
+                                                       float* __restrict__ dmain, int64_t total4, int c4n, int64_t hw) {
+  const int cc = c4n * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / c4n;
+    const int c = (int)(i % c4n) * 4;
+    const f32x4 ds = ld4(dsum + i * 4), mv = ld4(main + i * 4);
+    const f32x4 m = ld4(mean3 + c), is = ld4(invstd3 + c);
+    const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
+    f32x4 dv = {1.f, 1.f, 1.f, 1.f};
+    if (drop) dv = ld4(drop + (p / hw) * cc + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (mv[j] - m[j]) * is[j];
+      o[j] = k1[j] * (ds[j] * dv[j] - m1[j] - xh * m2[j]);
+    }
+    st4(dmain + i * 4, o);
+  }
+}
+
+// gradient w.r.t. BN_o's output for the upsample (2x2 sum) / unpool (gather at idx) skip branches
+template <int MODE>
+__global__ __launch_bounds__(256) void merge_bwd_other(const float* __restrict__ dsum, const int32_t* __restrict__ idx,
+                                                       float* __restrict__ dother, int n, int h, int w, int c4n,
+                                                       int64_t total4) {
+  const int c = c4n * 4;
+  const int h2 = h >> 1, w2 = w >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int64_t q = i / c4n;
+    const int ch = (int)(i % c4n) * 4;
+    const int x2 = (int)(q % w2);
+    const int64_t t = q / w2;
+    const int y2 = (int)(t % h2);
+    const int n_ = (int)(t / h2);
+    f32x4 o;
+    if (MODE == 2) {
+      const float* base = dsum + (((int64_t)n_ * h + 2 * y2) * w + 2 * x2) * c + ch;
+      o = ld4(base) + ld4(base + c) + ld4(base + (int64_t)w * c) + ld4(base + (int64_t)w * c + c);
+    } else {
+      const int4 iv = *reinterpret_cast<const int4*>(idx + i * 4);
+      const float* base = dsum + (int64_t)n_ * h * w * c;
+      o[0] = base[iv.x];
+      o[1] = base[iv.y];
+      o[2] = base[iv.z];
+      o[3] = base[iv.w];
+    }
+    st4(dother + i * 4, o);
+  }
+}
+
+static inline int ew_blocks(int64_t total4) {
+  int64_t b = ceil_div64(total4, 256 * 4);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+static ssmi_status check_c(int c, const char* who) {
+  SSMI_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, SSMI_E_UNSUPPORTED, "%s: channel count %d must be a multiple of 4 and <= 1024", who, c);
+  return SSMI_OK;
+}
+
+}  // namespace ssmi
+
+using namespace ssmi;
+
+extern "C" {
+
+size_t ssmi_bn_workspace_bytes(int64_t npix, int32_t c) {
+  (void)npix;
+  // partial sums (3 rows per block) + 3 coefficient rows
+  return ((size_t)kMaxRedBlocks * 3 + 3) * (size_t)c * sizeof(float);
+}
+
+ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
+                                int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  ssmi_status s = check_c(c, "bn_train_stats");
+  if (s) return s;
+  SSMI_REQUIRE(x && save_mean && save_invstd && npix > 0 && ld >= c && ld % 4 == 0, SSMI_E_INVALID_ARG, "bn_train_stats: bad argument");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_train_stats: workspace too small");
+  const int c4n = c / 4;
+  const int nb = red_blocks(npix, c4n);
+  float* part = reinterpret_cast<float*>(ws);
+  hipLaunchKernelGGL(bn_stats_partial, dim3(nb), dim3(256), 0, as_stream(stream), x, npix, c4n, ld, part);
+  SSMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_stats_final, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), part, nb, c, npix, eps,
+                     momentum, unbiased_moving, moving_mean, moving_var, save_mean, save_invstd);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_var, int32_t c, float eps,
+                                float* save_mean, float* save_invstd, void* stream) {
+  SSMI_REQUIRE(moving_mean && moving_var && save_mean && save_invstd && c > 0, SSMI_E_INVALID_ARG, "bn_infer_stats: bad argument");
+  hipLaunchKernelGGL(bn_infer_stats_kernel, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), moving_mean, moving_var,
+                     c, eps, save_mean, save_invstd);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_bn_act_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, int32_t act, const float* alpha, float slope, float* y, int64_t npix,
+                            int32_t c, void* stream) {
+  ssmi_status s = check_c(c, "bn_act_fwd");
+  if (s) return s;
+  SSMI_REQUIRE(x && mean && invstd && gamma && beta && y && npix > 0 && ld_x >= c && ld_x % 4 == 0, SSMI_E_INVALID_ARG, "bn_act_fwd: bad argument");
+  SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_fwd: PReLU needs alpha");
+  const int c4n = c / 4;
+  const int64_t total4 = npix * c4n;
+  const int nb = ew_blocks(total4);
+#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, y, total4, c4n)
+  if (act == SSMI_ACT_NONE) L(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L(SSMI_ACT_LEAKY);
+  else { set_error("bn_act_fwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
+#undef L
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                            float* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                            size_t ws_bytes, void* stream) {
+  ssmi_status s = check_c(c, "bn_act_bwd");
+  if (s) return s;
+  SSMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && npix > 0 && ld_x >= c && ld_x % 4 == 0, SSMI_E_INVALID_ARG, "bn_act_bwd: bad argument");
+  SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_bwd: PReLU needs alpha");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_act_bwd: workspace too small");
+  const int c4n = c / 4;
+  const int nb = red_blocks(npix, c4n);
+  float* part = reinterpret_cast<float*>(ws);
+  float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
+  hipStream_t st = as_stream(stream);
+#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<A>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, npix, c4n, part)
+  if (act == SSMI_ACT_NONE) L1(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L1(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L1(SSMI_ACT_LEAKY);
+  else { set_error("bn_act_bwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
+#undef L1
+  SSMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 63) / 64), dim3(64), 0, st, part, nb, c, npix, gamma, invstd, dgamma, dbeta,
+                     act == SSMI_ACT_PRELU ? dalpha : nullptr, coef);
+  SSMI_LAUNCH_CHECK();
+  const int64_t total4 = npix * c4n;
+  const int nb2 = ew_blocks(total4);
+#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, coef, dx, total4, c4n)
+  if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
+#undef L2
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+static ssmi_status fill_merge(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
+                              const float* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
+                              MergeArgs* a) {
+  SSMI_REQUIRE(d && main && bn3 && other && alpha, SSMI_E_INVALID_ARG, "merge: NULL argument");
+  SSMI_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, SSMI_E_SHAPE, "merge: bad shape");
+  ssmi_status s = check_c(d->c, "merge");
+  if (s) return s;
+  SSMI_REQUIRE(d->other_mode >= 0 && d->other_mode <= 3, SSMI_E_INVALID_ARG, "merge: other_mode %d", d->other_mode);
+  if (d->other_mode == 1) SSMI_REQUIRE(d->c_other > 0 && d->c_other % 4 == 0 && d->c_other <= d->c, SSMI_E_SHAPE, "merge: c_other %d", d->c_other);
+  if (d->other_mode >= 2) {
+    SSMI_REQUIRE(d->h % 2 == 0 && d->w % 2 == 0, SSMI_E_SHAPE, "merge: upsampled output must have even height/width");
+    SSMI_REQUIRE(bn_other != nullptr, SSMI_E_INVALID_ARG, "merge: bn_other required for mode %d", d->other_mode);
+  }
+  if (d->other_mode == 3) SSMI_REQUIRE(idx != nullptr, SSMI_E_INVALID_ARG, "merge: idx required for mode 3");
+  SSMI_REQUIRE(bn3->mean && bn3->invstd && bn3->gamma && bn3->beta, SSMI_E_INVALID_ARG, "merge: bn3 incomplete");
+  a->n = d->n; a->h = d->h; a->w = d->w; a->c = d->c; a->mode = d->other_mode; a->c_other = d->c_other;
+  a->main = main; a->mean3 = bn3->mean; a->invstd3 = bn3->invstd; a->gamma3 = bn3->gamma; a->beta3 = bn3->beta;
+  a->drop = drop; a->other = other; a->idx = idx; a->alpha = alpha;
+  a->mean_o = a->invstd_o = a->gamma_o = a->beta_o = nullptr;
+  if (bn_other) { a->mean_o = bn_other->mean; a->invstd_o = bn_other->invstd; a->gamma_o = bn_other->gamma; a->beta_o = bn_other->beta; }
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
+                           const float* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
+                           float* out, void* stream) {
+  MergeArgs a;
+  ssmi_status s = fill_merge(d, main, bn3, drop, other, bn_other, idx, alpha, &a);
+  if (s) return s;
+  SSMI_REQUIRE(out, SSMI_E_INVALID_ARG, "merge_fwd: out is NULL");
+  const int c4n = d->c / 4;
+  const int64_t total4 = (int64_t)d->n * d->h * d->w * c4n;
+  const int nb = ew_blocks(total4);
+#define L(M) hipLaunchKernelGGL((merge_fwd_kernel<M>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, total4, c4n)
+  switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
+#undef L
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+size_t ssmi_merge_workspace_bytes(const ssmi_merge_desc* d) {
+  if (!d) return 0;
+  return ssmi_bn_workspace_bytes(0, d->c);
+}
+
+ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const float* main, const ssmi_bn_params* bn3,
+                           const float* drop, const float* other, const ssmi_bn_params* bn_other, const int32_t* idx,
+                           const float* alpha, float* dmain, float* dsum, float* dother_bn, float* dgamma3,
+                           float* dbeta3, float* dalpha, void* ws, size_t ws_bytes, void* stream) {
+  MergeArgs a;
+  ssmi_status s = fill_merge(d, main, bn3, drop, other, bn_other, idx, alpha, &a);
+  if (s) return s;
+  SSMI_REQUIRE(dout && dmain && dsum, SSMI_E_INVALID_ARG, "merge_bwd: NULL gradient tensor");
+  SSMI_REQUIRE(d->other_mode < 2 || dother_bn, SSMI_E_INVALID_ARG, "merge_bwd: dother_bn required for mode %d", d->other_mode);
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_merge_workspace_bytes(d), SSMI_E_WORKSPACE, "merge_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const int c = d->c, c4n = c / 4;
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const int nb = red_blocks(npix, c4n);
+  float* part = reinterpret_cast<float*>(ws);
+  float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
+#define L(M) hipLaunchKernelGGL((merge_bwd_reduce<M>), dim3(nb), dim3(256), 0, st, a, dout, dsum, npix, c4n, part)
+  switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
+#undef L
+  SSMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 63) / 64), dim3(64), 0, st, part, nb, c, npix, bn3->gamma, bn3->invstd,
+                     dgamma3, dbeta3, dalpha, coef);
+  SSMI_LAUNCH_CHECK();
+  const int64_t total4 = npix * c4n;
+  hipLaunchKernelGGL(merge_bwd_apply, dim3(ew_blocks(total4)), dim3(256), 0, st, dsum, main, bn3->mean, bn3->invstd, drop,
+                     coef, dmain, total4, c4n, (int64_t)d->h * d->w);
+  SSMI_LAUNCH_CHECK();
+  if (d->other_mode >= 2) {
+    const int64_t t4 = (int64_t)d->n * (d->h / 2) * (d->w / 2) * c4n;
+    if (d->other_mode == 2)
+      hipLaunchKernelGGL((merge_bwd_other<2>), dim3(ew_blocks(t4)), dim3(256), 0, st, dsum, idx, dother_bn, d->n, d->h, d->w, c4n, t4);
+    else
+      hipLaunchKernelGGL((merge_bwd_other<3>), dim3(ew_blocks(t4)), dim3(256), 0, st, dsum, idx, dother_bn, d->n, d->h, d->w, c4n, t4);
+    SSMI_LAUNCH_CHECK();
+  }
+  return SSMI_OK;
+}
+
+}  // extern "C"

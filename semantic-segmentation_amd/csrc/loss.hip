@@ -1,0 +1,231 @@
+// Class-weighted sparse softmax cross-entropy fused with its gradient, the prediction argmax and the streaming
+// confusion matrix.  One thread per pixel; the pixel's logits (num_classes floats) are held in registers when
+// num_classes is one of the compiled sizes, otherwise re-read from cache.  HBM-bound: reads logits + label + weight,
+// writes dlogits.
+#include "common.h"
+
+namespace ssmi {
+
+static constexpr int kLossBlocks = 2048;
+
+template <int C>
+struct LogitRegs {
+  float v[C];
+};
+
+// Shared epilogue: block-reduce loss, flush LDS confusion matrix.
+__device__ __forceinline__ void loss_block_finish(float local_loss, int bad, int* cm_lds, int ncls, double* part,
+                                                  int64_t* cm, int32_t* bad_labels) {
+  __shared__ float red[4];
+  const float ws = wave_sum(local_loss);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+  if (cm) {
+    for (int e = threadIdx.x; e < ncls * ncls; e += 256) {
+      const int v = cm_lds[e];
+      if (v) atomicAdd(reinterpret_cast<unsigned long long*>(cm + e), (unsigned long long)v);
+    }
+  }
+  if (bad_labels && bad) atomicAdd(bad_labels, bad);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                   const float* __restrict__ weights, int64_t npix, float inv_npix,
+                                                   float grad_scale, float* __restrict__ dlogits, double* __restrict__ part,
+                                                   int64_t* __restrict__ cm, int64_t npix_metrics, uint64_t ignore_mask,
+                                                   int32_t* __restrict__ pred_out, int32_t* __restrict__ bad_labels) {
+  extern __shared__ int cm_lds[];
+  if (cm) {
+    for (int e = threadIdx.x; e < C * C; e += 256) cm_lds[e] = 0;
+    __syncthreads();
+  }
+  float local = 0.f;
+  int bad = 0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const float* zp = logits + p * C;
+    float z[C];
+    if (C % 4 == 0) {
+#pragma unroll
+      for (int j = 0; j < C / 4; ++j) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(zp + 4 * j);
+        z[4 * j] = t[0]; z[4 * j + 1] = t[1]; z[4 * j + 2] = t[2]; z[4 * j + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < C; ++j) z[j] = zp[j];
+    }
+    float mx = z[0];
+    int am = 0;
+#pragma unroll
+    for (int j = 1; j < C; ++j)
+      if (z[j] > mx) { mx = z[j]; am = j; }
+    float se = 0.f;
+    float e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { e[j] = __expf(z[j] - mx); se += e[j]; }
+    const int lab = labels[p];
+    const bool lv = (unsigned)lab < (unsigned)C;
+    const float wgt = lv ? weights[p] : 0.f;
+    if (!lv) ++bad;
+    float zl = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) zl = (j == lab) ? z[j] : zl;
+    const float lse = mx + __logf(se);
+    local += wgt * (lse - zl);
+    if (dlogits) {
+      const float k = grad_scale * wgt * inv_npix;
+      const float inv = 1.f / se;
+      float* dp = dlogits + p * C;
+      if (C % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) {
+          f32x4 t;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t[q] = k * (e[4 * j + q] * inv - ((4 * j + q) == lab ? 1.f : 0.f));
+          *reinterpret_cast<f32x4*>(dp + 4 * j) = t;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < C; ++j) dp[j] = k * (e[j] * inv - (j == lab ? 1.f : 0.f));
+      }
+    }
+    if (pred_out) pred_out[p] = am;
+    if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
+  }
+  if (cm) __syncthreads();
+  loss_block_finish(local, bad, cm_lds, C, part, cm, bad_labels);
+}
+
+// any class count up to 64: logits re-read three times (served by L1/L2)
+__global__ __launch_bounds__(256) void xent_kernel_generic(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                           const float* __restrict__ weights, int64_t npix, int C,
+                                                           float inv_npix, float grad_scale, float* __restrict__ dlogits,
+                                                           double* __restrict__ part, int64_t* __restrict__ cm,
+                                                           int64_t npix_metrics, uint64_t ignore_mask,
+                                                           int32_t* __restrict__ pred_out, int32_t* __restrict__ bad_labels) {
+  extern __shared__ int cm_lds[];
+  if (cm) {
+    for (int e = threadIdx.x; e < C * C; e += 256) cm_lds[e] = 0;
+    __syncthreads();
+  }
+  float local = 0.f;
+  int bad = 0;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const float* zp = logits + p * C;
+    float mx = zp[0];
+    int am = 0;
+    for (int j = 1; j < C; ++j) {
+      const float v = zp[j];
+      if (v > mx) { mx = v; am = j; }
+    }
+    float se = 0.f;
+    for (int j = 0; j < C; ++j) se += __expf(zp[j] - mx);
+    const int lab = labels[p];
+    const bool lv = (unsigned)lab < (unsigned)C;
+    const float wgt = lv ? weights[p] : 0.f;
+    if (!lv) ++bad;
+    const float zl = lv ? zp[lab] : 0.f;
+    local += wgt * (mx + __logf(se) - zl);
+    if (dlogits) {
+      const float k = grad_scale * wgt * inv_npix;
+      const float inv = 1.f / se;
+      float* dp = dlogits + p * C;
+      for (int j = 0; j < C; ++j) dp[j] = k * (__expf(zp[j] - mx) * inv - (j == lab ? 1.f : 0.f));
+    }
+    if (pred_out) pred_out[p] = am;
+    if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
+  }
+  if (cm) __syncthreads();
+  loss_block_finish(local, bad, cm_lds, C, part, cm, bad_labels);
+}
+
+__global__ void xent_final(const double* __restrict__ part, int nblocks, double inv_npix, float* __restrict__ loss_out) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[b];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss_out = (float)(sm[0] * inv_npix);
+}
+
+}  // namespace ssmi
+
+using namespace ssmi;
+
+extern "C" {
+
+size_t ssmi_softmax_xent_workspace_bytes(int64_t npix) {
+  (void)npix;
+  return (size_t)kLossBlocks * sizeof(double);
+}
+
+ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                      int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
+                                      int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                      int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream) {
+  SSMI_REQUIRE(logits && labels && weights && loss_out && npix > 0, SSMI_E_INVALID_ARG, "softmax_xent: bad argument");
+  SSMI_REQUIRE(num_classes >= 2 && num_classes <= 64, SSMI_E_UNSUPPORTED, "softmax_xent: num_classes %d outside [2,64]", num_classes);
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_softmax_xent_workspace_bytes(npix), SSMI_E_WORKSPACE, "softmax_xent: workspace too small");
+  SSMI_REQUIRE(npix_metrics >= 0 && npix_metrics <= npix, SSMI_E_INVALID_ARG, "softmax_xent: npix_metrics out of range");
+  hipStream_t st = as_stream(stream);
+  int64_t nb64 = ceil_div64(npix, 256);
+  if (nb64 > kLossBlocks) nb64 = kLossBlocks;
+  const int nb = (int)nb64;
+  double* part = reinterpret_cast<double*>(ws);
+  const float inv = (float)(1.0 / (double)npix);
+  const size_t lds = cm ? (size_t)num_classes * num_classes * sizeof(int) : 0;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+  if (num_classes == 24 && aligned) {
+    hipLaunchKernelGGL((xent_kernel<24>), dim3(nb), dim3(256), lds, st, logits, labels, weights, npix, inv, grad_scale,
+                       dlogits, part, cm, npix_metrics, ignore_mask, pred_out, bad_labels);
+  } else {
+    hipLaunchKernelGGL(xent_kernel_generic, dim3(nb), dim3(256), lds, st, logits, labels, weights, npix, num_classes, inv,
+                       grad_scale, dlogits, part, cm, npix_metrics, ignore_mask, pred_out, bad_labels);
+  }
+  SSMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(xent_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, loss_out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_metrics_from_cm(const int64_t* cm, int32_t n, uint64_t ignore_mask, double* out6) {
+  SSMI_REQUIRE(cm && out6 && n >= 1 && n <= 64, SSMI_E_INVALID_ARG, "metrics_from_cm: bad argument");
+  double total = 0, diag = 0;
+  double mpca_tf = 0, iou_sum = 0, iou_all = 0, mpca_s = 0, miou_s = 0;
+  int present = 0, kept = 0;
+  for (int i = 0; i < n; ++i) {
+    double row = 0, colsum = 0;
+    for (int j = 0; j < n; ++j) { row += (double)cm[i * n + j]; colsum += (double)cm[j * n + i]; }
+    const double tp = (double)cm[i * n + i];
+    total += row;
+    diag += tp;
+    const double acc_i = row > 0 ? tp / row : 0.0;
+    mpca_tf += acc_i;
+    const double den = row + colsum - tp;
+    const double iou = tp / (den > 0 ? den : 1.0);
+    if (den > 0) { iou_sum += iou; ++present; }
+    iou_all += iou;
+    if (!((ignore_mask >> i) & 1ull)) {
+      // src/scripts/calculate_metrics_from_cfms.py:24,45 round the numerator to float32, then divide in float64
+      mpca_s += (double)(float)tp / (row > 0 ? row : 1.0);
+      miou_s += (double)(float)tp / (den > 0 ? den : 1.0);
+      ++kept;
+    }
+  }
+  out6[0] = total > 0 ? diag / total : 0.0;
+  out6[1] = mpca_tf / n;
+  out6[2] = present ? iou_sum / present : 0.0;
+  out6[3] = iou_all / n;
+  out6[4] = kept ? mpca_s / kept : 0.0;
+  out6[5] = kept ? miou_s / kept : 0.0;
+  return SSMI_OK;
+}
+
+}  // extern "C"

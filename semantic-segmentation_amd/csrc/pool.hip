@@ -1,0 +1,275 @@
+// MaxPoolingWithArgmax2D / MaxUnpooling2D / nearest upsampling.  Pure HBM streaming kernels: one thread per
+// channel (or group of 4 channels when c % 4 == 0) of an output pixel, consecutive lanes on consecutive channels.
+#include "common.h"
+
+namespace ssmi {
+
+__device__ __forceinline__ f32x4 ld4p(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// generic scalar version (any c): one thread per output element
+__global__ __launch_bounds__(256) void maxpool_argmax_fwd_scalar(const float* __restrict__ x, int n, int h, int w, int c,
+                                                                 int ho, int wo, float* __restrict__ y, int y_ld,
+                                                                 int32_t* __restrict__ idx_i, float* __restrict__ idx_f,
+                                                                 int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    int64_t q = i / c;
+    const int ox = (int)(q % wo);
+    q /= wo;
+    const int oy = (int)(q % ho);
+    const int n_ = (int)(q / ho);
+    const float* base = x + (int64_t)n_ * h * w * c;
+    float best = 0.f;
+    int bi = 0;
+    bool first = true;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh) {
+      const int iy = oy * 2 + dh;
+      if (iy >= h) continue;
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int ix = ox * 2 + dw;
+        if (ix >= w) continue;
+        const int flat = (iy * w + ix) * c + ch;
+        const float v = base[flat];
+        if (first || v > best) { best = v; bi = flat; first = false; }
+      }
+    }
+    y[((int64_t)(n_ * ho + oy) * wo + ox) * y_ld + ch] = best;
+    if (idx_i) idx_i[i] = bi;
+    if (idx_f) idx_f[i] = (float)bi;
+  }
+}
+
+// vector version: c % 4 == 0, y_ld % 4 == 0, even h and w
+__global__ __launch_bounds__(256) void maxpool_argmax_fwd_vec(const float* __restrict__ x, int n, int h, int w, int c4n,
+                                                              float* __restrict__ y, int y_ld, int32_t* __restrict__ idx_i,
+                                                              float* __restrict__ idx_f, int64_t total4) {
+  const int c = c4n * 4;
+  const int ho = h >> 1, wo = w >> 1;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c4n) * 4;
+    int64_t q = i / c4n;
+    const int ox = (int)(q % wo);
+    const int64_t q2 = q / wo;
+    const int oy = (int)(q2 % ho);
+    const int n_ = (int)(q2 / ho);
+    const int f00 = ((2 * oy) * w + 2 * ox) * c + ch;
+    const float* base = x + (int64_t)n_ * h * w * c;
+    const f32x4 v00 = ld4p(base + f00), v01 = ld4p(base + f00 + c), v10 = ld4p(base + f00 + w * c),
+                v11 = ld4p(base + f00 + w * c + c);
+    f32x4 best = v00;
+    int bi[4] = {f00, f00 + 1, f00 + 2, f00 + 3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (v01[j] > best[j]) { best[j] = v01[j]; bi[j] = f00 + c + j; }
+      if (v10[j] > best[j]) { best[j] = v10[j]; bi[j] = f00 + w * c + j; }
+      if (v11[j] > best[j]) { best[j] = v11[j]; bi[j] = f00 + w * c + c + j; }
+    }
+    *reinterpret_cast<f32x4*>(y + q * y_ld + ch) = best;
+    if (idx_i) *reinterpret_cast<int4*>(idx_i + i * 4) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+    if (idx_f) *reinterpret_cast<f32x4*>(idx_f + i * 4) = f32x4{(float)bi[0], (float)bi[1], (float)bi[2], (float)bi[3]};
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_argmax_bwd_kernel(const float* __restrict__ dy, int dy_ld,
+                                                                 const int32_t* __restrict__ idx, int n, int h, int w, int c,
+                                                                 int ho, int wo, float* __restrict__ dx, int accumulate,
+                                                                 int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    int64_t q = i / c;
+    const int ix = (int)(q % w);
+    q /= w;
+    const int iy = (int)(q % h);
+    const int n_ = (int)(q / h);
+    const int64_t o = ((int64_t)n_ * ho + (iy >> 1)) * wo + (ix >> 1);
+    const int flat = (iy * w + ix) * c + ch;
+    const float g = (idx[o * c + ch] == flat) ? dy[o * dy_ld + ch] : 0.f;
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxunpool_scatter_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                                int64_t per_image_in, int64_t per_image_out,
+                                                                float* __restrict__ y, int64_t total, int* __restrict__ bad) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n_ = i / per_image_in;
+    const int64_t f = idx[i];
+    if (f >= 0 && f < per_image_out) atomicAdd(y + n_ * per_image_out + f, x[i]);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxunpool_local_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                              int n, int h, int w, int c, float* __restrict__ y,
+                                                              int64_t total) {
+  // over the OUTPUT [n, 2h, 2w, c]
+  const int H = 2 * h, W = 2 * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    int64_t q = i / c;
+    const int ox = (int)(q % W);
+    q /= W;
+    const int oy = (int)(q % H);
+    const int n_ = (int)(q / H);
+    const int64_t s = (((int64_t)n_ * h + (oy >> 1)) * w + (ox >> 1)) * c + ch;
+    const int flat = (oy * W + ox) * c + ch;
+    y[i] = (idx[s] == flat) ? x[s] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxunpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ idx,
+                                                            int64_t per_image_in, int64_t per_image_out,
+                                                            float* __restrict__ dx, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t n_ = i / per_image_in;
+    const int64_t f = idx[i];
+    dx[i] = (f >= 0 && f < per_image_out) ? dy[n_ * per_image_out + f] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void idx_f32_to_i32_kernel(const float* __restrict__ s, int32_t* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = (int32_t)s[i];
+}
+
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int n, int h, int w, int c,
+                                                           float* __restrict__ y, int64_t total) {
+  const int H = 2 * h, W = 2 * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    int64_t q = i / c;
+    const int ox = (int)(q % W);
+    q /= W;
+    const int oy = (int)(q % H);
+    const int n_ = (int)(q / H);
+    y[i] = x[(((int64_t)n_ * h + (oy >> 1)) * w + (ox >> 1)) * c + ch];
+  }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int n, int h, int w, int c,
+                                                           float* __restrict__ dx, int64_t total) {
+  const int W = 2 * w;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    int64_t q = i / c;
+    const int x_ = (int)(q % w);
+    q /= w;
+    const int y_ = (int)(q % h);
+    const int n_ = (int)(q / h);
+    const float* b = dy + ((((int64_t)n_ * 2 * h + 2 * y_) * W) + 2 * x_) * c + ch;
+    dx[i] = b[0] + b[c] + b[(int64_t)W * c] + b[(int64_t)W * c + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ d, float v, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = v;
+}
+
+static inline int grid_for(int64_t total) {
+  int64_t b = ceil_div64(total, 256 * 4);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace ssmi
+
+using namespace ssmi;
+
+extern "C" {
+
+ssmi_status ssmi_maxpool_argmax_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
+                                    int32_t* idx_i32, float* idx_f32, void* stream) {
+  SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && y_ld >= c, SSMI_E_INVALID_ARG, "maxpool_argmax_fwd: bad argument");
+  SSMI_REQUIRE((int64_t)h * w * c < (int64_t)1 << 31, SSMI_E_UNSUPPORTED, "maxpool_argmax_fwd: per-image index exceeds int32");
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const bool vec = (c % 4 == 0) && (y_ld % 4 == 0) && (h % 2 == 0) && (w % 2 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+  if (vec) {
+    const int64_t total4 = (int64_t)n * ho * wo * (c / 4);
+    hipLaunchKernelGGL(maxpool_argmax_fwd_vec, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, n, h, w, c / 4, y,
+                       y_ld, idx_i32, idx_f32, total4);
+  } else {
+    const int64_t total = (int64_t)n * ho * wo * c;
+    hipLaunchKernelGGL(maxpool_argmax_fwd_scalar, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, ho,
+                       wo, y, y_ld, idx_i32, idx_f32, total);
+  }
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_maxpool_argmax_bwd(const float* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, float* dx, int32_t accumulate, void* stream) {
+  SSMI_REQUIRE(dy && idx && dx && n > 0 && h > 0 && w > 0 && c > 0 && dy_ld >= c, SSMI_E_INVALID_ARG, "maxpool_argmax_bwd: bad argument");
+  const int ho = (h + 1) / 2, wo = (w + 1) / 2;
+  const int64_t total = (int64_t)n * h * w * c;
+  hipLaunchKernelGGL(maxpool_argmax_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, idx, n, h,
+                     w, c, ho, wo, dx, accumulate, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_maxunpool_fwd(const float* x, const int32_t* idx, int32_t n, int32_t h, int32_t w, int32_t c, float* y,
+                               void* stream) {
+  SSMI_REQUIRE(x && idx && y && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "maxunpool_fwd: bad argument");
+  const int64_t pin = (int64_t)h * w * c, pout = pin * 4;
+  SSMI_HIP(hipMemsetAsync(y, 0, (size_t)n * pout * sizeof(float), as_stream(stream)));
+  const int64_t total = (int64_t)n * pin;
+  hipLaunchKernelGGL(maxunpool_scatter_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, idx, pin, pout, y,
+                     total, (int*)nullptr);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_maxunpool_local_fwd(const float* x, const int32_t* idx, int32_t n, int32_t h, int32_t w, int32_t c,
+                                     float* y, void* stream) {
+  SSMI_REQUIRE(x && idx && y && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "maxunpool_local_fwd: bad argument");
+  const int64_t total = (int64_t)n * h * w * c * 4;
+  hipLaunchKernelGGL(maxunpool_local_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, idx, n, h, w, c, y,
+                     total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_maxunpool_bwd(const float* dy, const int32_t* idx, int32_t n, int32_t h, int32_t w, int32_t c,
+                               float* dx, void* stream) {
+  SSMI_REQUIRE(dy && idx && dx && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "maxunpool_bwd: bad argument");
+  const int64_t pin = (int64_t)h * w * c, pout = pin * 4;
+  const int64_t total = (int64_t)n * pin;
+  hipLaunchKernelGGL(maxunpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, idx, pin, pout, dx,
+                     total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_idx_f32_to_i32(const float* src, int32_t* dst, int64_t count, void* stream) {
+  SSMI_REQUIRE(src && dst && count > 0, SSMI_E_INVALID_ARG, "idx_f32_to_i32: bad argument");
+  hipLaunchKernelGGL(idx_f32_to_i32_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), src, dst, count);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, void* stream) {
+  SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "upsample_nn2x_fwd: bad argument");
+  const int64_t total = (int64_t)n * h * w * c * 4;
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, float* dx, void* stream) {
+  SSMI_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "upsample_nn2x_bwd: bad argument");
+  const int64_t total = (int64_t)n * h * w * c;
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, n, h, w, c, dx, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_fill_f32(float* dst, float value, int64_t count, void* stream) {
+  SSMI_REQUIRE(dst && count > 0, SSMI_E_INVALID_ARG, "fill_f32: bad argument");
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), dst, value, count);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+}  // extern "C"

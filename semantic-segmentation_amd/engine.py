@@ -1,0 +1,671 @@
+"""Execution engine: the layer graph of an ENet-style encoder-decoder laid out for one MI355X.
+
+Design (one process per GPU):
+  * all trainable tensors live in ONE flat fp32 arena `theta` (16-byte aligned segments, Keras creation order);
+    gradients, Adam/SGD slots mirror it, so the optimizer is one kernel and the data-parallel all-reduce is a
+    bucketed reduce over a contiguous buffer;
+  * BatchNormalization moving statistics live in a second arena `state`;
+  * activations are NHWC fp32 device buffers allocated once per input shape; every arithmetic op is a call into
+    libssmi.so (HIP, gfx950) on the current HIP stream, so a whole step can be captured into a HIP graph;
+  * blocks are the fused units of the reference's builders (initial block, encoder / decoder bottleneck, logits head):
+    concat / zero-pad / upsample / unpool / add / PReLU / dropout are never materialised on their own.
+
+Reference topology: src/models.py:1054-1319 (ENetNaiveUpsampling), 1360-1628 (ENetMaxUnpooling).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from ._lib import BnParams, ConvDesc, MergeDesc, lib
+
+BN_EPS = 1e-3       # Keras BatchNormalization default
+BN_MOMENTUM = 0.1   # src/models.py:1064 (weight of the OLD moving value)
+ACT_NONE, ACT_PRELU, ACT_LEAKY = 0, 1, 2
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def same_pad(size: int, k: int, stride: int, dil: int = 1) -> Tuple[int, int]:
+    """TF SAME rule -> (out, pad_before)."""
+    k_eff = (k - 1) * dil + 1
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k_eff - size, 0)
+    return out, total // 2
+
+
+# ----------------------------------------------------------------------------------------------------------
+# parameter bookkeeping
+# ----------------------------------------------------------------------------------------------------------
+
+class ParamSpec:
+    __slots__ = ("key", "shape", "trainable", "init", "fan_in", "offset", "size")
+
+    def __init__(self, key, shape, trainable, init, fan_in=0):
+        self.key, self.shape, self.trainable, self.init, self.fan_in = key, tuple(shape), trainable, init, fan_in
+        self.size = int(np.prod(shape))
+        self.offset = -1
+
+
+class ParamStore:
+    """Flat arenas + named views.  Order of registration = Keras layer-creation order (weight order of
+    model.get_weights(): per layer kernel, bias / gamma, beta, moving_mean, moving_variance / alpha)."""
+
+    def __init__(self):
+        self.specs: "OrderedDict[str, ParamSpec]" = OrderedDict()
+        self.n_train = 0
+        self.n_state = 0
+        self.theta = self.grad = self.state = None
+        self.views: Dict[str, torch.Tensor] = {}
+        self.gviews: Dict[str, torch.Tensor] = {}
+
+    def add(self, key, shape, trainable=True, init="zeros", fan_in=0):
+        if key in self.specs:
+            raise ValueError("duplicate weight name: {}".format(key))
+        s = ParamSpec(key, shape, trainable, init, fan_in)
+        if trainable:
+            s.offset = self.n_train
+            self.n_train += (s.size + 3) // 4 * 4
+        else:
+            s.offset = self.n_state
+            self.n_state += (s.size + 3) // 4 * 4
+        self.specs[key] = s
+        return s
+
+    def materialise(self, device):
+        self.theta = torch.zeros(max(self.n_train, 4), dtype=torch.float32, device=device)
+        self.grad = torch.zeros_like(self.theta)
+        self.state = torch.zeros(max(self.n_state, 4), dtype=torch.float32, device=device)
+        for k, s in self.specs.items():
+            arena = self.theta if s.trainable else self.state
+            self.views[k] = arena[s.offset:s.offset + s.size].view(s.shape)
+            if s.trainable:
+                self.gviews[k] = self.grad[s.offset:s.offset + s.size].view(s.shape)
+
+    def trainable_keys(self) -> List[str]:
+        return [k for k, s in self.specs.items() if s.trainable]
+
+    def init_values(self, seed: int):
+        """Keras default initialisers: he_normal for bottleneck/decoder kernels, glorot_uniform for the initial conv,
+        zeros for biases/beta/alpha/moving_mean, ones for gamma/moving_variance."""
+        rng = np.random.RandomState(seed)
+        for k, s in self.specs.items():
+            if s.init == "he_normal":
+                v = rng.standard_normal(s.shape) * np.sqrt(2.0 / s.fan_in)
+            elif s.init == "glorot_uniform":
+                kh, kw, cin, cout = s.shape
+                lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
+                v = rng.uniform(-lim, lim, size=s.shape)
+            elif s.init == "ones":
+                v = np.ones(s.shape)
+            else:
+                v = np.zeros(s.shape)
+            self.views[k].copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# primitive layers (thin objects around one or two C-ABI calls)
+# ----------------------------------------------------------------------------------------------------------
+
+class Conv:
+    """Keras Conv2D.  `transpose=True`: Keras Conv2DTranspose(padding='same', strides=stride); then cin/cout are the
+    transposed layer's own in/out channel counts and the kernel has the Keras layout (kh, kw, out, in)."""
+
+    def __init__(self, store: ParamStore, name, kh, kw, cin, cout, stride=1, dil=1, padding="same", bias=True,
+                 transpose=False, init="he_normal"):
+        self.name, self.kh, self.kw, self.cin, self.cout = name, kh, kw, cin, cout
+        self.stride, self.dil, self.padding, self.transpose = stride, dil, padding, transpose
+        if transpose:
+            store.add(name + "/kernel", (kh, kw, cout, cin), True, init, kh * kw * cin)
+        else:
+            store.add(name + "/kernel", (kh, kw, cin, cout), True, init, kh * kw * cin)
+        self.has_bias = bias
+        if bias:
+            store.add(name + "/bias", (cout,), True, "zeros")
+        self.store = store
+        self.desc = None
+        self.ws_bytes = 0
+
+    def plan(self, n, h, w, x_ld=None, y_ld=None):
+        """(h, w) is the spatial size of this layer's INPUT.  Returns the output (h, w)."""
+        L = lib()
+        d = ConvDesc()
+        if not self.transpose:
+            if self.padding == "same":
+                ho, pt = same_pad(h, self.kh, self.stride, self.dil)
+                wo, pl = same_pad(w, self.kw, self.stride, self.dil)
+            else:
+                ho = (h - ((self.kh - 1) * self.dil + 1)) // self.stride + 1
+                wo = (w - ((self.kw - 1) * self.dil + 1)) // self.stride + 1
+                pt = pl = 0
+            d.n, d.h, d.w, d.cin, d.ho, d.wo, d.cout = n, h, w, self.cin, ho, wo, self.cout
+            d.x_ld = x_ld or self.cin
+            d.y_ld = y_ld or self.cout
+            out_hw = (ho, wo)
+            d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l = self.kh, self.kw, self.stride, self.dil, pt, pl
+            self.ws_bytes = L.conv2d_bwd_weight_workspace_bytes(C.byref(d))
+        else:
+            # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
+            H, W = h * self.stride, w * self.stride
+            ho, pt = same_pad(H, self.kh, self.stride, 1)
+            wo, pl = same_pad(W, self.kw, self.stride, 1)
+            assert (ho, wo) == (h, w)
+            d.n, d.h, d.w, d.cin, d.ho, d.wo, d.cout = n, H, W, self.cout, h, w, self.cin
+            d.x_ld = y_ld or self.cout   # tconv output is the underlying conv's x
+            d.y_ld = x_ld or self.cin
+            out_hw = (H, W)
+            d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l = self.kh, self.kw, self.stride, 1, pt, pl
+            self.ws_bytes = L.conv2d_transpose_bwd_weight_workspace_bytes(C.byref(d))
+        self.desc = d
+        self._dref = C.byref(d)
+        v, g = self.store.views, self.store.gviews
+        self.w, self.dw = v[self.name + "/kernel"], g[self.name + "/kernel"]
+        self.b = v[self.name + "/bias"] if self.has_bias else None
+        self.db = g[self.name + "/bias"] if self.has_bias else None
+        return out_hw
+
+    def fwd(self, x, y, st):
+        L = lib()
+        if self.transpose:
+            L.conv2d_transpose_fwd(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), st)
+        else:
+            L.conv2d_fwd(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), st)
+
+    def bwd_data(self, dy, dx, st, add=None):
+        L = lib()
+        if self.transpose:
+            assert add is None
+            L.conv2d_transpose_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(dx), st)
+        else:
+            L.conv2d_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), st)
+
+    def bwd_weight(self, x, dy, ws, st):
+        L = lib()
+        if self.transpose:
+            L.conv2d_transpose_bwd_weight(self._dref, _ptr(x), _ptr(dy), _ptr(self.dw), _ptr(self.db), _ptr(ws),
+                                          ws.numel() * 4, st)
+        else:
+            L.conv2d_bwd_weight(self._dref, _ptr(x), _ptr(dy), _ptr(self.dw), _ptr(self.db), _ptr(ws), ws.numel() * 4, st)
+
+
+class BatchNorm:
+    """Keras BatchNormalization(momentum=0.1) optionally fused with the PReLU that follows it."""
+
+    def __init__(self, store: ParamStore, name, c, prelu_name=None):
+        self.name, self.c, self.prelu_name = name, c, prelu_name
+        store.add(name + "/gamma", (c,), True, "ones")
+        store.add(name + "/beta", (c,), True, "zeros")
+        store.add(name + "/moving_mean", (c,), False, "zeros")
+        store.add(name + "/moving_variance", (c,), False, "ones")
+        self.store = store
+        self.stats_buf = None
+
+    def add_prelu(self, store, prelu_name):
+        self.prelu_name = prelu_name
+        store.add(prelu_name + "/alpha", (1, 1, self.c), True, "zeros")
+
+    def plan(self, device):
+        v, g = self.store.views, self.store.gviews
+        self.gamma, self.beta = v[self.name + "/gamma"], v[self.name + "/beta"]
+        self.dgamma, self.dbeta = g[self.name + "/gamma"], g[self.name + "/beta"]
+        self.mm, self.mv = v[self.name + "/moving_mean"], v[self.name + "/moving_variance"]
+        self.alpha = self.dalpha = None
+        if self.prelu_name:
+            self.alpha, self.dalpha = v[self.prelu_name + "/alpha"], g[self.prelu_name + "/alpha"]
+        self.stats_buf = torch.zeros(2, self.c, dtype=torch.float32, device=device)
+        self.mean, self.invstd = self.stats_buf[0], self.stats_buf[1]
+        self.params = BnParams(_ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta))
+        self._pref = C.byref(self.params)
+
+    def stats(self, x, npix, ld, training, update_moving, unbiased, ws, st):
+        L = lib()
+        if training:
+            L.bn_train_stats(_ptr(x), npix, self.c, ld, BN_EPS, BN_MOMENTUM, 1 if unbiased else 0,
+                             _ptr(self.mm) if update_moving else None, _ptr(self.mv) if update_moving else None,
+                             _ptr(self.mean), _ptr(self.invstd), _ptr(ws), ws.numel() * 4, st)
+        else:
+            L.bn_infer_stats(_ptr(self.mm), _ptr(self.mv), self.c, BN_EPS, _ptr(self.mean), _ptr(self.invstd), st)
+
+    def act_fwd(self, x, ld, y, npix, st):
+        act = ACT_PRELU if self.alpha is not None else ACT_NONE
+        lib().bn_act_fwd(_ptr(x), ld, _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), act,
+                         _ptr(self.alpha), 0.0, _ptr(y), npix, self.c, st)
+
+    def act_bwd(self, dy, x, ld, dx, npix, ws, st):
+        act = ACT_PRELU if self.alpha is not None else ACT_NONE
+        lib().bn_act_bwd(_ptr(dy), _ptr(x), ld, _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), act,
+                         _ptr(self.alpha), 0.0, _ptr(dx), _ptr(self.dgamma), _ptr(self.dbeta), _ptr(self.dalpha), npix,
+                         self.c, _ptr(ws), ws.numel() * 4, st)
+
+
+class RunCfg:
+    """Per-call switches threaded through the blocks."""
+    __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws")
+
+    def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws):
+        self.training, self.update_moving, self.unbiased_moving = training, update_moving, unbiased_moving
+        self.use_dropout, self.st, self.ws = use_dropout, st, ws
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fused blocks
+# ----------------------------------------------------------------------------------------------------------
+
+class Block:
+    name = ""
+
+    def convs(self) -> List[Conv]:
+        return []
+
+    def dropout(self) -> Optional[Tuple[str, float, int]]:
+        return None
+
+
+class InitialBlock(Block):
+    """conv3x3/s2 (3->13) || maxpool2x2 (3) -> concat(16) [-> BN -> PReLU in the naive variant]
+    (src/models.py:1055-1066 / 1361-1370).  The concat is never materialised separately: both producers write
+    channel slices of one 16-channel buffer."""
+
+    def __init__(self, store, variant):
+        self.name = "initial_block"
+        self.variant = variant
+        self.conv = Conv(store, "initial_block_conv2d", 3, 3, 3, 13, stride=2, padding="same", bias=True,
+                         init="glorot_uniform")
+        self.bn = None
+        if variant == "naive":
+            self.bn = BatchNorm(store, "initial_block_bnorm", 16)
+            self.bn.add_prelu(store, "initial_block_prelu")
+
+    def convs(self):
+        return [self.conv]
+
+    def plan(self, n, h, w, dev):
+        self.n, self.h, self.w = n, h, w
+        self.ho, self.wo = self.conv.plan(n, h, w, x_ld=3, y_ld=16)
+        assert h % 2 == 0 and w % 2 == 0, "input height/width must be even"
+        self.npix = n * self.ho * self.wo
+        self.cat = torch.empty(n, self.ho, self.wo, 16, dtype=torch.float32, device=dev)
+        self.pool_slice = self.cat.view(-1)[13:]
+        self.idx = torch.empty(n, self.ho, self.wo, 3, dtype=torch.int32, device=dev) if self.variant == "unpool" else None
+        if self.bn:
+            self.bn.plan(dev)
+            self.out = torch.empty_like(self.cat)
+            self.dcat = torch.empty_like(self.cat)
+        else:
+            self.out = self.cat
+        return (self.ho, self.wo, 16)
+
+    def fwd(self, x, cfg: RunCfg):
+        L = lib()
+        self.x = x
+        self.conv.fwd(x, self.cat, cfg.st)
+        L.maxpool_argmax_fwd(_ptr(x), self.n, self.h, self.w, 3, _ptr(self.pool_slice), 16, _ptr(self.idx), None, cfg.st)
+        if self.bn:
+            self.bn.stats(self.cat, self.npix, 16, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws, cfg.st)
+            self.bn.act_fwd(self.cat, 16, self.out, self.npix, cfg.st)
+        return self.out
+
+    def bwd(self, dout, cfg: RunCfg):
+        if self.bn:
+            self.bn.act_bwd(dout, self.cat, 16, self.dcat, self.npix, cfg.ws, cfg.st)
+            d = self.dcat
+        else:
+            d = dout
+        self.conv.bwd_weight(self.x, d, cfg.ws, cfg.st)
+        return None  # the images need no gradient
+
+
+class Bottleneck(Block):
+    """Encoder bottleneck (src/models.py:1069-1174 / 1373-1481) and decoder bottleneck (1208-1299 / 1520-1610).
+
+    main : conv1 (1x1, or 2x2/s2 when downsampling) -> BN1+PReLU1 -> conv2 (3x3 | dilated 3x3 | 1x5 then 5x1 |
+           transposed 3x3/s2) -> BN2+PReLU2 -> conv3 (1x1) -> BN3 [-> SpatialDropout2D]
+    other: identity | maxpool2x2 + channel zero-pad | 1x1 conv -> BN -> (nearest upsample | max-unpool)
+    out  : PReLU3(main + other), computed by one fused merge kernel.
+    """
+
+    def __init__(self, store, prefix, cin, cout, kind, variant, downsample=False, upsample=False, asymmetric=0, dilated=0,
+                 dropout_rate=None):
+        self.name = prefix
+        self.cin, self.cout, self.kind, self.variant = cin, cout, kind, variant
+        self.downsample, self.upsample = downsample, upsample
+        internal = cout // 4
+        self.internal = internal
+        s = 2 if downsample else 1
+        self.conv1 = Conv(store, prefix + "_proj_conv2d_1", s, s, cin, internal, stride=s, padding="valid", bias=False)
+        self.bn1 = BatchNorm(store, prefix + "_bnorm_1", internal)
+        self.bn1.add_prelu(store, prefix + "_prelu_1")
+        self.conv2a = None
+        if upsample:
+            self.conv2 = Conv(store, prefix + "_tconv2d_1", 3, 3, internal, internal, stride=2, bias=True, transpose=True)
+        elif asymmetric:
+            self.conv2a = Conv(store, prefix + "_aconv2d_1", 1, asymmetric, internal, internal, bias=False)
+            self.conv2 = Conv(store, prefix + "_aconv2d_2", asymmetric, 1, internal, internal, bias=True)
+        elif dilated:
+            self.conv2 = Conv(store, prefix + "_dconv2d", 3, 3, internal, internal, dil=dilated, bias=True)
+        else:
+            self.conv2 = Conv(store, prefix + "_conv2d_1", 3, 3, internal, internal, bias=True)
+        self.bn2 = BatchNorm(store, prefix + "_bnorm_2", internal)
+        self.bn2.add_prelu(store, prefix + "_prelu_2")
+        self.conv3 = Conv(store, prefix + "_proj_conv2d_2", 1, 1, internal, cout, padding="valid", bias=False)
+        self.conv_o = self.bn_o = None
+        has_other_conv = kind == "dec" and (cin != cout or upsample)
+        if has_other_conv and not upsample:
+            raise NotImplementedError("decoder bottleneck with a projected, non-upsampled skip branch")
+
+        def make_other():
+            self.conv_o = Conv(store, prefix + "_other_conv2d", 1, 1, cin, cout, padding="valid", bias=False)
+            self.bn_o = BatchNorm(store, prefix + "_other_bnorm_1", cout)
+
+        # weight order follows layer creation order in the reference builders
+        if kind == "dec" and variant == "unpool":
+            if has_other_conv:
+                make_other()
+            self.bn3 = BatchNorm(store, prefix + "_bnorm_3", cout)
+        else:
+            self.bn3 = BatchNorm(store, prefix + "_bnorm_3", cout)
+            if has_other_conv:
+                make_other()
+        store.add(prefix + "_prelu_3/alpha", (1, 1, cout), True, "zeros")
+        self.drop_rate = dropout_rate   # None: no SpatialDropout2D layer in this block
+        self.drop_mask = None           # [n, cout] view set by the network
+        if downsample:
+            self.mode = 1
+        elif upsample:
+            self.mode = 2 if variant == "naive" else 3
+        else:
+            self.mode = 0
+
+    def convs(self):
+        return [c for c in (self.conv1, self.conv2a, self.conv2, self.conv3, self.conv_o) if c is not None]
+
+    def dropout(self):
+        if self.drop_rate is None:
+            return None
+        return (self.name + "_sdrop2d_1", self.drop_rate, self.cout)
+
+    def plan(self, n, h, w, dev, unpool_idx=None):
+        """(h, w): input spatial size.  unpool_idx: int32 indices for mode 3."""
+        self.n = n
+        f32 = dict(dtype=torch.float32, device=dev)
+        h1, w1 = self.conv1.plan(n, h, w)
+        h2, w2 = h1, w1
+        if self.conv2a is not None:
+            self.conv2a.plan(n, h1, w1)
+            self.t = torch.empty(n, h1, w1, self.internal, **f32)
+            self.dt = torch.empty_like(self.t)
+        h2, w2 = self.conv2.plan(n, h1, w1)
+        self.conv3.plan(n, h2, w2)
+        self.hin, self.win, self.h1, self.w1, self.ho, self.wo = h, w, h1, w1, h2, w2
+        self.np_in, self.np1, self.np_out = n * h * w, n * h1 * w1, n * h2 * w2
+        i, c = self.internal, self.cout
+        self.y1 = torch.empty(n, h1, w1, i, **f32)
+        self.a1 = torch.empty_like(self.y1)
+        self.y2 = torch.empty(n, h2, w2, i, **f32)
+        self.a2 = torch.empty_like(self.y2)
+        self.y3 = torch.empty(n, h2, w2, c, **f32)
+        self.out = torch.empty_like(self.y3)
+        # gradients
+        self.dy3 = torch.empty_like(self.y3)
+        self.dsum = torch.empty_like(self.y3)
+        self.da2 = torch.empty_like(self.a2)   # reused in place for dy2
+        self.da1 = torch.empty_like(self.a1)   # reused in place for dy1
+        self.dx = torch.empty(n, h, w, self.cin, **f32)
+        for b in (self.bn1, self.bn2, self.bn3):
+            b.plan(dev)
+        self.alpha3 = self.bn3.store.views[self.name + "_prelu_3/alpha"]
+        self.dalpha3 = self.bn3.store.gviews[self.name + "_prelu_3/alpha"]
+        self.pooled = self.idx = self.yo = None
+        if self.mode == 1:
+            self.pooled = torch.empty(n, h2, w2, self.cin, **f32)
+            self.idx = torch.empty(n, h2, w2, self.cin, dtype=torch.int32, device=dev)
+        if self.mode >= 2:
+            self.conv_o.plan(n, h, w)
+            self.bn_o.plan(dev)
+            self.yo = torch.empty(n, h, w, c, **f32)
+            self.dyo_bn = torch.empty_like(self.yo)
+            self.dx_main = torch.empty_like(self.dx)
+            self.unpool_idx = unpool_idx
+            if self.mode == 3:
+                assert unpool_idx is not None and tuple(unpool_idx.shape) == (n, h, w, c), \
+                    "max-unpooling indices {} do not match the skip tensor {}".format(
+                        None if unpool_idx is None else tuple(unpool_idx.shape), (n, h, w, c))
+        md = MergeDesc()
+        md.n, md.h, md.w, md.c, md.other_mode, md.c_other = n, h2, w2, c, self.mode, (self.cin if self.mode == 1 else c)
+        self.md = md
+        self._mref = C.byref(md)
+        return (h2, w2, c)
+
+    def _merge_other(self):
+        if self.mode == 0:
+            return self.x, None, None
+        if self.mode == 1:
+            return self.pooled, None, None
+        return self.yo, self.bn_o._pref, (self.unpool_idx if self.mode == 3 else None)
+
+    def fwd(self, x, cfg: RunCfg):
+        L = lib()
+        st, ws = cfg.st, cfg.ws
+        tr, um, ub = cfg.training, cfg.update_moving, cfg.unbiased_moving
+        self.x = x
+        i = self.internal
+        self.conv1.fwd(x, self.y1, st)
+        self.bn1.stats(self.y1, self.np1, i, tr, um, ub, ws, st)
+        self.bn1.act_fwd(self.y1, i, self.a1, self.np1, st)
+        if self.conv2a is not None:
+            self.conv2a.fwd(self.a1, self.t, st)
+            self.conv2.fwd(self.t, self.y2, st)
+        else:
+            self.conv2.fwd(self.a1, self.y2, st)
+        self.bn2.stats(self.y2, self.np_out, i, tr, um, ub, ws, st)
+        self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
+        self.conv3.fwd(self.a2, self.y3, st)
+        self.bn3.stats(self.y3, self.np_out, self.cout, tr, um, ub, ws, st)
+        if self.mode == 1:
+            L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin,
+                                 _ptr(self.idx), None, st)
+        elif self.mode >= 2:
+            self.conv_o.fwd(x, self.yo, st)
+            self.bn_o.stats(self.yo, self.np_in, self.cout, tr, um, ub, ws, st)
+        other, bn_o, idx = self._merge_other()
+        drop = self.drop_mask if (cfg.use_dropout and self.drop_mask is not None) else None
+        self._drop_used = drop
+        L.merge_fwd(self._mref, _ptr(self.y3), self.bn3._pref, _ptr(drop), _ptr(other), bn_o, _ptr(idx), _ptr(self.alpha3),
+                    _ptr(self.out), st)
+        return self.out
+
+    def bwd(self, dout, cfg: RunCfg):
+        L = lib()
+        st, ws = cfg.st, cfg.ws
+        wsb = ws.numel() * 4
+        i = self.internal
+        other, bn_o, idx = self._merge_other()
+        L.merge_bwd(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o, _ptr(idx),
+                    _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
+                    _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
+        # conv3
+        self.conv3.bwd_weight(self.a2, self.dy3, ws, st)
+        self.conv3.bwd_data(self.dy3, self.da2, st)
+        self.bn2.act_bwd(self.da2, self.y2, i, self.da2, self.np_out, ws, st)      # da2 -> dy2 (in place)
+        # conv2
+        if self.conv2a is not None:
+            self.conv2.bwd_weight(self.t, self.da2, ws, st)
+            self.conv2.bwd_data(self.da2, self.dt, st)
+            self.conv2a.bwd_weight(self.a1, self.dt, ws, st)
+            self.conv2a.bwd_data(self.dt, self.da1, st)
+        else:
+            self.conv2.bwd_weight(self.a1, self.da2, ws, st)
+            self.conv2.bwd_data(self.da2, self.da1, st)
+        self.bn1.act_bwd(self.da1, self.y1, i, self.da1, self.np1, ws, st)         # da1 -> dy1 (in place)
+        # conv1 + skip branch
+        self.conv1.bwd_weight(self.x, self.da1, ws, st)
+        if self.mode == 0:
+            self.conv1.bwd_data(self.da1, self.dx, st, add=self.dsum)
+        elif self.mode == 1:
+            self.conv1.bwd_data(self.da1, self.dx, st)
+            L.maxpool_argmax_bwd(_ptr(self.dsum), self.cout, _ptr(self.idx), self.n, self.hin, self.win, self.cin,
+                                 _ptr(self.dx), 1, st)
+        else:
+            self.conv1.bwd_data(self.da1, self.dx_main, st)
+            self.bn_o.act_bwd(self.dyo_bn, self.yo, self.cout, self.dyo_bn, self.np_in, ws, st)   # -> d(yo) in place
+            self.conv_o.bwd_weight(self.x, self.dyo_bn, ws, st)
+            self.conv_o.bwd_data(self.dyo_bn, self.dx, st, add=self.dx_main)
+        return self.dx
+
+
+class LogitsHead(Block):
+    """Conv2DTranspose(num_classes, 2x2, strides 2) named 'logits' (src/models.py:1311-1317)."""
+
+    def __init__(self, store, cin, num_classes):
+        self.name = "logits"
+        self.conv = Conv(store, "logits", 2, 2, cin, num_classes, stride=2, bias=True, transpose=True)
+        self.num_classes = num_classes
+
+    def convs(self):
+        return [self.conv]
+
+    def plan(self, n, h, w, dev):
+        self.ho, self.wo = self.conv.plan(n, h, w)
+        self.out = torch.empty(n, self.ho, self.wo, self.num_classes, dtype=torch.float32, device=dev)
+        self.dout = torch.empty_like(self.out)
+        self.dx = torch.empty(n, h, w, self.conv.cin, dtype=torch.float32, device=dev)
+        return (self.ho, self.wo, self.num_classes)
+
+    def fwd(self, x, cfg):
+        self.x = x
+        self.conv.fwd(x, self.out, cfg.st)
+        return self.out
+
+    def bwd(self, dout, cfg):
+        self.conv.bwd_weight(self.x, dout, cfg.ws, cfg.st)
+        self.conv.bwd_data(dout, self.dx, cfg.st)
+        return self.dx
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the network
+# ----------------------------------------------------------------------------------------------------------
+
+ENC_PATTERN = [("1", {}), ("2", {"dilated": 2}), ("3", {"asymmetric": 5}), ("4", {"dilated": 4}),
+               ("5", {}), ("6", {"dilated": 8}), ("7", {"asymmetric": 5}), ("8", {"dilated": 16})]
+
+
+class ENetGraph:
+    """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling`."""
+
+    def __init__(self, variant: str, num_classes: int, device="cuda"):
+        assert variant in ("naive", "unpool")
+        self.variant, self.num_classes = variant, num_classes
+        self.device = torch.device(device)
+        st = self.store = ParamStore()
+        B = Bottleneck
+        blocks: List[Block] = [InitialBlock(st, variant)]
+        blocks.append(B(st, "en_bn_1.0", 16, 64, "enc", variant, downsample=True, dropout_rate=0.01))
+        for i in range(4):
+            blocks.append(B(st, "en_bn_1.{}".format(i + 1), 64, 64, "enc", variant, dropout_rate=0.01))
+        blocks.append(B(st, "en_bn_2.0", 64, 128, "enc", variant, downsample=True, dropout_rate=0.1))
+        for stage in (2, 3):
+            for suffix, kw in ENC_PATTERN:
+                blocks.append(B(st, "en_bn_{}.{}".format(stage, suffix), 128, 128, "enc", variant, dropout_rate=0.1, **kw))
+        ddrop = 0.1 if variant == "naive" else None   # the max-unpooling decoder has no dropout (src/models.py:1576-1607)
+        blocks.append(B(st, "de_bn_4.0", 128, 64, "dec", variant, upsample=True, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_4.1", 64, 64, "dec", variant, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_4.2", 64, 64, "dec", variant, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_5.0", 64, 16, "dec", variant, upsample=True, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_5.1", 16, 16, "dec", variant, dropout_rate=ddrop))
+        blocks.append(LogitsHead(st, 16, num_classes))
+        self.blocks = blocks
+        self.by_name = {b.name: b for b in blocks}
+        st.materialise(self.device)
+        self.shape = None
+        self.drop_layers = [b.dropout() for b in blocks if b.dropout() is not None]
+
+    # -- planning -------------------------------------------------------------------------------------
+    def plan(self, n, h, w):
+        if self.shape == (n, h, w):
+            return
+        if h % 16 or w % 16:
+            raise ValueError("input height/width must be multiples of 16 (got {}x{})".format(h, w))
+        dev = self.device
+        L = lib()
+        hh, ww, c = self.blocks[0].plan(n, h, w, dev)
+        for b in self.blocks[1:]:
+            if isinstance(b, Bottleneck):
+                uidx = None
+                if b.mode == 3:
+                    src = self.by_name["en_bn_2.0" if b.name == "de_bn_4.0" else "en_bn_1.0"]
+                    uidx = src.idx   # LIFO index stack of src/models.py:1614,1617
+                hh, ww, c = b.plan(n, hh, ww, dev, unpool_idx=uidx)
+            else:
+                hh, ww, c = b.plan(n, hh, ww, dev)
+        # dropout tables: one arena, grouped by rate so that two launches refresh every table
+        order = sorted(range(len(self.drop_layers)), key=lambda i: self.drop_layers[i][1])
+        total = sum(n * self.drop_layers[i][2] for i in order)
+        self.drop_arena = torch.ones(max(total, 4), dtype=torch.float32, device=dev)
+        self.drop_groups: List[Tuple[float, int, int]] = []   # (rate, offset, count)
+        off = 0
+        self.drop_views: Dict[str, torch.Tensor] = {}
+        for i in order:
+            name, rate, ch = self.drop_layers[i]
+            cnt = n * ch
+            self.drop_views[name] = self.drop_arena[off:off + cnt].view(n, ch)
+            if self.drop_groups and self.drop_groups[-1][0] == rate:
+                r, o, k = self.drop_groups[-1]
+                self.drop_groups[-1] = (r, o, k + cnt)
+            else:
+                self.drop_groups.append((rate, off, cnt))
+            off += cnt
+        for b in self.blocks:
+            d = b.dropout()
+            if d is not None:
+                b.drop_mask = self.drop_views[d[0]]
+        # shared workspace
+        need = L.bn_workspace_bytes(0, 1024)
+        for b in self.blocks:
+            for cv in b.convs():
+                need = max(need, cv.ws_bytes)
+        npix = n * h * w
+        need = max(need, L.softmax_xent_workspace_bytes(npix))
+        self.ws = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
+        self.shape = (n, h, w)
+
+    # -- execution ------------------------------------------------------------------------------------
+    def forward(self, images: torch.Tensor, training: bool, update_moving: bool = True, unbiased_moving: bool = False,
+                use_dropout: Optional[bool] = None, stream: Optional[int] = None):
+        n, h, w, c = images.shape
+        assert c == 3 and images.dtype == torch.float32 and images.is_contiguous()
+        self.plan(n, h, w)
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        cfg = RunCfg(training, update_moving and training, unbiased_moving,
+                     training if use_dropout is None else use_dropout, st, self.ws)
+        x = images
+        for b in self.blocks:
+            x = b.fwd(x, cfg)
+        self._cfg = cfg
+        return x
+
+    def backward(self, dlogits: torch.Tensor):
+        cfg = self._cfg
+        d = dlogits
+        for b in reversed(self.blocks):
+            d = b.bwd(d, cfg)
+
+    def refresh_dropout(self, seed: int, step_block: torch.Tensor, stream: Optional[int] = None):
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        L = lib()
+        for gi, (rate, off, cnt) in enumerate(self.drop_groups):
+            L.dropout_mask(self.drop_arena.data_ptr() + 4 * off, cnt, rate, seed, _ptr(step_block), gi, st)
+
+    @property
+    def logits(self):
+        return self.blocks[-1].out
+
+    @property
+    def dlogits(self):
+        return self.blocks[-1].dout

@@ -1,0 +1,438 @@
+"""ExtendedModel: the training/evaluation engine behind `ModelBase.model`
+(reference: src/keras_extensions/extended_model.py - compile :236-684, predict_on_batch :686-710,
+fit_generator :713-1113, evaluate_generator :1116-1298, reset_metrics :139-157, write_cfm_to_file :115-137).
+
+One `train_on_batch` of the reference is one tf.Session.run (feed -> forward -> loss -> gradients -> optimizer -> BN
+updates -> streaming metric updates -> fetch).  Here the same step is a fixed sequence of libssmi.so kernel launches
+on one HIP stream, captured once per input shape into HIP graphs and replayed:
+
+    segment A : dropout tables, forward, fused loss+gradient+confusion matrix, backward of the late blocks
+    (bucket 1 all-reduce starts here when data-parallel)
+    segment B : backward of the early blocks
+    (bucket 2 all-reduce)
+    segment C : optimizer over the flat arena
+
+Nothing in a step synchronises with the host unless the caller asks for the scalar results.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from collections import OrderedDict
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .._lib import lib
+from ..engine import ENetGraph, _ptr
+from .. import metrics as metrics_mod
+
+
+class LayerInfo:
+    """Keras-style view of one layer: name, trainable flag, weight keys in Keras order."""
+
+    def __init__(self, name, weight_keys):
+        self.name, self.weight_keys, self.trainable = name, list(weight_keys), True
+
+
+class ExtendedModel(object):
+
+    def __init__(self, name: str, graph: ENetGraph, input_shape, num_classes: int, lambda_loss: bool):
+        self.name = name
+        self.graph = graph
+        self.input_shape = tuple(input_shape)
+        self.num_classes = num_classes
+        self.lambda_loss = lambda_loss
+        self.input_names = ["images"] + (["labels", "class_weights", "num_unlabeled"] if lambda_loss else [])
+        self.output_names = (["loss", "logits"] if lambda_loss else ["logits"])
+        self.optimizer = None
+        self.metrics = None
+        self.metrics_names: List[str] = []
+        self.metrics_cfm: List[str] = []
+        self.metrics_streaming: List[str] = []
+        self.metrics_hidden_from_progbar: List[str] = []
+        self.metrics_excluded_from_callbacks: List[str] = []
+        self._metric_fns: List[Callable] = []
+        self.stop_training = False
+        self.seed = 14874
+        self.unbiased_moving_variance = False
+        self.use_hip_graph = True
+        self.grad_sync = None          # trainers.GradientBucketReducer when data-parallel
+        self._bufs_shape = None
+        self._graphs: Dict[tuple, list] = {}
+        self._cm = None
+        self._ignore_bits = 0
+        self._compiled = False
+        # Keras layer list (weights grouped per layer, creation order)
+        per_layer: "OrderedDict[str, list]" = OrderedDict()
+        for key in graph.store.specs:
+            lname = key.rsplit("/", 1)[0]
+            per_layer.setdefault(lname, []).append(key)
+        self.layers = [LayerInfo(n, ks) for n, ks in per_layer.items()]
+
+    # ------------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------------
+    def weight_names(self) -> List[str]:
+        return list(self.graph.store.specs.keys())
+
+    def get_weights(self) -> List[np.ndarray]:
+        v = self.graph.store.views
+        return [v[k].detach().cpu().numpy().copy() for k in self.graph.store.specs]
+
+    def set_weights(self, weights: Sequence[np.ndarray]):
+        specs = self.graph.store.specs
+        if len(weights) != len(specs):
+            raise ValueError('You called `set_weights(weights)` on model "{}" with a weight list of length {}, but the '
+                             'model was expecting {} weights.'.format(self.name, len(weights), len(specs)))
+        for (k, s), w in zip(specs.items(), weights):
+            w = np.asarray(w)
+            if tuple(w.shape) != s.shape:
+                raise ValueError('Layer weight shape {} not compatible with provided weight shape {} ({})'.format(
+                    s.shape, tuple(w.shape), k))
+            self.graph.store.views[k].copy_(torch.from_numpy(np.ascontiguousarray(w, dtype=np.float32)))
+
+    def get_weights_dict(self) -> "OrderedDict[str, np.ndarray]":
+        return OrderedDict(zip(self.weight_names(), self.get_weights()))
+
+    def set_weights_dict(self, d):
+        self.set_weights([d[k] for k in self.weight_names()])
+
+    def save_weights(self, filepath, overwrite=True):
+        """Weights by Keras name ('layer/kernel', ...) in a .npz container (h5py is not available on this platform)."""
+        if os.path.exists(filepath) and not overwrite:
+            raise IOError("{} exists".format(filepath))
+        np.savez(filepath, **{k.replace("/", "::"): v for k, v in self.get_weights_dict().items()})
+
+    def load_weights(self, filepath, by_name=False):
+        with np.load(filepath, allow_pickle=False) as z:
+            d = {k.replace("::", "/"): z[k] for k in z.files}
+        if by_name:
+            cur = self.get_weights_dict()
+            cur.update({k: v for k, v in d.items() if k in cur})
+            d = cur
+        self.set_weights_dict(d)
+
+    def count_params(self):
+        return sum(s.size for s in self.graph.store.specs.values())
+
+    # ------------------------------------------------------------------------------------------------
+    # compile
+    # ------------------------------------------------------------------------------------------------
+    def compile(self, optimizer, loss=None, metrics=None, loss_weights=None, **kwargs):
+        """Keeps the reference's argument shapes.  `loss` / `loss_weights` dictionaries of the supervised trainer
+        ({'loss': dummy_loss, 'logits': 0*y_pred}, {'loss': 1, 'logits': 0}; src/trainers.py:2436-2440) select the
+        in-graph lambda loss, which is what the fused kernel computes; other combinations are rejected."""
+        if not self.lambda_loss:
+            raise NotImplementedError("compile() for training needs a model built with a lambda loss type")
+        if isinstance(loss_weights, dict):
+            if float(loss_weights.get("loss", 1.0)) != 1.0 or float(loss_weights.get("logits", 0.0)) != 0.0:
+                raise NotImplementedError("only loss_weights {'loss': 1, 'logits': 0} are supported")
+        self.optimizer = optimizer
+        optimizer.bind(self.graph.store)
+        self.loss = loss
+        self.loss_weights = loss_weights
+        self.metrics = metrics
+        fns: List[Callable] = []
+        if isinstance(metrics, dict):
+            for out_name, lst in metrics.items():
+                if out_name != "logits":
+                    raise ValueError("metrics can only be attached to the 'logits' output")
+                fns.extend(lst)
+        elif metrics:
+            fns.extend(metrics)
+        self._metric_fns = fns
+        self.metrics_names = ["loss", "loss_loss", "logits_loss"]
+        ignore = None
+        for fn in fns:
+            nm = "logits_" + fn.__name__
+            self.metrics_names.append(nm)
+            if getattr(fn, "streaming", False):
+                self.metrics_streaming.append(nm)
+            if getattr(fn, "cfm", False):
+                self.metrics_cfm.append(nm)
+            if getattr(fn, "hide_from_progbar", False):
+                self.metrics_hidden_from_progbar.append(nm)
+            if getattr(fn, "exclude_from_callbacks", False):
+                self.metrics_excluded_from_callbacks.append(nm)
+            ic = tuple(sorted(getattr(fn, "ignore_classes", []) or []))
+            if ignore is not None and ic != ignore:
+                raise NotImplementedError("all metrics must share the same ignore_classes")
+            ignore = ic
+        self._ignore_classes = list(ignore or [])
+        self._ignore_bits = metrics_mod.ignore_mask_bits(self._ignore_classes)
+        dev = self.graph.device
+        self._cm = torch.zeros(self.num_classes, self.num_classes, dtype=torch.int64, device=dev) if fns else None
+        self._loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._compiled = True
+        self._graphs.clear()
+
+    @property
+    def using_cfm_metric(self):
+        return len(self.metrics_cfm) > 0
+
+    def reset_metrics(self):
+        """extended_model.py:139-157: zero the streaming state at epoch boundaries."""
+        if self._cm is not None:
+            self._cm.zero_()
+
+    def write_cfm_to_file(self, epoch, cfm_key, cfm, file_path=None, log_folder_path=None):
+        if file_path is None:
+            if log_folder_path is None:
+                return
+            file_path = os.path.join(log_folder_path, 'cfms/', '{}_{}.txt'.format(cfm_key, epoch))
+        os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
+        np.savetxt(file_path, X=cfm)
+
+    # ------------------------------------------------------------------------------------------------
+    # batch staging
+    # ------------------------------------------------------------------------------------------------
+    def _ensure_buffers(self, n, h, w):
+        if self._bufs_shape == (n, h, w):
+            return
+        dev = self.graph.device
+        self.images_buf = torch.zeros(n, h, w, 3, dtype=torch.float32, device=dev)
+        self.labels_buf = torch.zeros(n, h, w, dtype=torch.int32, device=dev)
+        self.weights_buf = torch.zeros(n, h, w, dtype=torch.float32, device=dev)
+        self.graph.plan(n, h, w)
+        self._bufs_shape = (n, h, w)
+        self._graphs.clear()
+
+    @staticmethod
+    def _to_dev(dst: torch.Tensor, src):
+        if torch.is_tensor(src):
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        else:
+            a = np.ascontiguousarray(src).reshape(tuple(dst.shape))
+            dst.copy_(torch.from_numpy(a).to(dst.dtype), non_blocking=True)
+
+    def set_batch(self, x):
+        """Stage one batch [images, labels, class_weights, num_unlabeled] (numpy or torch) into the static device
+        buffers the captured graphs read."""
+        images = x[0]
+        n, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        self._ensure_buffers(n, h, w)
+        self._to_dev(self.images_buf, images)
+        if self.lambda_loss and len(x) > 1:
+            self._to_dev(self.labels_buf, x[1])
+            self._to_dev(self.weights_buf, x[2])
+            nu = x[3]
+            nu = int(nu.reshape(-1)[0].item() if torch.is_tensor(nu) else np.asarray(nu).reshape(-1)[0])
+            if nu != 0:
+                # src/losses.py:327-329,369 slices only the weights; logits/labels keep the full batch, so the
+                # reference's own graph is shape-inconsistent for num_unlabeled > 0 in the supervised loss
+                raise ValueError("the supervised lambda loss requires num_unlabeled == 0")
+
+    # ------------------------------------------------------------------------------------------------
+    # step construction
+    # ------------------------------------------------------------------------------------------------
+    def _segments(self, training: bool) -> List[Callable[[int], None]]:
+        g = self.graph
+        L = lib()
+        n, h, w = self._bufs_shape
+        npix = n * h * w
+        C_ = self.num_classes
+
+        def loss_call(st, want_grad):
+            L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npix, C_, 1.0,
+                                   _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), _ptr(self._cm), npix,
+                                   self._ignore_bits, None, _ptr(self._bad), _ptr(g.ws), g.ws.numel() * 4, st)
+
+        if not training:
+            def seg_eval(st):
+                g.forward(self.images_buf, training=False, stream=st)
+                loss_call(st, False)
+            return [seg_eval]
+
+        split = self._split_index()
+        blocks = g.blocks
+
+        def seg_a(st):
+            if g.drop_groups:
+                g.refresh_dropout(self.seed, self.optimizer.step_block, stream=st)
+            g.forward(self.images_buf, training=True, update_moving=True, unbiased_moving=self.unbiased_moving_variance,
+                      stream=st)
+            loss_call(st, True)
+            d = g.dlogits
+            for b in reversed(blocks[split:]):
+                d = b.bwd(d, g._cfg)
+            self._d_mid = d
+
+        def seg_b(st):
+            d = self._d_mid
+            for b in reversed(blocks[:split]):
+                d = b.bwd(d, g._cfg)
+
+        def seg_c(st):
+            scale = 1.0 / self.grad_sync.world_size if self.grad_sync is not None else 1.0
+            self.optimizer.apply(grad_scale=scale, stream=st)
+
+        return [seg_a, seg_b, seg_c]
+
+    def _split_index(self) -> int:
+        """Backward is cut in front of en_bn_2.0: the late blocks hold ~95 % of the parameters, the early blocks the
+        high-resolution (slow) backward work that hides the first bucket's all-reduce."""
+        for i, b in enumerate(self.graph.blocks):
+            if b.name == "en_bn_2.0":
+                return i
+        return len(self.graph.blocks) // 2
+
+    def bucket_ranges(self):
+        """[(lo, hi)] element ranges of the gradient arena, in the order they become final during backward."""
+        st = self.graph.store
+        split_block = self.graph.blocks[self._split_index()]
+        first_key = split_block.convs()[0].name + "/kernel"
+        cut = st.specs[first_key].offset
+        return [(cut, st.theta.numel()), (0, cut)]
+
+    def _run(self, training: bool):
+        key = (training, self._bufs_shape, self.grad_sync is not None)
+        stream = torch.cuda.current_stream()
+        st = stream.cuda_stream
+        segs = self._segments(training)
+        hooks = self._hooks(training)
+        if not self.use_hip_graph or st == 0:
+            for s, hk in zip(segs, hooks):
+                s(st)
+                hk()
+            return
+        L = lib()
+        if key not in self._graphs:
+            # one eager pass first (plans buffers, warms up), then capture each segment
+            glist = []
+            for s in segs:
+                L.graph_begin_capture(st)
+                try:
+                    s(st)
+                finally:
+                    h = C.c_void_p()
+                    L.graph_end_capture(st, C.byref(h))
+                glist.append(h)
+            self._graphs[key] = glist
+        for h, hk in zip(self._graphs[key], hooks):
+            L.graph_launch(h, st)
+            hk()
+
+    def _hooks(self, training):
+        if not training:
+            return [lambda: None]
+        if self.grad_sync is None:
+            return [lambda: None, lambda: None, lambda: None]
+        rs = self.bucket_ranges()
+        gs = self.grad_sync
+        grad = self.graph.store.grad
+        return [lambda: gs.start(grad, rs[0]), lambda: (gs.start(grad, rs[1]), gs.finish()), lambda: None]
+
+    # ------------------------------------------------------------------------------------------------
+    # Keras-shaped batch API
+    # ------------------------------------------------------------------------------------------------
+    def _results(self):
+        loss = float(self._loss_buf.item())
+        bad = int(self._bad.item())
+        if bad:
+            self._bad.zero_()
+            raise ValueError("{} label values outside [0, {})".format(bad, self.num_classes))
+        out = [loss, loss, 0.0]
+        if self._metric_fns:
+            cm = self._cm.cpu().numpy()
+            for fn in self._metric_fns:
+                out.append(fn.value_from_cm(cm))
+        return out
+
+    def train_step_async(self):
+        """One optimisation step on the staged batch; returns nothing and does not synchronise."""
+        if not self._compiled:
+            raise RuntimeError("compile() the model before training")
+        self._run(True)
+
+    def train_on_batch(self, x, y=None, sample_weight=None, class_weight=None):
+        """Keras Model.train_on_batch: returns [total_loss, loss_loss, logits_loss, *metrics] (metrics_names order)."""
+        if not self._compiled:
+            raise RuntimeError("compile() the model before training")
+        self.set_batch(x)
+        self._run(True)
+        return self._results()
+
+    def test_on_batch(self, x, y=None, sample_weight=None):
+        if not self._compiled:
+            raise RuntimeError("compile() the model before evaluating")
+        self.set_batch(x)
+        self._run(False)
+        return self._results()
+
+    def predict_on_batch(self, x, use_training_phase_layers=False):
+        """extended_model.py:686-710: logits for a batch; with use_training_phase_layers the BN/dropout layers run in
+        their training phase (no moving-average updates, as in a Keras predict function)."""
+        images = x[0] if isinstance(x, (list, tuple)) else x
+        n, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        self._ensure_buffers(n, h, w)
+        self._to_dev(self.images_buf, images)
+        st = torch.cuda.current_stream().cuda_stream
+        if use_training_phase_layers and self.graph.drop_groups:
+            blk = self.optimizer.step_block if self.optimizer is not None else None
+            self.graph.refresh_dropout(self.seed + 1, blk, stream=st)
+        self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
+        return self.graph.logits.detach().cpu().numpy()
+
+    def predict(self, x, batch_size=None, verbose=0):
+        images = x[0] if isinstance(x, (list, tuple)) else x
+        bs = batch_size or int(images.shape[0])
+        outs = [self.predict_on_batch(images[i:i + bs]) for i in range(0, int(images.shape[0]), bs)]
+        return np.concatenate(outs, axis=0)
+
+    # ------------------------------------------------------------------------------------------------
+    # generator loops (host side; extended_model.py:947-1093, 1223-1298)
+    # ------------------------------------------------------------------------------------------------
+    def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, validation_data=None,
+                      validation_steps=None, initial_epoch=0, trainer=None, random_seed=None, **kwargs):
+        history = []
+        step_index = initial_epoch * steps_per_epoch
+        get = generator.__next__ if hasattr(generator, "__next__") else None
+        for epoch in range(initial_epoch, epochs):
+            self.reset_metrics()
+            logs = {}
+            for b in range(steps_per_epoch):
+                batch = get() if get else generator.get_batch(epoch, b)
+                x, y = batch[0], batch[1]
+                if trainer is not None:
+                    x, y = trainer.modify_batch_data(step_index, x, y, validation=False)
+                outs = self.train_on_batch(x, y)
+                if trainer is not None:
+                    trainer.on_batch_end(step_index)
+                step_index += 1
+                logs = dict(zip(self.metrics_names, outs))
+            if validation_data is not None:
+                val = self.evaluate_generator(validation_data, validation_steps, trainer=trainer, validation=True)
+                logs.update({"val_" + k: v for k, v in zip(self.metrics_names, val)})
+            history.append(logs)
+            self.reset_metrics()
+            if trainer is not None:
+                trainer.on_epoch_end(epoch, step_index, logs)
+            if self.stop_training:
+                break
+        if trainer is not None:
+            trainer.on_training_end()
+        return history
+
+    def evaluate_generator(self, generator, steps, trainer=None, validation=False, **kwargs):
+        """Aggregation of extended_model.py:1279-1298: streaming metrics take the last batch's (cumulative) value,
+        the others a batch-size weighted average."""
+        self.reset_metrics()
+        get = generator.__next__ if hasattr(generator, "__next__") else None
+        all_outs, sizes = [], []
+        for b in range(steps):
+            batch = get() if get else generator.get_batch(0, b)
+            x, y = batch[0], batch[1]
+            if trainer is not None:
+                x, y = trainer.modify_batch_data(b, x, y, validation=validation)
+            all_outs.append(self.test_on_batch(x, y))
+            sizes.append(int(x[0].shape[0]))
+        res = []
+        for i, nm in enumerate(self.metrics_names):
+            if nm in self.metrics_streaming:
+                res.append(all_outs[-1][i])
+            else:
+                res.append(float(np.average([o[i] for o in all_outs], weights=sizes)))
+        return res

@@ -1,0 +1,101 @@
+"""Loss functions with the call shapes of the reference's src/losses.py, computed by libssmi.so.
+
+Tensors are float32/int32 CUDA (ROCm) torch tensors in NHWC; each function returns a 0-d CUDA float tensor.
+The fused kernel also produces the logits gradient; `last_gradient()` hands it to callers that drive their own
+backward pass (the model engine does this internally).
+"""
+from __future__ import annotations
+
+from enum import Enum
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import lib
+
+
+class ModelLambdaLossType(Enum):
+    """src/losses.py:11-22."""
+    NONE = 0
+    SEGMENTATION_CATEGORICAL_CROSS_ENTROPY = 1
+    SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER = 2
+    SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL = 3
+    SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL = 4
+    CLASSIFICATION_CATEGORICAL_CROSS_ENTROPY = 5
+    CLASSIFICATION_SEMI_SUPERVISED_MEAN_TEACHER = 6
+
+
+_last = {}
+
+
+def last_gradient() -> Optional[torch.Tensor]:
+    """d(loss)/d(logits) of the most recent loss call on this process."""
+    return _last.get("dlogits")
+
+
+def _xent(logits: torch.Tensor, labels: torch.Tensor, weights: torch.Tensor, want_grad=True):
+    if logits.dim() != 4:
+        raise ValueError("y_pred must have rank 4 (BxHxWxC), got rank {}".format(logits.dim()))
+    if labels.dim() != 3 or weights.dim() != 3:
+        raise ValueError("y_true and weights must have rank 3 (BxHxW)")
+    if tuple(labels.shape) != tuple(logits.shape[:3]) or tuple(weights.shape) != tuple(labels.shape):
+        raise ValueError("shape mismatch: logits {}, labels {}, weights {}".format(
+            tuple(logits.shape), tuple(labels.shape), tuple(weights.shape)))
+    if not logits.is_cuda:
+        raise RuntimeError("the loss runs on the GPU only (libssmi.so); got a CPU tensor")
+    L = lib()
+    logits = logits.contiguous().float()
+    labels = labels.contiguous().to(torch.int32)
+    weights = weights.contiguous().float()
+    npix = labels.numel()
+    C = logits.shape[-1]
+    ws = torch.empty(L.softmax_xent_workspace_bytes(npix) // 4 + 4, dtype=torch.float32, device=logits.device)
+    loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    st = torch.cuda.current_stream().cuda_stream
+    L.softmax_xent_fwd_bwd(logits.data_ptr(), labels.data_ptr(), weights.data_ptr(), npix, C, 1.0,
+                           None if dl is None else dl.data_ptr(), loss.data_ptr(), None, 0, 0, None, None,
+                           ws.data_ptr(), ws.numel() * 4, st)
+    _last["dlogits"] = dl
+    return loss
+
+
+def dummy_loss(y_true, y_pred):
+    """src/losses.py:222-236: passes the lambda-loss layer's output through."""
+    return y_pred
+
+
+def _preprocess_segmentation_lambda_loss_args(args, num_expected_args):
+    """src/losses.py:310-331."""
+    if len(args) != num_expected_args:
+        raise ValueError('Expected {} arguments, got: {} ({})'.format(num_expected_args, len(args), args))
+    y_pred, y_true, weights, num_unlabeled = args[0], args[1], args[2], args[3]
+    if y_pred.dim() != 4 or y_true.dim() != 3 or weights.dim() != y_true.dim() or num_unlabeled.dim() != 2:
+        raise ValueError("rank mismatch: y_pred 4, y_true 3, weights 3, num_unlabeled 2 expected")
+    nu = int(num_unlabeled.reshape(-1)[0].item())
+    num_labeled = y_true.shape[0] - nu
+    return y_pred, y_true, weights[0:num_labeled], nu, num_labeled
+
+
+def segmentation_categorical_cross_entropy_lambda_loss(args):
+    """src/losses.py:341-374.  args = [logits BxHxWxC, labels BxHxW int32, weights BxHxW, num_unlabeled Bx1 int32].
+    As in the reference the labels/logits are not sliced, so num_unlabeled must be 0 for the shapes to agree."""
+    y_pred, y_true, weights, num_unlabeled, num_labeled = _preprocess_segmentation_lambda_loss_args(args, 4)
+    return _xent(y_pred, y_true, weights)
+
+
+def segmentation_sparse_weighted_categorical_cross_entropy(class_weights):
+    """src/losses.py:334-338 (+268-307): y_true BxHxWx1, per-pixel weights = class_weights[y_true]."""
+    if class_weights is None:
+        raise ValueError('Class weights is None. Use a numpy array of ones instead of None.')
+    cw_host = np.asarray(class_weights, dtype=np.float32)
+
+    def loss(y_true, y_pred):
+        if y_pred.dim() != 4 or y_true.dim() != 4:
+            raise ValueError("y_true and y_pred must have rank 4")
+        lab = y_true.squeeze(-1).to(torch.int64)
+        cw = torch.from_numpy(cw_host).to(y_pred.device)
+        return _xent(y_pred, lab.to(torch.int32), cw[lab])
+
+    return loss
