@@ -6,7 +6,7 @@
 
 namespace ssmi {
 
-static constexpr int kMaxRedBlocks = 1024;
+static constexpr int kMaxRedBlocks = 512;
 
 static inline int red_blocks(int64_t npix, int c4) {
   const int ppi = 256 / c4;
@@ -62,20 +62,45 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   }
 }
 
-__global__ void bn_stats_final(const float* __restrict__ part, int nblocks, int c, int64_t npix, float eps,
-                               float momentum, int unbiased, float* __restrict__ moving_mean,
-                               float* __restrict__ moving_var, float* __restrict__ save_mean,
-                               float* __restrict__ save_invstd) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s += (double)part[((int64_t)b * 2 + 0) * c + ch];
-    ss += (double)part[((int64_t)b * 2 + 1) * c + ch];
+// Sums NR rows of per-block partials for 8 channels per block: thread (chl = tid & 7, slice = tid >> 3) adds the blocks
+// slice, slice+32, ... in double, then the 32 slices are combined through LDS.  Result valid for tid < 8.
+template <int NR>
+__device__ __forceinline__ void final_reduce(const float* __restrict__ part, int nblocks, int c, int ch, double (&out)[NR]) {
+  __shared__ double sm[NR][256];
+  const int slice = threadIdx.x >> 3;
+  double acc[NR];
+#pragma unroll
+  for (int k = 0; k < NR; ++k) acc[k] = 0.0;
+  if (ch < c) {
+    for (int b = slice; b < nblocks; b += 32) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) acc[k] += (double)part[((int64_t)b * NR + k) * c + ch];
+    }
   }
+#pragma unroll
+  for (int k = 0; k < NR; ++k) sm[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 8) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      double s = 0.0;
+      for (int q = 0; q < 32; ++q) s += sm[k][q * 8 + threadIdx.x];
+      out[k] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ part, int nblocks, int c, int64_t npix,
+                                                      float eps, float momentum, int unbiased,
+                                                      float* __restrict__ moving_mean, float* __restrict__ moving_var,
+                                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
+  double r[2];
+  final_reduce<2>(part, nblocks, c, ch, r);
+  if (threadIdx.x >= 8 || ch >= c) return;
   const double n = (double)npix;
-  const double mean = s / n;
-  double var = ss / n - mean * mean;
+  const double mean = r[0] / n;
+  double var = r[1] / n - mean * mean;
   if (var < 0.0) var = 0.0;
   save_mean[ch] = (float)mean;
   save_invstd[ch] = (float)(1.0 / sqrt(var + (double)eps));
@@ -167,24 +192,20 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict
 }
 
 // finalize: parameter gradients + coefficients for the apply pass: coef[0]=gamma*invstd, coef[1]=mean(dz), coef[2]=mean(dz*xhat)
-__global__ void bn_bwd_final(const float* __restrict__ part, int nblocks, int c, int64_t npix,
-                             const float* __restrict__ gamma, const float* __restrict__ invstd,
-                             float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dalpha,
-                             float* __restrict__ coef) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
-  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s0 += (double)part[((int64_t)b * 3 + 0) * c + ch];
-    s1 += (double)part[((int64_t)b * 3 + 1) * c + ch];
-    s2 += (double)part[((int64_t)b * 3 + 2) * c + ch];
-  }
-  if (dbeta) dbeta[ch] = (float)s0;
-  if (dgamma) dgamma[ch] = (float)s1;
-  if (dalpha) dalpha[ch] = (float)s2;
+__global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ part, int nblocks, int c, int64_t npix,
+                                                    const float* __restrict__ gamma, const float* __restrict__ invstd,
+                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                    float* __restrict__ dalpha, float* __restrict__ coef) {
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
+  double r[3];
+  final_reduce<3>(part, nblocks, c, ch, r);
+  if (threadIdx.x >= 8 || ch >= c) return;
+  if (dbeta) dbeta[ch] = (float)r[0];
+  if (dgamma) dgamma[ch] = (float)r[1];
+  if (dalpha) dalpha[ch] = (float)r[2];
   coef[ch] = gamma[ch] * invstd[ch];
-  coef[c + ch] = (float)(s0 / (double)npix);
-  coef[2 * c + ch] = (float)(s1 / (double)npix);
+  coef[c + ch] = (float)(r[0] / (double)npix);
+  coef[2 * c + ch] = (float)(r[1] / (double)npix);
 }
 
 template <int ACT>
@@ -414,7 +435,7 @@ ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb), dim3(256), 0, as_stream(stream), x, npix, c4n, ld, part);
   SSMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final, dim3((c + 63) / 64), dim3(64), 0, as_stream(stream), part, nb, c, npix, eps,
+  hipLaunchKernelGGL(bn_stats_final, dim3((c + 7) / 8), dim3(256), 0, as_stream(stream), part, nb, c, npix, eps,
                      momentum, unbiased_moving, moving_mean, moving_var, save_mean, save_invstd);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
@@ -466,7 +487,7 @@ ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const
   else { set_error("bn_act_bwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L1
   SSMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 63) / 64), dim3(64), 0, st, part, nb, c, npix, gamma, invstd, dgamma, dbeta,
+  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 7) / 8), dim3(256), 0, st, part, nb, c, npix, gamma, invstd, dgamma, dbeta,
                      act == SSMI_ACT_PRELU ? dalpha : nullptr, coef);
   SSMI_LAUNCH_CHECK();
   const int64_t total4 = npix * c4n;
@@ -543,7 +564,7 @@ ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const fl
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
   SSMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 63) / 64), dim3(64), 0, st, part, nb, c, npix, bn3->gamma, bn3->invstd,
+  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 7) / 8), dim3(256), 0, st, part, nb, c, npix, bn3->gamma, bn3->invstd,
                      dgamma3, dbeta3, dalpha, coef);
   SSMI_LAUNCH_CHECK();
   const int64_t total4 = npix * c4n;

@@ -22,19 +22,42 @@ static Geo to_geo(const ssmi_conv_desc* d) {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
+// All operand loads are raw buffer loads: the descriptor carries the tensor's byte size, and a lane that must read a
+// zero (padding, tile tail, masked channel) simply passes an out-of-range offset - the hardware bounds check returns 0.
+// This keeps every load unconditional, so they issue back to back and overlap (a `valid ? load : 0` select makes hipcc
+// branch around each load and drain the memory counter after it).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned kOOB = 0x80000000u;   // >= any descriptor size (tensors are limited to 2 GiB - 1)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+struct Sizes {
+  unsigned x_bytes, y_bytes, w_bytes;   // byte sizes of the x-like, y-like and kernel tensors
+};
+
 // ---------------------------------------------------------------------------------------------------
 // forward: y[p, co] = bias[co] + sum_{tap, ci} x[pix(p, tap), ci] * w[tap, ci, co]
 // VEC: cin % 8 == 0 and 16-byte aligned rows -> each lane loads 4 consecutive channels at once; the k order inside
 // a block of 8 channels is permuted identically for A and B (lane half hh takes channels 4*hh .. 4*hh+3).
 // ---------------------------------------------------------------------------------------------------
 template <int NT, bool VEC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y) {
+__global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const float* __restrict__ x,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       float* __restrict__ y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   if (tile0 >= M) return;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
   const int64_t p = tile0 + r;
   const bool pv = p < M;
@@ -43,6 +66,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, const float* __res
   const int64_t t1 = pp / g.wo;
   const int oy = (int)(t1 % g.ho);
   const int n_ = (int)(t1 / g.ho);
+  const unsigned img_off = (unsigned)n_ * (unsigned)(g.h * g.w) * (unsigned)g.x_ld * 4u;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -51,49 +75,46 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, const float* __res
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   bool colv[NT];
-  int col[NT];
+  unsigned wcol[NT];   // byte offset of the lane's column inside a kernel row, or kOOB
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    col[t] = cbase + t * 32 + r;
-    colv[t] = col[t] < g.cout;
-    if (!colv[t]) col[t] = 0;
+    const int c = cbase + t * 32 + r;
+    colv[t] = c < g.cout;
+    wcol[t] = colv[t] ? (unsigned)c * 4u : kOOB;
   }
+  const unsigned wrow = (unsigned)g.cout * 4u;   // bytes per (tap, ci) kernel row
 
   for (int ky = 0; ky < g.kh; ++ky) {
     const int iy = oy * g.stride + ky * g.dil - g.pad_t;
     for (int kx = 0; kx < g.kw; ++kx) {
       const int ix = ox * g.stride + kx * g.dil - g.pad_l;
       const bool inb = pv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
-      const float* xp = x + (((int64_t)n_ * g.h + (inb ? iy : 0)) * g.w + (inb ? ix : 0)) * g.x_ld;
-      const float* wp = w + (int64_t)(ky * g.kw + kx) * g.cin * g.cout;
+      const unsigned xo = inb ? img_off + (unsigned)(iy * g.w + ix) * (unsigned)g.x_ld * 4u : kOOB;
+      const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
       if (VEC) {
 #pragma unroll 2
         for (int c0 = 0; c0 < g.cin; c0 += 8) {
           const int ci = c0 + 4 * hh;
-          f32x4 a = {0.f, 0.f, 0.f, 0.f};
-          if (inb) a = *reinterpret_cast<const f32x4*>(xp + ci);
+          const f32x4 a = bload4(rx, xo + (unsigned)ci * 4u);
+          float b[4][NT];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              float b = wp[(int64_t)(ci + j) * g.cout + col[t]];
-              b = colv[t] ? b : 0.f;
-              acc[t] = MFMA32(a[j], b, acc[t]);
-            }
-          }
+            for (int t = 0; t < NT; ++t) b[j][t] = bload(rw, wtap + (unsigned)(ci + j) * wrow + wcol[t]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[j][t], acc[t]);
         }
       } else {
 #pragma unroll 4
         for (int c0 = 0; c0 < g.cin; c0 += 2) {
           const int ci = c0 + hh;
           const bool cv = ci < g.cin;
-          const int cis = cv ? ci : 0;
-          float a = xp[cis];
-          a = (inb && cv) ? a : 0.f;
+          const float a = bload(rx, cv ? xo + (unsigned)ci * 4u : kOOB);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            float b = wp[(int64_t)cis * g.cout + col[t]];
-            b = (cv && colv[t]) ? b : 0.f;
+            const float b = bload(rw, cv ? wtap + (unsigned)ci * wrow + wcol[t] : kOOB);
             acc[t] = MFMA32(a, b, acc[t]);
           }
         }
@@ -104,12 +125,13 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, const float* __res
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (!colv[t]) continue;
-    const float bv = bias ? bias[col[t]] : 0.f;
+    const int c = cbase + t * 32 + r;
+    const float bv = bias ? bias[c] : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
       const int64_t po = tile0 + row;
-      if (po < M) y[po * g.y_ld + col[t]] = acc[t][i] + bv;
+      if (po < M) y[po * g.y_ld + c] = acc[t][i] + bv;
     }
   }
 }
@@ -119,10 +141,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, const float* __res
 //   dx[n, iy, ix, ci] = bias[ci] + add[..] + sum_{ky,kx : (iy + pad_t - ky*dil) % stride == 0, ...} sum_co
 //                        dy[n, (iy+pad_t-ky*dil)/stride, (ix+pad_l-kx*dil)/stride, co] * w[ky,kx,ci,co]
 // blockIdx.z enumerates the stride x stride phases (iy % stride, ix % stride) so the set of contributing taps is
-// uniform inside a block.
+// uniform inside a block.  VEC (cout % 8 == 0): 16-byte loads along co for both dy and the kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* __restrict__ dy,
+template <int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ add,
                                                             const float* __restrict__ bias, float* __restrict__ dx) {
@@ -135,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
   const int64_t M = (int64_t)g.n * qh * qw;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   if (tile0 >= M) return;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
 
   const int64_t p = tile0 + r;
@@ -145,6 +168,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
   const int qy = (int)(t1 % qh);
   const int n_ = (int)(t1 / qh);
   const int iy = qy * s + pa, ix = qx * s + pb;
+  const unsigned img_off = (unsigned)n_ * (unsigned)(g.ho * g.wo) * (unsigned)g.y_ld * 4u;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -153,12 +177,13 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   bool colv[NT];
-  int col[NT];
+  unsigned wci[NT];   // byte offset of kernel row (ci = lane's column) inside a tap, or kOOB
+  const unsigned wrow = (unsigned)g.cout * 4u;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    col[t] = cbase + t * 32 + r;  // input channel ci of the forward conv
-    colv[t] = col[t] < g.cin;
-    if (!colv[t]) col[t] = 0;
+    const int c = cbase + t * 32 + r;   // input channel ci of the forward conv
+    colv[t] = c < g.cin;
+    wci[t] = colv[t] ? (unsigned)c * wrow : kOOB;
   }
 
   for (int ky = 0; ky < g.kh; ++ky) {
@@ -172,20 +197,32 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
       const int tx = ix + g.pad_l - kx * g.dil;
       const int ox = tx / s;
       const bool inb = pv && ty >= 0 && tx >= 0 && oy < g.ho && ox < g.wo;
-      const float* yp = dy + (((int64_t)n_ * g.ho + (inb ? oy : 0)) * g.wo + (inb ? ox : 0)) * g.y_ld;
-      const float* wp = w + (int64_t)(ky * g.kw + kx) * g.cin * g.cout;
-#pragma unroll 4
-      for (int c0 = 0; c0 < g.cout; c0 += 2) {
-        const int co = c0 + hh;
-        const bool cv = co < g.cout;
-        const int cos = cv ? co : 0;
-        float a = yp[cos];
-        a = (inb && cv) ? a : 0.f;
+      const unsigned yo = inb ? img_off + (unsigned)(oy * g.wo + ox) * (unsigned)g.y_ld * 4u : kOOB;
+      const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
+      if (VEC) {
+#pragma unroll 2
+        for (int c0 = 0; c0 < g.cout; c0 += 8) {
+          const unsigned co4 = (unsigned)(c0 + 4 * hh) * 4u;
+          const f32x4 a = bload4(ry, yo + co4);
+          f32x4 b[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          float b = wp[(int64_t)col[t] * g.cout + cos];
-          b = (cv && colv[t]) ? b : 0.f;
-          acc[t] = MFMA32(a, b, acc[t]);
+          for (int t = 0; t < NT; ++t) b[t] = bload4(rw, wtap + wci[t] + co4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[t][j], acc[t]);
+        }
+      } else {
+#pragma unroll 4
+        for (int c0 = 0; c0 < g.cout; c0 += 2) {
+          const int co = c0 + hh;
+          const bool cv = co < g.cout;
+          const float a = bload(ry, cv ? yo + (unsigned)co * 4u : kOOB);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const float b = bload(rw, cv ? wtap + wci[t] + (unsigned)co * 4u : kOOB);
+            acc[t] = MFMA32(a, b, acc[t]);
+          }
         }
       }
     }
@@ -194,7 +231,8 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     if (!colv[t]) continue;
-    const float bv = bias ? bias[col[t]] : 0.f;
+    const int c = cbase + t * 32 + r;
+    const float bv = bias ? bias[c] : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -204,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
         const int64_t t2 = po / qw;
         const int oy_ = (int)(t2 % qh);
         const int nn = (int)(t2 / qh);
-        const int64_t off = (((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb)) * g.x_ld + col[t];
+        const int64_t off = (((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb)) * g.x_ld + c;
         float v = acc[t][i] + bv;
         if (add) v += add[off];
         dx[off] = v;
@@ -215,95 +253,156 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, const float* 
 
 // ---------------------------------------------------------------------------------------------------
 // weight gradient: dw[(tap,ci), co] = sum_p x[pix(p,tap), ci] * dy[p, co]; optional extra row K = sum_p dy[p, co].
-// Each wave owns kernel rows [32*ktile, 32*ktile+32) x NT column tiles and a contiguous chunk of output rows,
-// and writes its partial sums to part[chunk][K_aug][cout]; conv_bwd_weight_reduce sums the chunks in a fixed
-// order (deterministic).
+// The [K_aug x cout] result is cut into 32x32 output tiles (kt, ct).  A workgroup owns one strip of output rows and
+// up to 4*TPW tiles: its waves split the tiles (wave w takes tiles w, w+wps, ...), so the 4 waves stream the same
+// pixels (dy and the shifted x rows come from L1/L2 after the first touch) while each keeps TPW accumulators.
+// When there are fewer than 4 tiles, the waves of a workgroup take different strips instead.
+// Partial sums go to part[strip][K_aug][cout]; conv_bwd_weight_reduce adds the strips in a fixed order.
 // ---------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, const float* __restrict__ x,
-                                                              const float* __restrict__ dy, float* __restrict__ part,
-                                                              int K, int K_aug, int ktiles, int rows_per_chunk,
-                                                              int nchunks) {
+struct WgArgs {
+  int K, K_aug, ktiles, cotiles, T;   // T = ktiles * cotiles
+  int wps;                            // waves per strip (min(4, T))
+  int nstrips, rows_per_strip;
+};
+
+template <int TPW>
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, Sizes sz, WgArgs a, const float* __restrict__ x,
+                                                              const float* __restrict__ dy, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;  // (chunk, ktile)
-  if (unit >= (int64_t)nchunks * ktiles) return;
-  const int ktile = (int)(unit % ktiles);
-  const int chunk = (int)(unit / ktiles);
-  const int cbase = blockIdx.y * 32 * NT;
+  const int spb = 4 / a.wps;
+  const int strip = blockIdx.x * spb + wave / a.wps;
+  const int widx = wave % a.wps;
+  if (strip >= a.nstrips || wave >= spb * a.wps) return;
+  const int tile0 = blockIdx.y * (a.wps * TPW) + widx;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), ry = make_rsrc(dy, sz.y_bytes);
 
-  const int k = ktile * 32 + r;
-  const bool kv = k < K;
-  const bool kbias = (k == K) && (K_aug > K);
-  const int ks = kv ? k : 0;
-  const int tap = ks / g.cin, ci = ks % g.cin;
-  const int ky = tap / g.kw, kx = tap % g.kw;
-
-  f32x16 acc[NT];
+  bool tv[TPW], kv[TPW], kb[TPW], colv[TPW];
+  int kyd[TPW], kxd[TPW], kt_[TPW], col[TPW];
+  unsigned cib[TPW], colb[TPW];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  bool colv[NT];
-  int col[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    col[t] = cbase + t * 32 + r;
-    colv[t] = col[t] < g.cout;
-    if (!colv[t]) col[t] = 0;
+  for (int j = 0; j < TPW; ++j) {
+    const int t = tile0 + a.wps * j;
+    tv[j] = t < a.T;
+    const int ts = tv[j] ? t : 0;
+    const int kt = ts / a.cotiles, ct = ts % a.cotiles;
+    kt_[j] = kt;
+    const int k = kt * 32 + r;
+    kv[j] = tv[j] && k < a.K;
+    kb[j] = tv[j] && (k == a.K) && (a.K_aug > a.K);
+    const int ks = kv[j] ? k : 0;
+    const int tap = ks / g.cin;
+    cib[j] = (unsigned)(ks % g.cin) * 4u;
+    kyd[j] = (tap / g.kw) * g.dil - g.pad_t;
+    kxd[j] = (tap % g.kw) * g.dil - g.pad_l;
+    col[j] = ct * 32 + r;
+    colv[j] = tv[j] && col[j] < g.cout;
+    colb[j] = colv[j] ? (unsigned)col[j] * 4u : kOOB;
   }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
   const int R = g.n * g.ho;
-  const int row0 = chunk * rows_per_chunk;
-  const int row1 = min(R, row0 + rows_per_chunk);
-  for (int row = row0; row < row1; ++row) {
+  const int row0 = strip * a.rows_per_strip;
+  const int row1 = min(R, row0 + a.rows_per_strip);
+  // One dword per lane per operand per MFMA makes the pixel loop latency bound, so operands are fetched in batches of
+  // U MFMA steps, two batches in flight: while batch b feeds the matrix core, batch b+1 is already on its way.
+  constexpr int U = (TPW == 1) ? 16 : 8;
+  const int spr = (g.wo + 1) / 2;          // MFMA steps per output row (2 pixels per step)
+  const int bpr = (spr + U - 1) / U;       // batches per row
+  const int nbatch = (row1 - row0) * bpr;
+  float a0[U][TPW], b0[U][TPW], a1[U][TPW], b1[U][TPW];
+  const unsigned xpix = (unsigned)g.x_ld * 4u, ypix = (unsigned)g.y_ld * 4u;
+
+  auto load_batch = [&](int bi, float (&av)[U][TPW], float (&bv)[U][TPW]) {
+    const bool bvld = bi < nbatch;
+    const int bis = bvld ? bi : 0;
+    const int row = row0 + bis / bpr;
+    const int step0 = (bis % bpr) * U;
     const int n_ = row / g.ho, oy = row % g.ho;
-    const int iy = oy * g.stride + ky * g.dil - g.pad_t;
-    const bool yv = kv && (unsigned)iy < (unsigned)g.h;
-    const float* xrow = x + ((int64_t)n_ * g.h + (yv ? iy : 0)) * g.w * g.x_ld + ci;
-    const float* dyrow = dy + ((int64_t)n_ * g.ho + oy) * g.wo * g.y_ld;
-#pragma unroll 4
-    for (int ox0 = 0; ox0 < g.wo; ox0 += 2) {
-      const int ox = ox0 + hh;
-      const bool ov = ox < g.wo;
-      const int oxs = ov ? ox : 0;
-      const int ix = oxs * g.stride + kx * g.dil - g.pad_l;
-      const bool xv = yv && ov && (unsigned)ix < (unsigned)g.w;
-      float a = xrow[(int64_t)(xv ? ix : 0) * g.x_ld];
-      a = xv ? a : 0.f;
-      if (kbias) a = ov ? 1.f : 0.f;
+    const unsigned dyrow = (unsigned)(n_ * g.ho + oy) * (unsigned)g.wo * ypix;
+    unsigned xrow[TPW];
+    bool yv[TPW];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        float b = dyrow[(int64_t)oxs * g.y_ld + col[t]];
-        b = (ov && colv[t]) ? b : 0.f;
-        acc[t] = MFMA32(a, b, acc[t]);
+    for (int j = 0; j < TPW; ++j) {
+      const int iy = oy * g.stride + kyd[j];
+      yv[j] = bvld && kv[j] && (unsigned)iy < (unsigned)g.h;
+      xrow[j] = (unsigned)(n_ * g.h + (yv[j] ? iy : 0)) * (unsigned)g.w * xpix + cib[j];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ox = (step0 + u) * 2 + hh;
+      const bool ov = bvld && ox < g.wo;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int ix = ox * g.stride + kxd[j];
+        const bool xv = yv[j] && ov && (unsigned)ix < (unsigned)g.w;
+        const float t = bload(rx, xv ? xrow[j] + (unsigned)ix * xpix : kOOB);
+        av[u][j] = kb[j] ? (ov ? 1.f : 0.f) : t;
+        bv[u][j] = bload(ry, ov ? dyrow + (unsigned)ox * ypix + colb[j] : kOOB);
       }
     }
+  };
+  auto mma_batch = [&](float (&av)[U][TPW], float (&bv)[U][TPW]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) acc[j] = MFMA32(av[u][j], bv[u][j], acc[j]);
+  };
+
+  load_batch(0, a0, b0);
+  for (int bi = 0; bi < nbatch; bi += 2) {
+    load_batch(bi + 1, a1, b1);
+    mma_batch(a0, b0);
+    load_batch(bi + 2, a0, b0);
+    mma_batch(a1, b1);
   }
 
-  float* pbase = part + (int64_t)chunk * K_aug * g.cout;
+  float* pbase = part + (int64_t)strip * a.K_aug * g.cout;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (!colv[t]) continue;
+  for (int j = 0; j < TPW; ++j) {
+    if (!colv[j]) continue;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int rr = (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const int kk = ktile * 32 + rr;
-      if (kk < K_aug) pbase[(int64_t)kk * g.cout + col[t]] = acc[t][i];
+      const int kk = kt_[j] * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (kk < a.K_aug) pbase[(int64_t)kk * g.cout + col[j]] = acc[j][i];
     }
   }
 }
 
-__global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __restrict__ part, int nchunks, int K,
+// Strip reduction: 16 outputs x 16 strip-slices per workgroup; every thread adds its strips (slice, slice+16, ...) with
+// four independent accumulators, the 16 slices are then combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __restrict__ part, int nstrips, int K,
                                                               int K_aug, int cout, float* __restrict__ dw,
                                                               float* __restrict__ dbias) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float sm[256];
   const int E = K_aug * cout;
-  if (e >= E) return;
-  float s = 0.f;
-  for (int c = 0; c < nchunks; ++c) s += part[(int64_t)c * E + e];
-  if (e < K * cout) dw[e] = s;
-  else if (dbias) dbias[e - K * cout] = s;
+  const int e = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int slice = threadIdx.x >> 4;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < E) {
+    const float* p = part + e;
+    int c = slice;
+    for (; c + 48 < nstrips; c += 64) {
+      s0 += p[(int64_t)c * E];
+      s1 += p[(int64_t)(c + 16) * E];
+      s2 += p[(int64_t)(c + 32) * E];
+      s3 += p[(int64_t)(c + 48) * E];
+    }
+    for (; c < nstrips; c += 16) s0 += p[(int64_t)c * E];
+  }
+  sm[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < 16 && e < E) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q * 16 + threadIdx.x];
+    if (e < K * cout) dw[e] = t;
+    else if (dbias) dbias[e - K * cout] = t;
+  }
 }
 
 // column sums of a [npix, c] matrix with row stride ld (bias gradient of a transposed convolution)
@@ -353,13 +452,26 @@ static ssmi_status check_desc(const ssmi_conv_desc* d) {
 
 static int pick_nt(int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); }
 
+// byte sizes for the buffer descriptors; tensors above 2 GiB - 1 are rejected (32-bit buffer offsets)
+static ssmi_status make_sizes(const Geo& g, Sizes* sz) {
+  const int64_t xb = (int64_t)g.n * g.h * g.w * g.x_ld * 4, yb = (int64_t)g.n * g.ho * g.wo * g.y_ld * 4;
+  const int64_t wb = (int64_t)g.kh * g.kw * g.cin * g.cout * 4;
+  SSMI_REQUIRE(xb < 0x7FFFFFFFLL && yb < 0x7FFFFFFFLL && wb < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
+               "conv: tensors of 2 GiB or more are not supported (x %lld B, y %lld B)", (long long)xb, (long long)yb);
+  sz->x_bytes = (unsigned)xb; sz->y_bytes = (unsigned)yb; sz->w_bytes = (unsigned)wb;
+  return SSMI_OK;
+}
+
 static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, const float* bias, float* y,
                               hipStream_t st) {
+  Sizes sz;
+  ssmi_status e = make_sizes(g, &sz);
+  if (e) return e;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, x, w, bias, y)
+#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
   } else {
@@ -372,57 +484,81 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
 
 static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w, const float* add, const float* bias,
                                    float* dx, hipStream_t st) {
+  Sizes sz;
+  ssmi_status e = make_sizes(g, &sz);
+  if (e) return e;
   const int s = g.stride;
   const int qh = (g.h + s - 1) / s, qw = (g.w + s - 1) / s;
   const int64_t M = (int64_t)g.n * qh * qw;
   const int nt = pick_nt(g.cin);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cin + 32 * nt - 1) / (32 * nt)), (unsigned)(s * s));
-#define L(NT) hipLaunchKernelGGL((conv_bwd_data_kernel<NT>), grid, dim3(256), 0, st, g, dy, w, add, bias, dx)
-  if (nt == 1) L(1); else if (nt == 2) L(2); else L(4);
+  const bool vec = (g.cout % 8 == 0) && (g.y_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+#define L(NT, V) hipLaunchKernelGGL((conv_bwd_data_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx)
+  if (vec) {
+    if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
+  } else {
+    if (nt == 1) L(1, false); else if (nt == 2) L(2, false); else L(4, false);
+  }
 #undef L
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
 
 struct WgPlan {
-  int K, K_aug, ktiles, nchunks, rows_per_chunk, nt, cgroups;
+  WgArgs a;
+  int tpw, groups, blocks_x;
   size_t bytes;
 };
 
 static WgPlan plan_wg(const Geo& g, bool with_bias) {
   WgPlan p;
-  p.K = g.kh * g.kw * g.cin;
-  p.K_aug = p.K + (with_bias ? 1 : 0);
-  p.ktiles = (p.K_aug + 31) / 32;
-  p.nt = pick_nt(g.cout);
-  p.cgroups = (g.cout + 32 * p.nt - 1) / (32 * p.nt);
+  WgArgs& a = p.a;
+  a.K = g.kh * g.kw * g.cin;
+  a.K_aug = a.K + (with_bias ? 1 : 0);
+  a.ktiles = (a.K_aug + 31) / 32;
+  a.cotiles = (g.cout + 31) / 32;
+  a.T = a.ktiles * a.cotiles;
+  a.wps = a.T < 4 ? a.T : 4;
+  int tpw = (a.T + 3) / 4;
+  if (tpw > 3) tpw = 3;
+  if (tpw < 1) tpw = 1;
+  p.tpw = tpw;
+  p.groups = (a.T + a.wps * tpw - 1) / (a.wps * tpw);
+  const int spb = 4 / a.wps;
   const int R = g.n * g.ho;
-  int target = 2048 / (p.ktiles * p.cgroups);
-  if (target < 1) target = 1;
+  // about one workgroup per CU per tile group; more strips only add partial-sum traffic
+  int target = (256 * spb) / p.groups;
+  if (target < spb) target = spb;
   if (target > R) target = R;
-  if (target > 256) target = 256;
-  p.rows_per_chunk = (R + target - 1) / target;
-  p.nchunks = (R + p.rows_per_chunk - 1) / p.rows_per_chunk;
-  p.bytes = (size_t)p.nchunks * p.K_aug * g.cout * sizeof(float);
+  a.rows_per_strip = (R + target - 1) / target;
+  a.nstrips = (R + a.rows_per_strip - 1) / a.rows_per_strip;
+  p.blocks_x = (a.nstrips + spb - 1) / spb;
+  p.bytes = (size_t)a.nstrips * a.K_aug * g.cout * sizeof(float);
   return p;
+}
+
+static size_t wg_ws_bytes(const Geo& g) {
+  const size_t b0 = plan_wg(g, false).bytes, b1 = plan_wg(g, true).bytes;
+  return b0 > b1 ? b0 : b1;
 }
 
 static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
                                      size_t ws_bytes, hipStream_t st) {
-  // always plan with the bias row so that the workspace query does not depend on dbias
+  Sizes sz;
+  ssmi_status e = make_sizes(g, &sz);
+  if (e) return e;
   WgPlan p = plan_wg(g, dbias != nullptr);
   SSMI_REQUIRE(ws != nullptr && ws_bytes >= p.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
                ws_bytes, p.bytes);
   float* part = reinterpret_cast<float*>(ws);
-  dim3 grid((unsigned)ceil_div64((int64_t)p.nchunks * p.ktiles, 4), (unsigned)p.cgroups, 1);
-#define L(NT)                                                                                              \
-  hipLaunchKernelGGL((conv_bwd_weight_kernel<NT>), grid, dim3(256), 0, st, g, x, dy, part, p.K, p.K_aug, p.ktiles, \
-                     p.rows_per_chunk, p.nchunks)
-  if (p.nt == 1) L(1); else if (p.nt == 2) L(2); else L(4);
+  dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
+#define L(TPW) hipLaunchKernelGGL((conv_bwd_weight_kernel<TPW>), grid, dim3(256), 0, st, g, sz, p.a, x, dy, part)
+  if (p.tpw == 1) L(1); else if (p.tpw == 2) L(2); else L(3);
 #undef L
   SSMI_LAUNCH_CHECK();
-  const int E = p.K_aug * g.cout;
-  hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 255) / 256), dim3(256), 0, st, part, p.nchunks, p.K, p.K_aug,
+  const int E = p.a.K_aug * g.cout;
+  hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 15) / 16), dim3(256), 0, st, part, p.a.nstrips, p.a.K, p.a.K_aug,
                      g.cout, dw, dbias);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
@@ -463,7 +599,7 @@ ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const
 
 size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d) {
   if (check_desc(d)) return 0;
-  return plan_wg(to_geo(d), true).bytes;
+  return wg_ws_bytes(to_geo(d));
 }
 
 ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
@@ -500,7 +636,7 @@ static int colsum_blocks(int64_t npix, int c) {
 
 size_t ssmi_conv2d_transpose_bwd_weight_workspace_bytes(const ssmi_conv_desc* d) {
   if (check_desc(d)) return 0;
-  const size_t a = plan_wg(to_geo(d), false).bytes;
+  const size_t a = wg_ws_bytes(to_geo(d));
   return a + (size_t)512 * d->cin * sizeof(float);
 }
 
@@ -512,7 +648,7 @@ ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const floa
   SSMI_REQUIRE(ws_bytes >= ssmi_conv2d_transpose_bwd_weight_workspace_bytes(d), SSMI_E_WORKSPACE,
                "conv2d_transpose_bwd_weight: workspace too small");
   Geo g = to_geo(d);
-  const size_t a = plan_wg(g, false).bytes;
+  const size_t a = wg_ws_bytes(g);
   s = launch_bwd_weight(g, dyt, xt, dw, nullptr, ws, a, as_stream(stream));
   if (s) return s;
   if (dbias) {

@@ -1,0 +1,170 @@
+"""Data-parallel supervised segmentation trainer (replaces the single-device loop of the reference's
+src/trainers.py: TrainerBase.__init__ :170-282, _get_model_optimizer :1070-1125, SegmentationTrainer.train :2334-2376,
+loss/metric wiring :2420-2460).
+
+One process per GPU.  Every rank holds a full replica (flat parameter arena), runs forward/backward on its shard of the
+global batch and the ranks average gradients with RCCL all-reduces over two buckets of the flat gradient arena; the
+first bucket (late layers, ~95 % of the bytes) is reduced on the communicator's stream while the early layers' backward
+is still running.  BatchNormalization statistics stay per replica (what any Keras data-parallel wrapper would do).
+Evaluation shards the images and sums the int64 confusion matrices, so metrics do not depend on the rank count.
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class GradientBucketReducer:
+    """Sum-all-reduce of ranges of a flat gradient tensor, asynchronously on the process group's own stream.
+
+    start(grad, (lo, hi)) enqueues the all-reduce of grad[lo:hi] behind everything already queued on the current
+    stream; finish() makes the current stream wait for every pending bucket.  The optimizer divides by world_size
+    (grad_scale), which reproduces the global-batch mean because the loss is a mean over equally sized shards
+    (src/losses.py:263).  Works with any backend (nccl = RCCL on ROCm; gloo in CPU tests).
+    """
+
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world_size = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._pending = []
+        self.bytes_reduced = 0
+
+    def start(self, grad: torch.Tensor, rng: Tuple[int, int]):
+        lo, hi = rng
+        if hi <= lo:
+            return
+        view = grad[lo:hi]
+        self.bytes_reduced += view.numel() * view.element_size()
+        self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def broadcast_(self, tensors: Sequence[torch.Tensor], src: int = 0):
+        for t in tensors:
+            dist.broadcast(t, src=src, group=self.group)
+
+    def sum_int64_(self, t: torch.Tensor):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+def shard_range(global_batch: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous equal shards of the global batch (global batch 128 -> 8 x 16)."""
+    if global_batch % world_size:
+        raise ValueError("global batch {} is not divisible by world size {}".format(global_batch, world_size))
+    per = global_batch // world_size
+    return rank * per, (rank + 1) * per
+
+
+def init_distributed_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, local_rank, world_size)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world
+
+
+class SegmentationTrainer(object):
+    """Supervised segmentation trainer driven by the reference's JSON config keys
+    (configs/segmentation/config-segmentation-supervised.json): input_shape, num_classes (from the material CSV in the
+    reference; given directly here), num_labeled_per_batch, optimizer{name, learning_rate, momentum, decay},
+    ignore_classes, use_class_weights / override_class_weights, random_seed, num_epochs."""
+
+    def __init__(self, trainer_type, model_name, model_folder_name, config_file_path=None, config: Optional[dict] = None,
+                 num_classes: int = 24, device=None):
+        from . import models, losses, metrics
+        from .keras_extensions import extended_optimizers as xo
+        if trainer_type != "segmentation_supervised":
+            raise NotImplementedError("trainer type {} is outside the supervised hot path".format(trainer_type))
+        if config is None:
+            with open(config_file_path) as f:
+                config = json.load(f)
+        self.config = config
+        self.model_name = model_name
+        self.model_folder_name = model_folder_name
+        self.rank, self.local_rank, self.world_size = init_distributed_from_env()
+        self.device = device or ("cuda:{}".format(self.local_rank))
+        self.num_classes = num_classes
+        self.random_seed = int(config.get("random_seed", 14874))
+        self.ignore_classes = list(config.get("ignore_classes", [0]))
+        self.num_epochs = int(config.get("num_epochs", 1))
+        self.num_labeled_per_batch = int(config.get("num_labeled_per_batch", 16))
+        cw = config.get("override_class_weights")
+        if cw is None or not config.get("use_class_weights", True):
+            cw = np.ones(num_classes, dtype=np.float32)
+            for c in self.ignore_classes:
+                cw[c] = 0.0   # src/trainers.py:2047-2053
+        self.class_weights = np.asarray(cw, dtype=np.float32)
+        mb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes,
+                              losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, device=self.device)
+        self.model_wrapper = mb
+        self.model = mb.model
+        self.model.seed = self.random_seed + self.rank   # independent dropout draws per replica
+        self.model.graph.store.init_values(self.random_seed)
+        oc = config.get("optimizer", {"name": "adam", "learning_rate": 5e-4})
+        name = oc.get("name", "adam").lower()
+        if name == "adam":
+            opt = xo.Adam(lr=oc.get("learning_rate", 1e-3), decay=oc.get("decay", 0.0))
+        elif name == "sgd":
+            opt = xo.SGD(lr=oc.get("learning_rate", 0.01), momentum=oc.get("momentum", 0.0), decay=oc.get("decay", 0.0))
+        else:
+            raise ValueError("Unsupported optimizer name: {}".format(name))
+        nu = 0
+        ic = self.ignore_classes
+        self.model.compile(optimizer=opt, loss={'loss': losses.dummy_loss, 'logits': lambda _, y_pred: 0.0 * y_pred},
+                           loss_weights={'loss': 1.0, 'logits': 0.0},
+                           metrics={'logits': [metrics.segmentation_accuracy(nu, ic), metrics.segmentation_mean_iou(num_classes, nu, ic),
+                                               metrics.segmentation_mean_per_class_accuracy(num_classes, nu, ic),
+                                               metrics.segmentation_confusion_matrix(num_classes, nu, ic)]})
+        self.reducer = None
+        if self.world_size > 1:
+            self.reducer = GradientBucketReducer()
+            st = self.model.graph.store
+            self.reducer.broadcast_([st.theta, st.state], src=0)
+            self.model.grad_sync = self.reducer
+
+    # hooks of the reference's engine (src/trainers.py:1314-1334)
+    def modify_batch_data(self, step_index, x, y, validation=False):
+        return x, y
+
+    def on_batch_end(self, step_index):
+        pass
+
+    def on_epoch_end(self, epoch_index, step_index, logs):
+        pass
+
+    def on_training_end(self):
+        pass
+
+    def global_confusion_matrix(self) -> np.ndarray:
+        cm = self.model._cm.clone()
+        if self.reducer is not None:
+            self.reducer.sum_int64_(cm)
+        return cm.cpu().numpy()
+
+    def train(self, generator, steps_per_epoch, validation_data=None, validation_steps=None):
+        return self.model.fit_generator(generator, steps_per_epoch, epochs=self.num_epochs, validation_data=validation_data,
+                                        validation_steps=validation_steps, trainer=self, random_seed=self.random_seed)
