@@ -1,0 +1,88 @@
+"""World-size-2 data-parallel checks on CPU (gloo): the bucketed reducer + 1/world scaling reproduce the global-batch
+gradient of equally sized shards, the int64 confusion-matrix sum is exact, and sharding covers the batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import pkg, ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from conftest import pkg as _pkg
+    from oracle import enet_oracle as E
+    trainers = _pkg("trainers")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = trainers.GradientBucketReducer()
+    name, nc, GB, H, W = "enet-naive-upsampling", 6, 4, 32, 32
+    w0 = E.init_weights(name, nc, seed=1, perturb=True)
+    images, labels, pw = E.synthetic_batch(GB, H, W, nc, seed=2, block=8)
+    lo, hi = trainers.shard_range(GB, world, rank)
+    ref = E.train_step(name, w0, images[lo:hi], labels[lo:hi], pw[lo:hi], None)
+    keys = E.trainable_keys(name, nc)
+    flat = torch.cat([torch.from_numpy(ref["grads"][k].reshape(-1)) for k in keys])
+    n = flat.numel()
+    cut = n // 3
+    # two buckets in backward order, then the optimizer-side 1/world scaling
+    red.start(flat, (cut, n))
+    red.start(flat, (0, cut))
+    red.finish()
+    flat /= red.world_size
+    cm = torch.from_numpy(ref["cm"].copy())
+    red.sum_int64_(cm)
+    t = torch.full((3,), float(rank))
+    red.broadcast_([t], src=0)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "r0.npz"), flat=flat.numpy(), cm=cm.numpy(), bytes=red.bytes_reduced, t=t.numpy())
+    else:
+        np.savez(os.path.join(out_dir, "r1.npz"), flat=flat.numpy(), cm=cm.numpy(), t=t.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_average_and_cm_sum(tmp_path):
+    from oracle import enet_oracle as E
+    port = _free_port()
+    mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method="spawn")
+    r0, r1 = np.load(tmp_path / "r0.npz"), np.load(tmp_path / "r1.npz")
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["cm"], r1["cm"])
+    assert np.array_equal(r1["t"], np.zeros(3))
+    name, nc, GB, H, W = "enet-naive-upsampling", 6, 4, 32, 32
+    w0 = E.init_weights(name, nc, seed=1, perturb=True)
+    images, labels, pw = E.synthetic_batch(GB, H, W, nc, seed=2, block=8)
+    keys = E.trainable_keys(name, nc)
+    # per-replica BatchNorm: the reference quantity is the mean of the two shard gradients
+    g = [E.train_step(name, w0, images[a:b], labels[a:b], pw[a:b], None) for a, b in ((0, 2), (2, 4))]
+    exp = torch.cat([torch.from_numpy(0.5 * (g[0]["grads"][k] + g[1]["grads"][k]).reshape(-1)) for k in keys]).numpy()
+    assert np.allclose(r0["flat"], exp, rtol=1e-12, atol=1e-15)
+    assert np.array_equal(r0["cm"], g[0]["cm"] + g[1]["cm"])
+    assert int(r0["bytes"]) == exp.size * 8
+
+
+def test_shard_range():
+    trainers = pkg("trainers")
+    cover = []
+    for r in range(8):
+        lo, hi = trainers.shard_range(128, 8, r)
+        assert hi - lo == 16
+        cover.extend(range(lo, hi))
+    assert cover == list(range(128))
+    with pytest.raises(ValueError):
+        trainers.shard_range(10, 4, 0)

@@ -1,0 +1,174 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every declared symbol (no compute calls
+without a GPU), builders reproduce the reference's names/shapes/order, host helpers agree with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg, ROOT
+from oracle import enet_oracle as E
+from oracle import tf_keras_ops as K
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "ssmi.h")).read()
+    return sorted(set(re.findall(r"^(?:ssmi_status|size_t|int32_t|const char\*)\s+(ssmi_[a-z0-9_]+)\s*\(", hdr, re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = pkg("_lib")
+    dll = C.CDLL(lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(dll, name), "libssmi.so does not export " + name
+    # and the binding covers exactly the header
+    assert sorted(lib.EXPORTED_SYMBOLS) == declared
+
+
+def test_host_only_entry_points():
+    L = pkg("_lib").lib()
+    assert L.version() >= 100
+    for size, k, s, d in [(512, 3, 2, 1), (64, 3, 1, 16), (64, 5, 1, 1), (7, 3, 2, 1), (64, 2, 2, 1), (33, 3, 1, 2)]:
+        o, p = C.c_int32(), C.c_int32()
+        L.same_pad(size, k, s, d, C.byref(o), C.byref(p))
+        exp = K.same_pad(size, k, s, d)
+        assert (o.value, p.value) == (exp[0], exp[1])
+        assert pkg("engine").same_pad(size, k, s, d) == (exp[0], exp[1])
+    with pytest.raises(pkg("_lib").SsmiError):
+        L.same_pad(0, 3, 1, 1, C.byref(C.c_int32()), C.byref(C.c_int32()))
+
+
+def test_metrics_from_cm_match_reference_definitions():
+    metrics = pkg("metrics")
+    rng = np.random.RandomState(1)
+    for trial in range(5):
+        cm = rng.randint(0, 2000, size=(24, 24)).astype(np.int64)
+        cm[0, :] = 0                 # ignored class never appears as a label
+        if trial == 1:
+            cm[5, :] = 0
+            cm[:, 5] = 0             # an absent class
+        if trial == 2:
+            cm *= 40000              # counts beyond 2**24: the script's float32 numerator rounds
+        m = metrics.metrics_from_confusion_matrix(cm, [0])
+        assert abs(m["accuracy"] - K.cfm_accuracy(cm)) < 1e-12
+        assert abs(m["mpca"] - K.tf_mean_per_class_accuracy(cm)) < 1e-12
+        assert abs(m["miou"] - K.tf_mean_iou(cm)) < 1e-12
+        assert abs(m["miou_all_classes"] - K.tf_mean_iou(cm, only_present=False)) < 1e-12
+        assert abs(m["script_mpca"] - K.cfm_mpca(cm, [0])) < 1e-12
+        assert abs(m["script_miou"] - K.cfm_miou(cm, [0])) < 1e-12
+    assert metrics.ignore_mask_bits([0, 3]) == 0b1001
+    with pytest.raises(ValueError):
+        metrics.ignore_mask_bits([64])
+
+
+@pytest.mark.parametrize("name", ["enet-naive-upsampling", "enet-max-unpooling"])
+def test_builder_weight_names_shapes_and_order(name):
+    models = pkg("models")
+    m = models.get_model(name, (None, None, 3), 24, device="cpu").model
+    spec = E.weight_spec(name, 24)
+    assert m.weight_names() == [k for k, _, _, _ in spec]
+    st = m.graph.store
+    for k, shape, init, _ in spec:
+        assert st.specs[k].shape == tuple(shape)
+        assert st.specs[k].init == init
+    n_train = sum(s.size for s in st.specs.values() if s.trainable)
+    assert n_train == {"enet-naive-upsampling": 364972, "enet-max-unpooling": 364924}[name]
+    # Keras layer view: one entry per layer, names unique
+    names = [l.name for l in m.layers]
+    assert len(names) == len(set(names)) and names[0] == "initial_block_conv2d" and names[-1] == "logits"
+    # arena segments are 16-byte aligned and do not overlap
+    offs = sorted((s.offset, s.size) for s in st.specs.values() if s.trainable)
+    for (o, n), (o2, _) in zip(offs, offs[1:]):
+        assert o % 4 == 0 and o + n <= o2
+
+
+def test_get_model_errors_like_the_reference():
+    models = pkg("models")
+    losses = pkg("losses")
+    with pytest.raises(ValueError, match="Unknown model name"):
+        models.get_model("resnet", (None, None, 3), 24, device="cpu")
+    with pytest.raises(ValueError, match="Unknown model lambda loss type"):
+        models.get_lambda_loss_function("nope")
+    with pytest.raises(NotImplementedError):
+        models.get_model("enet-naive-upsampling-encoder-only", (None, None, 3), 24, device="cpu")
+    assert models.get_lambda_loss_function(losses.ModelLambdaLossType.NONE) is None
+    assert models.get_lambda_loss_function(losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY) \
+        is losses.segmentation_categorical_cross_entropy_lambda_loss
+
+
+def test_set_get_weights_roundtrip_and_npz_container(tmp_path):
+    models = pkg("models")
+    m = models.get_model("enet-max-unpooling", (None, None, 3), 24, device="cpu").model
+    w0 = E.init_weights("enet-max-unpooling", 24, seed=3, perturb=True, dtype=np.float32)
+    m.set_weights([w0[k] for k in m.weight_names()])
+    got = m.get_weights()
+    assert all(np.array_equal(a, w0[k]) for a, k in zip(got, m.weight_names()))
+    f = str(tmp_path / "w.npz")
+    m.save_weights(f)
+    m2 = models.get_model("enet-max-unpooling", (None, None, 3), 24, device="cpu").model
+    m2.load_weights(f)
+    assert all(np.array_equal(a, b) for a, b in zip(m2.get_weights(), got))
+    with pytest.raises(ValueError):
+        m.set_weights(got[:-1])
+    bad = list(got)
+    bad[0] = bad[0][:, :, :, :5]
+    with pytest.raises(ValueError):
+        m.set_weights(bad)
+
+
+def test_keras_default_initialisers():
+    models = pkg("models")
+    m = models.get_model("enet-naive-upsampling", (None, None, 3), 24, device="cpu").model
+    m.graph.store.init_values(14874)
+    w = m.get_weights_dict()
+    assert np.all(w["en_bn_1.0_bnorm_1/gamma"] == 1) and np.all(w["en_bn_1.0_bnorm_1/moving_variance"] == 1)
+    assert np.all(w["en_bn_1.0_prelu_1/alpha"] == 0) and np.all(w["logits/bias"] == 0)
+    k = w["en_bn_2.1_conv2d_1/kernel"]
+    assert abs(k.std() - np.sqrt(2.0 / (9 * 32))) < 0.1 * np.sqrt(2.0 / (9 * 32))
+    lim = np.sqrt(6.0 / (27 + 9 * 13))
+    assert np.abs(w["initial_block_conv2d/kernel"]).max() <= lim
+
+
+def test_bucket_ranges_cover_the_arena_in_backward_order():
+    models = pkg("models")
+    losses = pkg("losses")
+    m = models.get_model("enet-naive-upsampling", (None, None, 3), 24,
+                         losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, device="cpu").model
+    (lo1, hi1), (lo2, hi2) = m.bucket_ranges()
+    n = m.graph.store.theta.numel()
+    assert lo2 == 0 and hi2 == lo1 and hi1 == n and 0 < lo1 < n
+    assert lo1 == m.graph.store.specs["en_bn_2.0_proj_conv2d_1/kernel"].offset
+    # the late bucket holds the bulk of the parameters
+    assert (hi1 - lo1) > 0.9 * n
+
+
+def test_ops_refuse_cpu_tensors():
+    pooling = pkg("layers.pooling")
+    losses = pkg("losses")
+    with pytest.raises(NotImplementedError, match="works only on GPU"):
+        pooling.MaxPoolingWithArgmax2D()(torch.zeros(1, 4, 4, 2))
+    with pytest.raises(NotImplementedError):
+        pooling.MaxPoolingWithArgmax2D(pool_size=(3, 3))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        losses.segmentation_categorical_cross_entropy_lambda_loss(
+            [torch.zeros(1, 2, 2, 3), torch.zeros(1, 2, 2, dtype=torch.int32), torch.ones(1, 2, 2),
+             torch.zeros(1, 1, dtype=torch.int32)])
+    with pytest.raises(ValueError, match="Expected 4 arguments"):
+        losses.segmentation_categorical_cross_entropy_lambda_loss([torch.zeros(1)])
+    with pytest.raises(ValueError, match="Class weights is None"):
+        losses.segmentation_sparse_weighted_categorical_cross_entropy(None)
+    assert pooling.MaxPoolingWithArgmax2D().compute_output_shape((None, 64, 64, 16)) == [(None, 32, 32, 16)] * 2
+    assert pooling.MaxUnpooling2D().compute_output_shape([(None, 32, 32, 16), (None, 32, 32, 16)]) == (None, 64, 64, 16)
+
+
+def test_metric_factories_carry_the_reference_attributes():
+    metrics = pkg("metrics")
+    cfm = metrics.segmentation_confusion_matrix(24, 0, [0])
+    assert cfm.__name__ == "cfm" and cfm.streaming and cfm.cfm and cfm.hide_from_progbar and cfm.exclude_from_callbacks
+    for f, nm in ((metrics.segmentation_accuracy(0, [0]), "acc"), (metrics.segmentation_mean_iou(24, 0, [0]), "miou"),
+                  (metrics.segmentation_mean_per_class_accuracy(24, 0, [0]), "mpca")):
+        assert f.__name__ == nm and f.streaming and not getattr(f, "cfm", False) and callable(f.reset_op)
