@@ -1,0 +1,427 @@
+"""Per-operator GPU parity through the C ABI against the CPU oracle (fp64), rtol 1e-3 for floating point
+(BASELINE.json north_star), bit-exact for indices and confusion matrices.  Shapes cover the kernel configurations of the
+ENet graphs plus ragged / odd / tie cases."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import tf_keras_ops as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
+
+
+def _check(got, ref, what, rtol=1e-3, atol_rel=1e-4):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = ref.detach().numpy().astype(np.float64) if torch.is_tensor(ref) else np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, "{}: shape {} vs {}".format(what, got.shape, ref.shape)
+    scale = np.abs(ref).max() if ref.size else 0.0
+    err = np.abs(got - ref)
+    bad = err > atol_rel * scale + rtol * np.abs(ref) + 1e-12
+    assert not bad.any(), "{}: {} of {} off, max err {:.3e}, scale {:.3e}".format(what, int(bad.sum()), ref.size, float(err.max()), scale)
+
+
+CONV_CASES = [
+    # kh kw cin cout stride dil padding bias  N  H  W
+    (3, 3, 3, 13, 2, 1, "same", True, 2, 16, 20),      # initial block conv (scalar path, cout < 32)
+    (2, 2, 16, 16, 2, 1, "valid", False, 2, 12, 8),    # downsampling projection
+    (2, 2, 64, 32, 2, 1, "valid", False, 1, 8, 8),
+    (1, 1, 64, 16, 1, 1, "valid", False, 2, 9, 7),     # ragged pixel tiles
+    (1, 1, 16, 64, 1, 1, "valid", False, 1, 8, 8),
+    (1, 1, 32, 128, 1, 1, "valid", False, 1, 8, 8),    # 4 column tiles
+    (1, 1, 128, 32, 1, 1, "valid", False, 1, 6, 6),
+    (3, 3, 16, 16, 1, 1, "same", True, 2, 8, 10),
+    (3, 3, 32, 32, 1, 1, "same", True, 1, 9, 9),
+    (3, 3, 32, 32, 1, 2, "same", True, 1, 8, 8),
+    (3, 3, 32, 32, 1, 16, "same", True, 1, 8, 8),      # dilation larger than the map
+    (1, 5, 32, 32, 1, 1, "same", False, 1, 6, 11),
+    (5, 1, 32, 32, 1, 1, "same", True, 1, 11, 6),
+    (3, 3, 4, 4, 1, 1, "same", True, 2, 8, 8),
+    (1, 1, 4, 16, 1, 1, "valid", False, 1, 8, 8),
+    (1, 1, 64, 4, 1, 1, "valid", False, 1, 8, 8),
+    (3, 3, 5, 7, 2, 1, "same", True, 1, 7, 9),         # odd everything
+    (3, 3, 24, 24, 1, 1, "same", True, 1, 8, 8),       # enhanced head width
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}".format(*c[:7]))
+def test_conv2d_fwd_bwd(case):
+    kh, kw, cin, cout, s, d, pad, bias, N, H, W = case
+    eng = pkg("engine")
+    rng = np.random.RandomState(hash(case) % 2**31)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=s, dil=d, padding=pad, bias=bias)
+    store.materialise(torch.device(DEV))
+    w = rng.standard_normal((kh, kw, cin, cout))
+    b = rng.standard_normal(cout) if bias else None
+    store.views["c/kernel"].copy_(_t(w))
+    if bias:
+        store.views["c/bias"].copy_(_t(b))
+    ho, wo = cv.plan(N, H, W)
+    x = rng.standard_normal((N, H, W, cin))
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = torch.tensor(w, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True) if bias else None
+    yr = K.conv2d(xt, wt, bt, s, d, pad)
+    assert tuple(yr.shape) == (N, ho, wo, cout)
+    dy = rng.standard_normal(tuple(yr.shape))
+    add = rng.standard_normal(x.shape)
+    yr.backward(torch.tensor(dy))
+    st = torch.cuda.current_stream().cuda_stream
+    xd, dyd = _t(x), _t(dy)
+    y = torch.empty(N, ho, wo, cout, device=DEV)
+    cv.fwd(xd, y, st)
+    _check(y, yr, "y")
+    dx = torch.full((N, H, W, cin), 7.0, device=DEV)
+    cv.bwd_data(dyd, dx, st)
+    _check(dx, xt.grad, "dx")
+    cv.bwd_data(dyd, dx, st, add=_t(add))
+    _check(dx, xt.grad + torch.tensor(add), "dx+add")
+    ws = torch.empty(cv.ws_bytes // 4 + 8, device=DEV)
+    cv.bwd_weight(xd, dyd, ws, st)
+    _check(store.gviews["c/kernel"], wt.grad, "dw")
+    if bias:
+        _check(store.gviews["c/bias"], bt.grad, "db")
+
+
+@pytest.mark.parametrize("k,cin,cout,N,H,W", [(3, 16, 16, 2, 6, 5), (3, 4, 4, 1, 8, 8), (2, 16, 24, 2, 5, 7), (2, 16, 5, 1, 4, 4)])
+def test_conv2d_transpose_fwd_bwd(k, cin, cout, N, H, W):
+    eng = pkg("engine")
+    rng = np.random.RandomState(k * 100 + cin)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "t", k, k, cin, cout, stride=2, bias=True, transpose=True)
+    store.materialise(torch.device(DEV))
+    w = rng.standard_normal((k, k, cout, cin))
+    b = rng.standard_normal(cout)
+    store.views["t/kernel"].copy_(_t(w))
+    store.views["t/bias"].copy_(_t(b))
+    ho, wo = cv.plan(N, H, W)
+    assert (ho, wo) == (2 * H, 2 * W)
+    x = rng.standard_normal((N, H, W, cin))
+    xt = torch.tensor(x, requires_grad=True)
+    wt = torch.tensor(w, requires_grad=True)
+    bt = torch.tensor(b, requires_grad=True)
+    yr = K.conv2d_transpose(xt, wt, bt, 2)
+    dy = rng.standard_normal(tuple(yr.shape))
+    yr.backward(torch.tensor(dy))
+    st = torch.cuda.current_stream().cuda_stream
+    y = torch.empty(N, ho, wo, cout, device=DEV)
+    cv.fwd(_t(x), y, st)
+    _check(y, yr, "yt")
+    dx = torch.empty(N, H, W, cin, device=DEV)
+    cv.bwd_data(_t(dy), dx, st)
+    _check(dx, xt.grad, "dxt")
+    ws = torch.empty(cv.ws_bytes // 4 + 8, device=DEV)
+    cv.bwd_weight(_t(x), _t(dy), ws, st)
+    _check(store.gviews["t/kernel"], wt.grad, "dw")
+    _check(store.gviews["t/bias"], bt.grad, "db")
+
+
+@pytest.mark.parametrize("c,npix,act", [(16, 1000, 1), (4, 333, 1), (128, 260, 1), (64, 77, 0), (24, 50, 2)])
+def test_bn_act_fwd_bwd(c, npix, act):
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(c + npix)
+    x = rng.standard_normal((1, 1, npix, c)) * 2 + 0.5
+    gamma, beta = rng.uniform(0.5, 1.5, c), rng.uniform(-0.5, 0.5, c)
+    alpha = rng.uniform(0.05, 0.4, c)
+    mm, mv = rng.standard_normal(c), rng.uniform(0.5, 2, c)
+    xt = torch.tensor(x, requires_grad=True)
+    gt, bt, at = (torch.tensor(v, requires_grad=True) for v in (gamma, beta, alpha))
+    z, mean, var = K.batch_norm_train(xt, gt, bt)
+    yr = K.prelu(z, at) if act == 1 else (K.leaky_relu(z, 0.1) if act == 2 else z)
+    dy = rng.standard_normal(x.shape)
+    yr.backward(torch.tensor(dy))
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(L.bn_workspace_bytes(npix, c) // 4 + 8, device=DEV)
+    xd = _t(x)
+    mmd, mvd = _t(mm), _t(mv)
+    mean_d, inv_d = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    L.bn_train_stats(xd.data_ptr(), npix, c, c, 1e-3, 0.1, 0, mmd.data_ptr(), mvd.data_ptr(), mean_d.data_ptr(), inv_d.data_ptr(),
+                     ws.data_ptr(), ws.numel() * 4, st)
+    _check(mean_d, mean, "mean")
+    _check(inv_d, torch.rsqrt(var + 1e-3), "invstd")
+    _check(mmd, 0.1 * mm + 0.9 * mean.detach().numpy(), "moving_mean")
+    _check(mvd, 0.1 * mv + 0.9 * var.detach().numpy(), "moving_var")
+    g_d, b_d, a_d = _t(gamma), _t(beta), _t(alpha)
+    y = torch.empty(npix, c, device=DEV)
+    L.bn_act_fwd(xd.data_ptr(), c, mean_d.data_ptr(), inv_d.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), act, a_d.data_ptr(), 0.1,
+                 y.data_ptr(), npix, c, st)
+    _check(y.view(1, 1, npix, c), yr, "y")
+    dx, dg, db, da = (torch.empty(s, device=DEV) for s in ((npix, c), (c,), (c,), (c,)))
+    L.bn_act_bwd(_t(dy).data_ptr(), xd.data_ptr(), c, mean_d.data_ptr(), inv_d.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), act,
+                 a_d.data_ptr(), 0.1, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), da.data_ptr(), npix, c, ws.data_ptr(),
+                 ws.numel() * 4, st)
+    _check(dx.view(1, 1, npix, c), xt.grad, "dx")
+    _check(dg, gt.grad, "dgamma")
+    _check(db, bt.grad, "dbeta")
+    if act == 1:
+        _check(da, at.grad, "dalpha")
+    # unbiased moving variance flag + inference statistics
+    mvd2 = _t(mv)
+    L.bn_train_stats(xd.data_ptr(), npix, c, c, 1e-3, 0.1, 1, None, mvd2.data_ptr(), mean_d.data_ptr(), inv_d.data_ptr(),
+                     ws.data_ptr(), ws.numel() * 4, st)
+    _check(mvd2, 0.1 * mv + 0.9 * var.detach().numpy() * npix / (npix - 1), "moving_var unbiased")
+    L.bn_infer_stats(_t(mm).data_ptr(), _t(mv).data_ptr(), c, 1e-3, mean_d.data_ptr(), inv_d.data_ptr(), st)
+    _check(inv_d, 1 / np.sqrt(mv + 1e-3), "infer invstd")
+
+
+@pytest.mark.parametrize("mode,c,c_other,drop", [(0, 64, 64, True), (0, 16, 16, False), (1, 64, 16, True), (1, 128, 64, True),
+                                                (2, 64, 64, True), (2, 16, 16, False), (3, 64, 64, False), (3, 16, 16, False)])
+def test_merge_fwd_bwd(mode, c, c_other, drop):
+    lib_mod = pkg("_lib")
+    L = lib_mod.lib()
+    rng = np.random.RandomState(mode * 1000 + c)
+    n, h, w = 2, 6, 8
+    main = rng.standard_normal((n, h, w, c))
+    g3, b3 = rng.uniform(0.5, 1.5, c), rng.uniform(-0.3, 0.3, c)
+    alpha = rng.uniform(0.05, 0.4, c)
+    dropm = (rng.uniform(size=(n, c)) > 0.3) / 0.7 if drop else None
+    mt = torch.tensor(main, requires_grad=True)
+    g3t, b3t, at = (torch.tensor(v, requires_grad=True) for v in (g3, b3, alpha))
+    z3, mean3, var3 = K.batch_norm_train(mt, g3t, b3t)
+    if drop:
+        z3 = K.spatial_dropout(z3, torch.tensor(dropm))
+    idx_np = None
+    if mode == 0:
+        other = rng.standard_normal((n, h, w, c))
+        ot = torch.tensor(other, requires_grad=True)
+        o2 = ot
+    elif mode == 1:
+        other = rng.standard_normal((n, h, w, c_other))
+        ot = torch.tensor(other, requires_grad=True)
+        o2 = K.channel_zero_pad(ot, c)
+    else:
+        other = rng.standard_normal((n, h // 2, w // 2, c))
+        go, bo = rng.uniform(0.5, 1.5, c), rng.uniform(-0.3, 0.3, c)
+        ot = torch.tensor(other, requires_grad=True)
+        got_, bot_ = torch.tensor(go, requires_grad=True), torch.tensor(bo, requires_grad=True)
+        zo, mean_o, var_o = K.batch_norm_train(ot, got_, bot_)
+        zo.retain_grad()
+        if mode == 2:
+            o2 = K.upsample_nn2(zo)
+        else:
+            src = rng.standard_normal((n, h, w, c)).astype(np.float32)
+            _, idx_np = K.max_pool_with_argmax_np(src)
+            o2 = K.max_unpool(zo, torch.from_numpy(idx_np))
+    sr = z3 + o2
+    outr = K.prelu(sr, at)
+    dout = rng.standard_normal((n, h, w, c))
+    outr.backward(torch.tensor(dout))
+
+    st = torch.cuda.current_stream().cuda_stream
+    md = lib_mod.MergeDesc(n, h, w, c, mode, c_other)
+    bn3 = lib_mod.BnParams(*(t.data_ptr() for t in (_t(mean3.detach().numpy()), _t(torch.rsqrt(var3 + 1e-3).detach().numpy()), _t(g3), _t(b3))))
+    keep = []
+
+    def P(a, dtype=torch.float32):
+        t = _t(a, dtype)
+        keep.append(t)
+        return t
+    bn3 = lib_mod.BnParams(P(mean3.detach().numpy()).data_ptr(), P(torch.rsqrt(var3 + 1e-3).detach().numpy()).data_ptr(),
+                           P(g3).data_ptr(), P(b3).data_ptr())
+    bno = None
+    if mode >= 2:
+        bno = lib_mod.BnParams(P(mean_o.detach().numpy()).data_ptr(), P(torch.rsqrt(var_o + 1e-3).detach().numpy()).data_ptr(),
+                               P(go).data_ptr(), P(bo).data_ptr())
+    main_d, other_d, alpha_d = P(main), P(other), P(alpha)
+    drop_d = P(dropm) if drop else None
+    idx_d = P(idx_np, torch.int32) if idx_np is not None else None
+    out = torch.empty(n, h, w, c, device=DEV)
+    L.merge_fwd(C.byref(md), main_d.data_ptr(), C.byref(bn3), None if drop_d is None else drop_d.data_ptr(), other_d.data_ptr(),
+                None if bno is None else C.byref(bno), None if idx_d is None else idx_d.data_ptr(), alpha_d.data_ptr(),
+                out.data_ptr(), st)
+    _check(out, outr, "out")
+    ws = torch.empty(L.merge_workspace_bytes(C.byref(md)) // 4 + 8, device=DEV)
+    dmain, dsum = torch.empty_like(out), torch.empty_like(out)
+    dother = torch.empty(n, h // 2, w // 2, c, device=DEV) if mode >= 2 else None
+    dg, db, da = (torch.empty(c, device=DEV) for _ in range(3))
+    L.merge_bwd(C.byref(md), P(dout).data_ptr(), main_d.data_ptr(), C.byref(bn3), None if drop_d is None else drop_d.data_ptr(),
+                other_d.data_ptr(), None if bno is None else C.byref(bno), None if idx_d is None else idx_d.data_ptr(),
+                alpha_d.data_ptr(), dmain.data_ptr(), dsum.data_ptr(), None if dother is None else dother.data_ptr(),
+                dg.data_ptr(), db.data_ptr(), da.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+    _check(dmain, mt.grad, "dmain")
+    _check(dg, g3t.grad, "dgamma3")
+    _check(db, b3t.grad, "dbeta3")
+    _check(da, at.grad, "dalpha")
+    if mode == 0:
+        _check(dsum, ot.grad, "dsum")
+    elif mode == 1:
+        _check(dsum[..., :c_other], ot.grad, "dsum[:c_other]")
+    else:
+        _check(dother, zo.grad, "dother_bn")
+
+
+@pytest.mark.parametrize("n,h,w,c", [(2, 8, 8, 16), (1, 7, 9, 3), (2, 6, 4, 64), (1, 2, 2, 1), (1, 5, 5, 4)])
+def test_maxpool_argmax_unpool_bit_exact(n, h, w, c):
+    pooling = pkg("layers.pooling")
+    rng = np.random.RandomState(h * 10 + c)
+    x = rng.randint(-3, 4, size=(n, h, w, c)).astype(np.float32)      # small integers -> many ties
+    yr, ir = K.max_pool_with_argmax_np(x)
+    xd = _t(x).requires_grad_(True)
+    y, idx_f = pooling.MaxPoolingWithArgmax2D()(xd)
+    assert idx_f.dtype == torch.float32
+    assert np.array_equal(y.detach().cpu().numpy(), yr)
+    assert np.array_equal(idx_f.cpu().numpy().astype(np.int64), ir)
+    dy = rng.standard_normal(yr.shape).astype(np.float32)
+    y.backward(_t(dy))
+    dxr = np.zeros((n, h * w * c), dtype=np.float32)
+    np.add.at(dxr, (np.arange(n)[:, None], ir.reshape(n, -1)), dy.reshape(n, -1))
+    assert np.array_equal(xd.grad.cpu().numpy().reshape(n, -1), dxr)
+    if h % 2 == 0 and w % 2 == 0:
+        vals = _t(rng.standard_normal(yr.shape).astype(np.float32)).requires_grad_(True)
+        up = pooling.MaxUnpooling2D()([vals, idx_f])
+        upr = K.max_unpool_np(vals.detach().cpu().numpy(), ir)
+        assert np.array_equal(up.detach().cpu().numpy(), upr)
+        g = rng.standard_normal(upr.shape).astype(np.float32)
+        up.backward(_t(g))
+        assert np.array_equal(vals.grad.cpu().numpy().reshape(n, -1), np.take_along_axis(g.reshape(n, -1), ir.reshape(n, -1), 1))
+        # window-local fast path gives the same tensor
+        L = pkg("_lib").lib()
+        idx_i = _t(ir, torch.int32)
+        out = torch.empty(n, h, w, c, device=DEV)
+        L.maxunpool_local_fwd(vals.data_ptr(), idx_i.data_ptr(), n, h // 2, w // 2, c, out.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+        assert np.array_equal(out.cpu().numpy(), upr)
+
+
+def test_maxunpool_general_indices_sum_duplicates():
+    pooling = pkg("layers.pooling")
+    vals = _t(np.array([[[[1.0], [2.0]], [[3.0], [4.0]]]], dtype=np.float32))        # [1,2,2,1]
+    idx = _t(np.array([[[[5.0], [5.0]], [[0.0], [15.0]]]], dtype=np.float32))
+    out = pooling.MaxUnpooling2D()([vals, idx]).cpu().numpy().reshape(-1)
+    exp = np.zeros(16, dtype=np.float32)
+    exp[5], exp[0], exp[15] = 3.0, 3.0, 4.0          # tf.scatter_nd sums duplicates
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("C_,npix", [(24, 5000), (24, 77), (5, 1000), (33, 300), (2, 64)])
+def test_softmax_xent_loss_grad_cm(C_, npix):
+    losses = pkg("losses")
+    metrics = pkg("metrics")
+    rng = np.random.RandomState(C_ + npix)
+    logits = rng.standard_normal((1, 1, npix, C_)) * 3
+    labels = rng.randint(0, C_, size=(1, 1, npix))
+    cw = rng.uniform(0.5, 2.0, C_)
+    cw[0] = 0
+    pw = cw[labels]
+    zt = torch.tensor(logits, requires_grad=True)
+    lr = K.sparse_weighted_pixelwise_xent(zt, torch.tensor(labels), torch.tensor(pw))
+    lr.backward()
+    loss = losses.segmentation_categorical_cross_entropy_lambda_loss(
+        [_t(logits), _t(labels, torch.int32), _t(pw), torch.zeros(1, 1, dtype=torch.int32, device=DEV)])
+    _check(loss, lr, "loss")
+    _check(losses.last_gradient(), zt.grad, "dlogits")
+    f = losses.segmentation_sparse_weighted_categorical_cross_entropy(cw)
+    _check(f(_t(labels[..., None], torch.int32), _t(logits)), lr, "class-weight form")
+    assert losses.dummy_loss(None, loss) is loss
+    # confusion matrix: bit-exact against numpy on the float32 logits the kernel sees, cumulative, resettable
+    l32 = logits.astype(np.float32)
+    cmf = metrics.segmentation_confusion_matrix(C_, 0, [0])
+    cm1 = cmf(_t(labels[..., None], torch.int32), _t(l32))
+    ref = K.confusion_matrix_np(labels, l32, C_, [0])
+    assert cm1.dtype == np.int64 and np.array_equal(cm1, ref)
+    cm2 = cmf(_t(labels[..., None], torch.int32), _t(l32))
+    assert np.array_equal(cm2, 2 * ref)
+    cmf.reset_op()
+    assert np.array_equal(cmf(_t(labels[..., None], torch.int32), _t(l32)), ref)
+    acc = metrics.segmentation_accuracy(0, [0])(_t(labels[..., None], torch.int32), _t(l32))
+    assert abs(acc - K.cfm_accuracy(ref)) < 1e-12
+    miou = metrics.segmentation_mean_iou(C_, 0, [0])(_t(labels[..., None], torch.int32), _t(l32))
+    assert abs(miou - K.tf_mean_iou(ref)) < 1e-12
+
+
+def test_softmax_xent_argmax_ties_and_extreme_logits():
+    metrics = pkg("metrics")
+    losses = pkg("losses")
+    logits = np.zeros((1, 1, 4, 24), dtype=np.float32)
+    logits[0, 0, 1, [3, 7]] = 2.0            # tie -> lowest index 3
+    logits[0, 0, 2, 23] = 80.0               # large but finite: stable softmax
+    logits[0, 0, 3, :] = -1e4
+    labels = np.array([[[5, 3, 23, 1]]], dtype=np.int32)
+    cm = metrics.segmentation_confusion_matrix(24, 0, None)(_t(labels[..., None], torch.int32), _t(logits))
+    assert cm[5, 0] == 1 and cm[3, 3] == 1 and cm[23, 23] == 1 and cm[1, 0] == 1 and cm.sum() == 4
+    loss = losses.segmentation_categorical_cross_entropy_lambda_loss(
+        [_t(logits), _t(labels, torch.int32), torch.ones(1, 1, 4, device=DEV), torch.zeros(1, 1, dtype=torch.int32, device=DEV)])
+    ref = K.sparse_weighted_pixelwise_xent(torch.tensor(logits, dtype=torch.float64), torch.tensor(labels), torch.ones(1, 1, 4, dtype=torch.float64))
+    _check(loss, ref, "loss")
+    assert np.isfinite(losses.last_gradient().cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("kind", ["adam", "adam_amsgrad_decay_scalers", "sgd", "sgd_nesterov_decay"])
+def test_optimizers_three_steps(kind):
+    eng = pkg("engine")
+    xo = pkg("keras_extensions.extended_optimizers")
+    rng = np.random.RandomState(7)
+    store = eng.ParamStore()
+    shapes = [(3, 3, 4, 5), (5,), (1, 1, 7), (13,)]
+    for i, s in enumerate(shapes):
+        store.add("p{}".format(i), s)
+    store.materialise(torch.device(DEV))
+    p0 = [rng.standard_normal(s) for s in shapes]
+    for i, v in enumerate(p0):
+        store.views["p{}".format(i)].copy_(_t(v))
+    scal = {1: 0.5, 3: 2.0}
+    if kind == "adam":
+        opt, kw = xo.Adam(lr=1e-2), dict(lr=1e-2)
+    elif kind == "adam_amsgrad_decay_scalers":
+        opt, kw = xo.Adam(lr=1e-2, decay=0.1, amsgrad=True, lr_scalers=scal), dict(lr=1e-2, decay=0.1, lr_scalers=scal)
+    elif kind == "sgd":
+        opt, kw = xo.SGD(lr=0.1, momentum=0.9), dict(lr=0.1, momentum=0.9)
+    else:
+        opt, kw = xo.SGD(lr=0.1, momentum=0.8, decay=0.05, nesterov=True, lr_scalers=scal), dict(lr=0.1, momentum=0.8, decay=0.05, nesterov=True, lr_scalers=scal)
+    opt.bind(store)
+    ps = [torch.tensor(v) for v in p0]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    vh = [torch.zeros_like(p) for p in ps] if "amsgrad" in kind else None
+    for it in range(3):
+        gs = [rng.standard_normal(s) for s in shapes]
+        for i, g in enumerate(gs):
+            store.gviews["p{}".format(i)].copy_(_t(g))
+        opt.apply(grad_scale=0.5)
+        gt = [torch.tensor(g) * 0.5 for g in gs]
+        if kind.startswith("adam"):
+            K.adam_step(ps, gt, ms, vs, it, vhats=vh, **kw)
+        else:
+            K.sgd_step(ps, gt, ms, it, **kw)
+        assert opt.iterations == it + 1
+        for i, p in enumerate(ps):
+            _check(store.views["p{}".format(i)], p, "{} step {} p{}".format(kind, it, i), rtol=1e-4, atol_rel=1e-5)
+
+
+def test_dropout_table_statistics_and_replay():
+    L = pkg("_lib").lib()
+    n = 1 << 16
+    m = torch.empty(n, device=DEV)
+    step = torch.zeros(2, dtype=torch.int64, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    L.dropout_mask(m.data_ptr(), n, 0.1, 14874, step.data_ptr(), 0, st)
+    a = m.cpu().numpy()
+    assert set(np.unique(a)).issubset({0.0, np.float32(1 / 0.9)})
+    assert abs((a == 0).mean() - 0.1) < 0.01
+    L.dropout_mask(m.data_ptr(), n, 0.1, 14874, step.data_ptr(), 0, st)
+    assert np.array_equal(m.cpu().numpy(), a)                 # same (seed, step, stream) -> same table
+    step[0] = 1
+    L.dropout_mask(m.data_ptr(), n, 0.1, 14874, step.data_ptr(), 0, st)
+    assert (m.cpu().numpy() != a).mean() > 0.1                # next step -> fresh draw
+    L.dropout_mask(m.data_ptr(), n, 0.0, 1, step.data_ptr(), 3, st)
+    assert (m.cpu().numpy() == 1).all()
+
+
+def test_error_reporting_through_the_abi():
+    lib_mod = pkg("_lib")
+    L = lib_mod.lib()
+    with pytest.raises(lib_mod.SsmiError, match="num_classes"):
+        L.softmax_xent_fwd_bwd(1, 1, 1, 10, 100, 1.0, None, 1, None, 0, 0, None, None, 1, 1 << 20, None)
+    with pytest.raises(lib_mod.SsmiError, match="multiple of 4"):
+        L.bn_act_fwd(1, 6, 1, 1, 1, 1, 0, None, 0.0, 1, 10, 6, None)
+    d = lib_mod.ConvDesc(1, 4, 4, 3, 4, 4, 3, 3, 3, 1, 1, 1, 1, 2, 3)     # x_ld < cin
+    with pytest.raises(lib_mod.SsmiError, match="leading dimension"):
+        L.conv2d_fwd(C.byref(d), 1, 1, None, 1, None)
