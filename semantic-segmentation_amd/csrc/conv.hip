@@ -373,6 +373,202 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, Sizes sz, W
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// weight gradient, LDS-staged variant (used whenever the staging tiles fit): a workgroup walks its strip of output
+// rows in chunks of P output pixels.  Per chunk all 256 threads fetch the dy chunk [P][cout] and the x patch
+// [kh][Wp][cin] that the chunk's taps touch with 16-byte buffer loads (zero padding comes from the bounds check), park
+// them in registers while the previous chunk is being multiplied, then drop them into LDS.  The MFMA operands are
+// plain ds_read_b32: lane (r, hh) of tile (kt, ct) reads x-patch word [tap(k), pixel 2*step+hh, ci(k)] and dy word
+// [pixel 2*step+hh][ct*32 + r].  Rows k >= K read a zero word, the bias row reads a ones/zeros vector.
+// ---------------------------------------------------------------------------------------------------
+struct WgLds {
+  int P, Wp;            // output pixels per chunk, x-patch width in input pixels
+  int xv_n, yv_n;       // 16-byte (VEC) or 4-byte elements per thread for the x patch / dy chunk
+  int x_elems, y_elems; // number of such elements
+  int coutp;            // dy chunk row length in LDS (cotiles * 32)
+  int ones_off, zero_off, yl_off;   // word offsets inside the LDS block
+  int lds_words;
+};
+static constexpr int kXvMax = 12, kYvMax = 8;
+
+// M16: 16x16 output tiles on v_mfma_f32_16x16x4_f32 (4 pixels per step) for cout <= 16, where 32-wide tiles would
+// spend half or more of the matrix core on padding columns.
+template <int TPW, bool VEC, bool M16>
+__global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgArgs a, WgLds l, const float* __restrict__ x,
+                                                           const float* __restrict__ dy, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  constexpr int TS = M16 ? 16 : 32;      // tile edge
+  constexpr int KQ = 64 / TS;            // pixels consumed per MFMA step
+  constexpr int NR = M16 ? 4 : 16;       // accumulator registers per tile
+  const int r = lane & (TS - 1), hh = lane / TS;
+  const int strip = blockIdx.x;
+  const int tile0 = blockIdx.y * (a.wps * TPW) + wave;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), ry = make_rsrc(dy, sz.y_bytes);
+  constexpr int EW = VEC ? 4 : 1;   // floats per staged element
+
+  // ---- per-lane MFMA operand addressing (fixed for the whole kernel) ----
+  bool colv[TPW];
+  int kt_[TPW], col[TPW], abase[TPW], astr[TPW];
+  bool has_tile = false;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = tile0 + a.wps * j;
+    const bool tv = (wave < a.wps) && t < a.T;
+    has_tile |= tv;
+    const int ts = tv ? t : 0;
+    const int kt = ts / a.cotiles, ct = ts % a.cotiles;
+    kt_[j] = kt;
+    const int k = kt * TS + r;
+    const bool kv = tv && k < a.K;
+    const bool kb = tv && (k == a.K) && (a.K_aug > a.K);
+    const int ks = kv ? k : 0;
+    const int tap = ks / g.cin, ci = ks % g.cin;
+    const int ky = tap / g.kw, kx = tap % g.kw;
+    abase[j] = kv ? ((ky * l.Wp + kx * g.dil + hh * g.stride) * g.cin + ci) : (kb ? l.ones_off + hh : l.zero_off);
+    astr[j] = kv ? KQ * g.stride * g.cin : (kb ? KQ : 0);
+    col[j] = ct * TS + r;
+    colv[j] = tv && col[j] < g.cout;
+  }
+  typedef float accv __attribute__((ext_vector_type(NR)));
+  accv acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int i = 0; i < NR; ++i) acc[j][i] = 0.f;
+
+  // ---- per-thread staging maps (independent of the chunk) ----
+  // x patch element e -> (ky, colp, c): LDS word = e*EW; global = row(ky) + colp*x_ld + c
+  int x_kyd[kXvMax], x_colp[kXvMax];
+  unsigned x_rel[kXvMax];
+  const int cin_e = g.cin / EW;   // elements per pixel (VEC requires cin % 4 == 0)
+#pragma unroll
+  for (int i = 0; i < kXvMax; ++i) {
+    const int e = tid + i * 256;
+    const int es = e < l.x_elems ? e : 0;
+    const int c = (es % cin_e) * EW;
+    const int t = es / cin_e;
+    x_colp[i] = t % l.Wp;
+    x_kyd[i] = (t / l.Wp) * g.dil;
+    x_rel[i] = (unsigned)c * 4u;
+    if (e >= l.x_elems) x_kyd[i] = -(1 << 28);   // always out of range -> loads nothing
+  }
+  int y_p[kYvMax];
+  unsigned y_rel[kYvMax];
+  const int cout_e = (g.cout + EW - 1) / EW;
+#pragma unroll
+  for (int i = 0; i < kYvMax; ++i) {
+    const int e = tid + i * 256;
+    const int es = e < l.y_elems ? e : 0;
+    y_p[i] = e < l.y_elems ? es / cout_e : (1 << 28);
+    y_rel[i] = (unsigned)((es % cout_e) * EW) * 4u;
+  }
+  // zero the whole block once (pad columns of the dy chunk, the zero word)
+  for (int i = tid; i < l.lds_words; i += 256) smem[i] = 0.f;
+
+  const int R = g.n * g.ho;
+  const int row0 = strip * a.rows_per_strip;
+  const int row1 = min(R, row0 + a.rows_per_strip);
+  const int cpr = (g.wo + l.P - 1) / l.P;
+  const int nchunks = (row1 - row0) * cpr;
+  const unsigned xpix = (unsigned)g.x_ld * 4u, ypix = (unsigned)g.y_ld * 4u;
+
+  f32x4 xr[kXvMax], yr[kYvMax];
+  auto prefetch = [&](int ch) {
+    const bool cv = ch < nchunks;
+    const int chs = cv ? ch : 0;
+    const int row = row0 + chs / cpr;
+    const int ox0 = (chs % cpr) * l.P;
+    const int n_ = row / g.ho, oy = row % g.ho;
+    const int iy0 = oy * g.stride - g.pad_t, ix0 = ox0 * g.stride - g.pad_l;
+    const int pv = min(l.P, g.wo - ox0);
+#pragma unroll
+    for (int i = 0; i < kXvMax; ++i) {
+      if (i < l.xv_n) {
+        const int iy = iy0 + x_kyd[i], ix = ix0 + x_colp[i];
+        const bool ok = cv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const unsigned off = ok ? (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i] : kOOB;
+        if (VEC) xr[i] = bload4(rx, off);
+        else xr[i][0] = bload(rx, off);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kYvMax; ++i) {
+      if (i < l.yv_n) {
+        const bool ok = cv && y_p[i] < pv;
+        const unsigned off = ok ? (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i] : kOOB;
+        if (VEC) yr[i] = bload4(ry, off);
+        else yr[i][0] = bload(ry, (ok && (y_rel[i] >> 2) < (unsigned)g.cout) ? off : kOOB);
+      }
+    }
+  };
+  auto commit = [&](int ch) {
+    const int ox0 = (ch % cpr) * l.P;
+    const int pv = min(l.P, g.wo - ox0);
+#pragma unroll
+    for (int i = 0; i < kXvMax; ++i) {
+      if (i < l.xv_n) {
+        const int e = tid + i * 256;
+        if (e < l.x_elems) {
+          if (VEC) *reinterpret_cast<f32x4*>(smem + e * 4) = xr[i];
+          else smem[e] = xr[i][0];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kYvMax; ++i) {
+      if (i < l.yv_n) {
+        const int e = tid + i * 256;
+        if (e < l.y_elems) {
+          float* dst = smem + l.yl_off + y_p[i] * l.coutp + (y_rel[i] >> 2);
+          if (VEC) *reinterpret_cast<f32x4*>(dst) = yr[i];
+          else *dst = yr[i][0];
+        }
+      }
+    }
+    if (tid < l.P) smem[l.ones_off + tid] = tid < pv ? 1.f : 0.f;
+    return pv;
+  };
+
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();            // everyone is done reading the previous chunk
+    const int pv = commit(ch);
+    __syncthreads();
+    prefetch(ch + 1);           // in flight while this chunk is multiplied
+    if (has_tile) {
+      const int steps = (pv + KQ - 1) / KQ;
+      const float* yl = smem + l.yl_off + hh * l.coutp;
+#pragma unroll 4
+      for (int st = 0; st < steps; ++st) {
+        float av[TPW], bv[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          av[j] = smem[abase[j] + st * astr[j]];
+          bv[j] = yl[st * KQ * l.coutp + col[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[j], 0, 0, 0);
+          else acc[j] = MFMA32(av[j], bv[j], acc[j]);
+        }
+      }
+    }
+  }
+
+  float* pbase = part + (int64_t)strip * a.K_aug * g.cout;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (!colv[j]) continue;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int kk = M16 ? kt_[j] * 16 + hh * 4 + i : kt_[j] * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (kk < a.K_aug) pbase[(int64_t)kk * g.cout + col[j]] = acc[j][i];
+    }
+  }
+}
+
 // Strip reduction: 16 outputs x 16 strip-slices per workgroup; every thread adds its strips (slice, slice+16, ...) with
 // four independent accumulators, the 16 slices are then combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __restrict__ part, int nstrips, int K,
@@ -405,32 +601,61 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __res
   }
 }
 
-// column sums of a [npix, c] matrix with row stride ld (bias gradient of a transposed convolution)
+// column sums of a [npix, c] matrix with row stride ld (bias gradient of a transposed convolution).
+// VEC (c % 4 == 0, ld % 4 == 0): thread = (pixel lane, group of 4 channels), 16-byte loads, grid-stride over pixels.
+template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ x, int64_t npix, int c, int ld,
                                                       float* __restrict__ part) {
-  // thread t handles column (t % c) for rows t / c + k * rows_per_iter
-  const int ppi = 256 / c;  // c <= 256 checked on the host
-  const int cc = threadIdx.x % c, pl = threadIdx.x / c;
-  __shared__ float sm[256];
-  float s = 0.f;
+  constexpr int EW = VEC ? 4 : 1;
+  const int ce = c / EW;                 // elements per pixel
+  const int ppi = 256 / ce;              // pixels per iteration (c <= 256 checked on the host)
+  const int cc = threadIdx.x % ce, pl = threadIdx.x / ce;
+  __shared__ f32x4 sm[256];
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
   if (pl < ppi) {
-    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) s += x[p * ld + cc];
+    const int64_t stride = (int64_t)gridDim.x * ppi;
+    int64_t p = (int64_t)blockIdx.x * ppi + pl;
+    for (; p + stride < npix; p += 2 * stride) {
+      if (VEC) {
+        s0 += *reinterpret_cast<const f32x4*>(x + p * ld + cc * 4);
+        s1 += *reinterpret_cast<const f32x4*>(x + (p + stride) * ld + cc * 4);
+      } else {
+        s0[0] += x[p * ld + cc];
+        s1[0] += x[(p + stride) * ld + cc];
+      }
+    }
+    if (p < npix) {
+      if (VEC) s0 += *reinterpret_cast<const f32x4*>(x + p * ld + cc * 4);
+      else s0[0] += x[p * ld + cc];
+    }
   }
-  sm[threadIdx.x] = (pl < ppi) ? s : 0.f;
+  sm[threadIdx.x] = (pl < ppi) ? s0 + s1 : f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
-  if (threadIdx.x < c) {
-    float t = 0.f;
-    for (int q = 0; q < ppi; ++q) t += sm[q * c + threadIdx.x];
-    part[(int64_t)blockIdx.x * c + threadIdx.x] = t;
+  if (threadIdx.x < ce) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < ppi; ++q) t += sm[q * ce + threadIdx.x];
+    float* dst = part + (int64_t)blockIdx.x * c + threadIdx.x * EW;
+    if (VEC) *reinterpret_cast<f32x4*>(dst) = t;
+    else *dst = t[0];
   }
 }
 
-__global__ void colsum_final(const float* __restrict__ part, int nblocks, int c, float* __restrict__ out) {
-  const int cc = blockIdx.x * blockDim.x + threadIdx.x;
-  if (cc >= c) return;
+__global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ part, int nblocks, int c,
+                                                    float* __restrict__ out) {
+  // 8 channels x 32 block-slices per workgroup
+  __shared__ double sm[256];
+  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int slice = threadIdx.x >> 3;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += (double)part[(int64_t)b * c + cc];
-  out[cc] = (float)s;
+  if (ch < c)
+    for (int b = slice; b < nblocks; b += 32) s += (double)part[(int64_t)b * c + ch];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < 8 && ch < c) {
+    double t = 0.0;
+    for (int q = 0; q < 32; ++q) t += sm[q * 8 + threadIdx.x];
+    out[ch] = (float)t;
+  }
 }
 
 static ssmi_status check_desc(const ssmi_conv_desc* d) {
@@ -507,6 +732,8 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
 
 struct WgPlan {
   WgArgs a;
+  WgLds l;
+  bool use_lds, vec, m16;
   int tpw, groups, blocks_x;
   size_t bytes;
 };
@@ -516,19 +743,55 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
   WgArgs& a = p.a;
   a.K = g.kh * g.kw * g.cin;
   a.K_aug = a.K + (with_bias ? 1 : 0);
-  a.ktiles = (a.K_aug + 31) / 32;
-  a.cotiles = (g.cout + 31) / 32;
-  a.T = a.ktiles * a.cotiles;
-  a.wps = a.T < 4 ? a.T : 4;
-  int tpw = (a.T + 3) / 4;
-  if (tpw > 3) tpw = 3;
-  if (tpw < 1) tpw = 1;
-  p.tpw = tpw;
-  p.groups = (a.T + a.wps * tpw - 1) / (a.wps * tpw);
-  const int spb = 4 / a.wps;
   const int R = g.n * g.ho;
-  // about one workgroup per CU per tile group; more strips only add partial-sum traffic
-  int target = (256 * spb) / p.groups;
+  auto tiles = [&](int ts) {
+    a.ktiles = (a.K_aug + ts - 1) / ts;
+    a.cotiles = (g.cout + ts - 1) / ts;
+    a.T = a.ktiles * a.cotiles;
+    a.wps = a.T < 4 ? a.T : 4;
+    int tpw = (a.T + 3) / 4;
+    if (tpw > 3) tpw = 3;
+    if (tpw < 1) tpw = 1;
+    p.tpw = tpw;
+    p.groups = (a.T + a.wps * tpw - 1) / (a.wps * tpw);
+  };
+  p.m16 = g.cout <= 16;
+  tiles(p.m16 ? 16 : 32);
+
+  // LDS-staged variant
+  WgLds& l = p.l;
+  p.vec = (g.cin % 4 == 0) && (g.cout % 4 == 0) && (g.x_ld % 4 == 0) && (g.y_ld % 4 == 0);
+  const int ew = p.vec ? 4 : 1;
+  l.coutp = a.cotiles * (p.m16 ? 16 : 32);
+  // chunk = the longest run of output pixels of one row whose staging fits the per-thread register budget and 64 KiB
+  // of LDS (long chunks keep more bytes in flight per workgroup and amortise the two barriers per chunk)
+  const int wo_even = (g.wo + 3) & ~3;   // multiple of the pixels per MFMA step
+  p.use_lds = false;
+  for (int P = wo_even < 256 ? wo_even : 256; P >= 4; P = (P > 64 ? P - 32 : P - 4)) {
+    l.P = P;
+    l.Wp = (P - 1) * g.stride + (g.kw - 1) * g.dil + 1;
+    l.x_elems = g.kh * l.Wp * (g.cin / ew);
+    l.y_elems = P * ((g.cout + ew - 1) / ew);
+    l.xv_n = (l.x_elems + 255) / 256;
+    l.yv_n = (l.y_elems + 255) / 256;
+    const int xw = (g.kh * l.Wp * g.cin + 3) & ~3;
+    l.ones_off = xw;
+    l.zero_off = xw + ((P + 3) & ~3);
+    l.yl_off = l.zero_off + 4;
+    l.lds_words = l.yl_off + P * l.coutp;
+    if (l.xv_n <= kXvMax && l.yv_n <= kYvMax && l.lds_words * 4 <= 64 * 1024) {
+      p.use_lds = true;
+      break;
+    }
+  }
+  if (!p.use_lds && p.m16) {   // the direct kernel only has 32x32 tiles
+    p.m16 = false;
+    tiles(32);
+  }
+
+  const int spb = p.use_lds ? 1 : 4 / a.wps;
+  // about two workgroups per CU per tile group; more strips only add partial-sum traffic
+  int target = ((p.use_lds ? 512 : 256) * spb) / p.groups;
   if (target < spb) target = spb;
   if (target > R) target = R;
   a.rows_per_strip = (R + target - 1) / target;
@@ -553,9 +816,19 @@ static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* 
                ws_bytes, p.bytes);
   float* part = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
+  if (p.use_lds) {
+    const size_t lds = (size_t)p.l.lds_words * 4;
+#define LL(TPW, V, M) hipLaunchKernelGGL((conv_bwd_weight_lds<TPW, V, M>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part)
+#define LT(V, M) do { if (p.tpw == 1) LL(1, V, M); else if (p.tpw == 2) LL(2, V, M); else LL(3, V, M); } while (0)
+    if (p.vec) { if (p.m16) LT(true, true); else LT(true, false); }
+    else { if (p.m16) LT(false, true); else LT(false, false); }
+#undef LT
+#undef LL
+  } else {
 #define L(TPW) hipLaunchKernelGGL((conv_bwd_weight_kernel<TPW>), grid, dim3(256), 0, st, g, sz, p.a, x, dy, part)
-  if (p.tpw == 1) L(1); else if (p.tpw == 2) L(2); else L(3);
+    if (p.tpw == 1) L(1); else if (p.tpw == 2) L(2); else L(3);
 #undef L
+  }
   SSMI_LAUNCH_CHECK();
   const int E = p.a.K_aug * g.cout;
   hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 15) / 16), dim3(256), 0, st, part, p.a.nstrips, p.a.K, p.a.K_aug,
@@ -628,7 +901,7 @@ ssmi_status ssmi_conv2d_transpose_bwd_data(const ssmi_conv_desc* d, const float*
 
 static int colsum_blocks(int64_t npix, int c) {
   const int ppi = 256 / c;
-  int64_t b = ceil_div64(npix, (int64_t)ppi * 16);
+  int64_t b = ceil_div64(npix, (int64_t)ppi * 8);
   if (b > 512) b = 512;
   if (b < 1) b = 1;
   return (int)b;
@@ -656,9 +929,12 @@ ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const floa
     float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + a);
     const int64_t npix = (int64_t)g.n * g.h * g.w;
     const int nb = colsum_blocks(npix, g.cin);
-    hipLaunchKernelGGL(colsum_partial, dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
+    if (g.cin % 4 == 0 && g.x_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dyt) & 15) == 0)
+      hipLaunchKernelGGL(colsum_partial<true>, dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
+    else
+      hipLaunchKernelGGL(colsum_partial<false>, dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
     SSMI_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final, dim3((g.cin + 63) / 64), dim3(64), 0, as_stream(stream), part, nb, g.cin, dbias);
+    hipLaunchKernelGGL(colsum_final, dim3((g.cin + 7) / 8), dim3(256), 0, as_stream(stream), part, nb, g.cin, dbias);
     SSMI_LAUNCH_CHECK();
   }
   return SSMI_OK;
