@@ -252,6 +252,221 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
 }
 
 // ---------------------------------------------------------------------------------------------------
+// LDS-weight implicit GEMM, shared by the forward convolution and the data gradient / transposed forward:
+//     out[p, o] = sum over valid taps t, reduction channels r :  in[pix(p, t), r] * Wl[t][r][o]
+//   forward   : in = x,  r = cin,  o = cout, Wl[t][r][o] = w[t][r][o]
+//   data grad : in = dy, r = cout, o = cin,  Wl[t][r][o] = w[t][o][r]   (one launch per stride phase: blockIdx.z)
+// The whole kernel matrix is staged once per workgroup in LDS (row stride WS words), so the B operand of every MFMA
+// is a conflict-free ds_read_b32 instead of a vector-memory load.  A wave owns MT pixel tiles x NT column tiles; the
+// A operand is one 16-byte buffer load per lane per k-block (4 consecutive reduction channels of the lane's pixel;
+// lane group kq takes channels 4*kq.. of the block, the same permutation is applied to the B rows), double buffered so
+// the loads of block b+1 are in flight while block b is multiplied.  k runs over (valid tap, channel) flattened, so
+// cin = 4 layers put four taps into one MFMA.  M16 selects v_mfma_f32_16x16x4_f32 (16-pixel x 16-channel tiles) for
+// outputs of <= 16 channels.  VEC=false (reduction channels not a multiple of 4) feeds one channel per lane.
+// ---------------------------------------------------------------------------------------------------
+struct GemmArgs {
+  int mode;                      // 0 forward, 1 data gradient
+  int C_r, C_o;
+  int in_h, in_w, in_ld;         // tensor the A operand is gathered from
+  int out_ld;
+  int WS;                        // LDS row stride in words
+  int q_blk, r_blk, q0_div;      // k-block advance: taps / channels per block (KB / C_r, KB % C_r)
+  int ngroups_max;
+};
+static constexpr int kMaxTaps = 32;
+
+template <bool M16, int MT, int NT, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const float* __restrict__ in,
+                                                     const float* __restrict__ w, const float* __restrict__ bias,
+                                                     const float* __restrict__ add, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TS = M16 ? 16 : 32;
+  constexpr int KQ = 64 / TS;
+  constexpr int NR = M16 ? 4 : 16;
+  constexpr int EW = VEC ? 4 : 1;
+  constexpr int KB = KQ * EW;             // reduction elements per k-block
+  typedef float accv __attribute__((ext_vector_type(NR)));
+  int* tab = reinterpret_cast<int*>(smem);          // [0]=nvt, then {dy, dx, wl_word_offset} per valid tap
+  float* Wl = smem + 4 + 4 * kMaxTaps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & (TS - 1), kq = lane / TS;
+  const int s = g.stride;
+  const bool bwd = a.mode == 1;
+  const int pa = bwd ? blockIdx.z / s : 0, pb = bwd ? blockIdx.z % s : 0;
+  const int qh = bwd ? (g.h - pa + s - 1) / s : g.ho, qw = bwd ? (g.w - pb + s - 1) / s : g.wo;
+  if (qh <= 0 || qw <= 0) return;
+  const int ntaps = g.kh * g.kw;
+
+  // ---- tap table + kernel matrix into LDS ----
+  if (tid == 0) {
+    int n = 0;
+    for (int t = 0; t < ntaps; ++t) {
+      const int ky = t / g.kw, kx = t % g.kw;
+      int dyo, dxo;
+      if (!bwd) {
+        dyo = ky * g.dil - g.pad_t;
+        dxo = kx * g.dil - g.pad_l;
+      } else {
+        const int ty = pa + g.pad_t - ky * g.dil, tx = pb + g.pad_l - kx * g.dil;
+        if ((((ty % s) + s) % s) != 0 || (((tx % s) + s) % s) != 0) continue;
+        dyo = (ty >= 0 ? ty / s : -((-ty) / s));   // exact: ty is a multiple of s
+        dxo = (tx >= 0 ? tx / s : -((-tx) / s));
+      }
+      tab[1 + 3 * n] = dyo;
+      tab[2 + 3 * n] = dxo;
+      tab[3 + 3 * n] = n * a.C_r * a.WS;     // only the valid taps are staged, packed
+      tab[4 + 3 * kMaxTaps + n] = t;         // source tap of staged slot n
+      ++n;
+    }
+    tab[0] = n;
+  }
+  __syncthreads();
+  {
+    const int nv = tab[0];
+    const int copad = NT * TS * ((a.C_o + NT * TS - 1) / (NT * TS));
+    const int rows = nv * a.C_r;
+    if (copad > a.C_o) {   // zero the pad columns
+      const int padw = copad - a.C_o;
+      for (int e = tid; e < rows * padw; e += 256) Wl[(e / padw) * a.WS + a.C_o + e % padw] = 0.f;
+    }
+    const int per_tap = g.cin * g.cout;
+    if (!bwd && a.WS == g.cout && (g.cout & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
+      // forward, unpadded rows: the LDS image is the kernel itself (all taps are valid and in order)
+      const f32x4* src = reinterpret_cast<const f32x4*>(w);
+      f32x4* dst = reinterpret_cast<f32x4*>(Wl);
+      for (int e = tid; e < (nv * per_tap) >> 2; e += 256) dst[e] = src[e];
+    } else {
+      for (int vi = 0; vi < nv; ++vi) {
+        const float* src = w + (int64_t)tab[4 + 3 * kMaxTaps + vi] * per_tap;
+        float* dst = Wl + vi * a.C_r * a.WS;
+        for (int e = tid; e < per_tap; e += 256) {
+          const int co = e % g.cout, ci = e / g.cout;
+          if (!bwd) dst[ci * a.WS + co] = src[e];
+          else dst[co * a.WS + ci] = src[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nvt = tab[0];
+  const int K = nvt * a.C_r;
+  const int nblk = (K + KB - 1) / KB;
+  const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, bwd ? sz.y_bytes : sz.x_bytes);
+  const int sm_ = bwd ? 1 : s;       // input coordinate = q * sm_ + tap offset
+  const int64_t M = (int64_t)g.n * qh * qw;
+  const int64_t ngroups = (M + MT * TS - 1) / (MT * TS);
+  const int cbase0 = blockIdx.y * NT * TS;
+  const int kq_tap0 = (kq * EW) / a.C_r, kq_r0 = (kq * EW) % a.C_r;
+
+  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+    const int64_t tile0 = grp * (MT * TS);
+    bool pv[MT];
+    int by[MT], bx[MT], img[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int64_t p = tile0 + m * TS + c;
+      pv[m] = p < M;
+      const int64_t pp = pv[m] ? p : 0;
+      const int qx = (int)(pp % qw);
+      const int64_t t1 = pp / qw;
+      by[m] = (int)(t1 % qh) * sm_;
+      bx[m] = qx * sm_;
+      img[m] = (int)(t1 / qh) * a.in_h * a.in_w;
+    }
+    accv acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < NR; ++i) acc[m][t][i] = 0.f;
+
+    int tapi = kq_tap0, r0 = kq_r0;
+    f32x4 A0[MT], A1[MT];
+    int wb0, wb1;
+    // the tap-table entry of the NEXT fetch is read at the end of the current one, off the critical path
+    int nty, ntx, nwb;
+    auto lookup = [&]() {
+      const int ts_ = tapi < nvt ? tapi : 0;
+      nty = tab[1 + 3 * ts_];
+      ntx = tab[2 + 3 * ts_];
+      nwb = tab[3 + 3 * ts_];
+    };
+    lookup();
+    auto fetch = [&](f32x4 (&A)[MT], int& wbase) {
+      const bool tv = tapi < nvt;
+      const int ty = nty, tx = ntx;
+      wbase = nwb + r0 * a.WS + cbase0 + c;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int iy = by[m] + ty, ix = bx[m] + tx;
+        const bool ok = tv && pv[m] && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
+        const unsigned off = ok ? ((unsigned)(img[m] + iy * a.in_w + ix) * (unsigned)a.in_ld + (unsigned)r0) * 4u : kOOB;
+        if (VEC) A[m] = bload4(rin, off);
+        else A[m][0] = bload(rin, off);
+      }
+      tapi += a.q_blk;
+      r0 += a.r_blk;
+      if (r0 >= a.C_r) { r0 -= a.C_r; ++tapi; }
+      lookup();
+    };
+    auto mma = [&](f32x4 (&A)[MT], int wbase) {
+#pragma unroll
+      for (int j = 0; j < EW; ++j) {
+        float b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = Wl[wbase + j * a.WS + t * TS];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if constexpr (M16) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][j], b[t], acc[m][t], 0, 0, 0);
+            else acc[m][t] = MFMA32(A[m][j], b[t], acc[m][t]);
+          }
+      }
+    };
+    fetch(A0, wb0);
+    for (int blk = 0; blk < nblk; blk += 2) {
+      fetch(A1, wb1);          // past the end: every lane reads zeros (tapi >= nvt)
+      mma(A0, wb0);
+      fetch(A0, wb0);
+      mma(A1, wb1);
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int col = cbase0 + t * TS + c;
+      if (col >= a.C_o) continue;
+      const float bvv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
+          const int64_t po = tile0 + m * TS + row;
+          if (po < M) {
+            int64_t off;
+            if (!bwd || s == 1) {
+              off = po * a.out_ld + col;
+            } else {
+              const int ox_ = (int)(po % qw);
+              const int64_t t2 = po / qw;
+              const int oy_ = (int)(t2 % qh);
+              const int nn = (int)(t2 / qh);
+              off = (((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb)) * a.out_ld + col;
+            }
+            float v = acc[m][t][i] + bvv;
+            if (add) v += add[off];
+            out[off] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight gradient: dw[(tap,ci), co] = sum_p x[pix(p,tap), ci] * dy[p, co]; optional extra row K = sum_p dy[p, co].
 // The [K_aug x cout] result is cut into 32x32 output tiles (kt, ct).  A workgroup owns one strip of output rows and
 // up to 4*TPW tiles: its waves split the tiles (wave w takes tiles w, w+wps, ...), so the 4 waves stream the same
@@ -687,11 +902,69 @@ static ssmi_status make_sizes(const Geo& g, Sizes* sz) {
   return SSMI_OK;
 }
 
+// Picks the LDS-weight kernel when the kernel matrix fits in 64 KiB of LDS; returns false otherwise.
+static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float* in, const float* w, const float* bias,
+                            const float* add, float* out, hipStream_t st, ssmi_status* status) {
+  GemmArgs a;
+  a.mode = mode;
+  a.C_r = mode == 0 ? g.cin : g.cout;
+  a.C_o = mode == 0 ? g.cout : g.cin;
+  a.in_h = mode == 0 ? g.h : g.ho;
+  a.in_w = mode == 0 ? g.w : g.wo;
+  a.in_ld = mode == 0 ? g.x_ld : g.y_ld;
+  a.out_ld = mode == 0 ? g.y_ld : g.x_ld;
+  const int ntaps = g.kh * g.kw;
+  if (ntaps > kMaxTaps) return false;
+  // Measured on MI355X (ENet layer shapes, batch 16): the LDS-weight kernel wins for narrow outputs (16x16 MFMA tiles
+  // waste no columns) and for the data gradient into >= 128 channels (the direct kernel reads the transposed kernel
+  // matrix with a 4*cout-byte lane stride); elsewhere the direct kernel's larger wave count hides latency better.
+  if (mode == 0 ? a.C_o > 16 : (a.C_o > 16 && a.C_o < 128)) return false;
+  const bool m16 = a.C_o <= 16;
+  const int ts = m16 ? 16 : 32;
+  const int nt = m16 ? 1 : (a.C_o <= 32 ? 1 : (a.C_o <= 64 ? 2 : 4));
+  const int ctiles = (a.C_o + nt * ts - 1) / (nt * ts);
+  const int copad = ctiles * nt * ts;
+  a.WS = m16 ? copad + 4 : copad;
+  // a stride phase of the data gradient sees at most ceil(k/s)^2 taps (all of them when dilated)
+  const int staged_taps = (mode == 0 || g.dil > 1) ? ntaps : ((g.kh + g.stride - 1) / g.stride) * ((g.kw + g.stride - 1) / g.stride);
+  const size_t lds = (size_t)(4 + 4 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
+  if (lds > 64 * 1024) return false;
+  const bool vec = (a.C_r % 4 == 0) && (a.in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  const int kb = (64 / ts) * (vec ? 4 : 1);
+  a.q_blk = kb / a.C_r;
+  a.r_blk = kb % a.C_r;
+  const int s = g.stride;
+  const int qh = mode == 0 ? g.ho : (g.h + s - 1) / s, qw = mode == 0 ? g.wo : (g.w + s - 1) / s;
+  const int64_t M = (int64_t)g.n * qh * qw;
+  const int mt = m16 ? 4 : (nt >= 4 ? 1 : 2);
+  const int64_t ngroups = ceil_div64(M, (int64_t)mt * ts);
+  int64_t bx = ceil_div64(ngroups, 4);
+  // enough workgroups to fill the chip, few enough that each stages the kernel matrix for several pixel groups
+  if (bx > 1024) bx = 1024;
+  dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
+#define LG(M16_, MT_, NT_, V_) \
+  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out)
+  if (m16) { if (vec) LG(true, 4, 1, true); else LG(true, 4, 1, false); }
+  else if (nt == 1) { if (vec) LG(false, 2, 1, true); else LG(false, 2, 1, false); }
+  else if (nt == 2) { if (vec) LG(false, 2, 2, true); else LG(false, 2, 2, false); }
+  else { if (vec) LG(false, 1, 4, true); else LG(false, 1, 4, false); }
+#undef LG
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("conv_gemm_lds launch: %s", hipGetErrorString(e));
+    *status = SSMI_E_HIP;
+  } else {
+    *status = SSMI_OK;
+  }
+  return true;
+}
+
 static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, const float* bias, float* y,
                               hipStream_t st) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e)) return e;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
@@ -712,6 +985,7 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  if (launch_gemm_lds(g, sz, 1, dy, w, bias, add, dx, st, &e)) return e;
   const int s = g.stride;
   const int qh = (g.h + s - 1) / s, qw = (g.w + s - 1) / s;
   const int64_t M = (int64_t)g.n * qh * qw;
