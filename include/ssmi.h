@@ -233,8 +233,19 @@ ssmi_status ssmi_dropout_mask(float* mask, int64_t count, float rate, uint64_t s
 
 /* Utility kernels. */
 ssmi_status ssmi_fill_f32(float* dst, float value, int64_t count, void* stream);
-ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, void* stream);
-ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, float* dx, void* stream);
+/* Keras UpSampling2D((2,2)) (src/models.py:920,1287,1713): x[n,h,w,c] -> y[n,2h,2w,c]; y (forward) and dy (backward) may be
+ * channel slices of a wider tensor (pixel stride y_ld / dy_ld), which is how `concatenate([up, skip])` (src/models.py:927)
+ * is assembled without a separate pass over the upsampled half. */
+ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
+                                   void* stream);
+ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c, float* dx,
+                                   void* stream);
+/* dst[p, 0:c] (accumulate ? += : =) src[p, 0:c] for npix pixels with independent pixel strides: the skip half of a
+ * concatenate (src/models.py:927) and the slices of its gradient. */
+ssmi_status ssmi_copy_ld(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                         int32_t accumulate, void* stream);
+/* SpatialDropout2D as its own layer (src/models.py:876): y[n,p,c] = x[n,p,c] * table[n,c]; the same call is its gradient. */
+ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t n, int64_t hw, int32_t c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * HIP graph capture of a whole training step (replaces the one tf.Session.run per step of

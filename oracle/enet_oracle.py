@@ -10,6 +10,7 @@ in Keras layouts (Conv2D kernel HWIO, Conv2DTranspose kernel (kh,kw,out,in), PRe
 Topologies follow:
   enet-naive-upsampling : src/models.py:1054-1319
   enet-max-unpooling    : src/models.py:1360-1628
+  enet-naive-upsampling-enhanced : src/models.py:1642-1796
 Deviation kept on purpose: the naive decoder's second PReLU is named `_prelu_2`
 (the reference names both `_prelu_1`, src/models.py:1231,1254, which Keras rejects).
 """
@@ -80,7 +81,9 @@ def _dec_bottleneck_spec(spec, p, cin, cout, upsample, variant):
     _conv(spec, p + "_proj_conv2d_1", 1, 1, cin, internal, False)
     _bn(spec, p + "_bnorm_1", internal)
     _prelu(spec, p + "_prelu_1", internal)
-    if upsample:
+    if upsample and variant == "enhanced":
+        _conv(spec, p + "_nn_rs_conv_conv2d", 3, 3, internal, internal, True)
+    elif upsample:
         _tconv(spec, p + "_tconv2d_1", 3, 3, internal, internal)
     else:
         _conv(spec, p + "_conv2d_1", 3, 3, internal, internal, True)
@@ -88,7 +91,7 @@ def _dec_bottleneck_spec(spec, p, cin, cout, upsample, variant):
     _prelu(spec, p + "_prelu_2", internal)
     _conv(spec, p + "_proj_conv2d_2", 1, 1, internal, cout, False)
     has_other = (cin != cout) or upsample
-    if variant == "naive":
+    if variant in ("naive", "enhanced"):
         _bn(spec, p + "_bnorm_3", cout)
         if has_other:
             _conv(spec, p + "_other_conv2d", 1, 1, cin, cout, False)
@@ -107,12 +110,14 @@ def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str
         variant = "naive"
     elif model_name == "enet-max-unpooling":
         variant = "unpool"
+    elif model_name == "enet-naive-upsampling-enhanced":
+        variant = "enhanced"
     else:
         raise ValueError("Unknown model name: {}".format(model_name))
     spec: list = []
     spec.append(("initial_block_conv2d/kernel", (3, 3, 3, 13), "glorot_uniform", 0))
     spec.append(("initial_block_conv2d/bias", (13,), "zeros", 0))
-    if variant == "naive":
+    if variant in ("naive", "enhanced"):
         _bn(spec, "initial_block_bnorm", 16)
         _prelu(spec, "initial_block_prelu", 16)
     _enc_bottleneck_spec(spec, "en_bn_1.0", 16, 64, downsample=True)
@@ -127,6 +132,12 @@ def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str
     _dec_bottleneck_spec(spec, "de_bn_4.2", 64, 64, False, variant)
     _dec_bottleneck_spec(spec, "de_bn_5.0", 64, 16, True, variant)
     _dec_bottleneck_spec(spec, "de_bn_5.1", 16, 16, False, variant)
+    if variant == "enhanced":
+        _conv(spec, "final_nn_rs_conv_conv2d", 3, 3, 16, num_classes, True)
+        _bn(spec, "final_nn_rs_conv_bnorm", num_classes)
+        _prelu(spec, "final_nn_rs_conv_prelu", num_classes)
+        _conv(spec, "logits", 1, 1, num_classes, num_classes, True)
+        return spec
     spec.append(("logits/kernel", (2, 2, num_classes, 16), "he_normal", 2 * 2 * 16))
     spec.append(("logits/bias", (num_classes,), "zeros", 0))
     return spec
@@ -173,7 +184,7 @@ def dropout_layer_rates(model_name: str) -> "OrderedDict[str, Tuple[float, int]]
     for stage in (2, 3):
         for suffix, _ in ENC_PATTERN:
             out["en_bn_{}.{}_sdrop2d_1".format(stage, suffix)] = (0.1, 128)
-    if model_name == "enet-naive-upsampling":
+    if model_name in ("enet-naive-upsampling", "enet-naive-upsampling-enhanced"):
         for nm, c in (("de_bn_4.0", 64), ("de_bn_4.1", 64), ("de_bn_4.2", 64), ("de_bn_5.0", 16), ("de_bn_5.1", 16)):
             out[nm + "_sdrop2d_1"] = (0.1, c)
     return out
@@ -259,17 +270,20 @@ def _dec_bottleneck(c: _Ctx, x, cout, p, upsample, variant, idx=None):
     cin = x.shape[3]
     d = c.conv(p + "_proj_conv2d_1", x, padding="valid")
     d = c.prelu(p + "_prelu_1", c.bn(p + "_bnorm_1", d))
-    d = c.tconv(p + "_tconv2d_1", d) if upsample else c.conv(p + "_conv2d_1", d)
+    if upsample and variant == "enhanced":
+        d = c.conv(p + "_nn_rs_conv_conv2d", K.upsample_nn2(d))
+    else:
+        d = c.tconv(p + "_tconv2d_1", d) if upsample else c.conv(p + "_conv2d_1", d)
     d = c.prelu(p + "_prelu_2", c.bn(p + "_bnorm_2", d))
     d = c.conv(p + "_proj_conv2d_2", d)
-    if variant == "naive":
+    if variant in ("naive", "enhanced"):
         d = c.sdrop(p + "_sdrop2d_1", c.bn(p + "_bnorm_3", d))
     other = x
     if cin != cout or upsample:
         other = c.bn(p + "_other_bnorm_1", c.conv(p + "_other_conv2d", other))
         if upsample:
-            other = K.upsample_nn2(other) if variant == "naive" else K.max_unpool(other, idx)
-    if variant != "naive":
+            other = K.upsample_nn2(other) if variant in ("naive", "enhanced") else K.max_unpool(other, idx)
+    if variant == "unpool":
         d = c.bn(p + "_bnorm_3", d)
     return c.prelu(p + "_prelu_3", d + other)
 
@@ -278,13 +292,14 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
                  drop_masks=None, collect: bool = False):
     """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
     ctx.acts the named intermediate tensors when collect=True."""
-    variant = "naive" if model_name == "enet-naive-upsampling" else "unpool"
-    if model_name not in ("enet-naive-upsampling", "enet-max-unpooling"):
+    variant = {"enet-naive-upsampling": "naive", "enet-max-unpooling": "unpool",
+               "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)
+    if variant is None:
         raise ValueError("Unknown model name: {}".format(model_name))
     c = _Ctx(params, training, drop_masks, collect)
     idx_stack = []
     conv = c.conv("initial_block_conv2d", images, stride=2)
-    if variant == "naive":
+    if variant in ("naive", "enhanced"):
         x = torch.cat([conv, K.max_pool_2x2(images)], dim=3)
         x = c.prelu("initial_block_prelu", c.bn("initial_block_bnorm", x))
     else:
@@ -313,7 +328,12 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
     x = _dec_bottleneck(c, x, 64, "de_bn_4.2", False, variant)
     x = _dec_bottleneck(c, x, 16, "de_bn_5.0", True, variant, idx_stack.pop() if want else None)
     x = _dec_bottleneck(c, x, 16, "de_bn_5.1", False, variant)
-    logits = c.tconv("logits", x)
+    if variant == "enhanced":
+        x = c.conv("final_nn_rs_conv_conv2d", K.upsample_nn2(x))
+        x = c.prelu("final_nn_rs_conv_prelu", c.bn("final_nn_rs_conv_bnorm", x))
+        logits = c.conv("logits", x)
+    else:
+        logits = c.tconv("logits", x)
     return logits, c
 
 

@@ -71,8 +71,10 @@ _PROTOS = {
     "ssmi_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _i32, _f32, _vp, _vp]),
     "ssmi_dropout_mask": (_i32, [_vp, _i64, _f32, _u64, _vp, _u32, _vp]),
     "ssmi_fill_f32": (_i32, [_vp, _f32, _i64, _vp]),
-    "ssmi_upsample_nn2x_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "ssmi_upsample_nn2x_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_upsample_nn2x_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "ssmi_upsample_nn2x_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "ssmi_copy_ld": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
+    "ssmi_scale_nc": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "ssmi_graph_begin_capture": (_i32, [_vp]),
     "ssmi_graph_end_capture": (_i32, [_vp, C.POINTER(_vp)]),
     "ssmi_graph_launch": (_i32, [_vp, _vp]),

@@ -132,22 +132,24 @@ __global__ __launch_bounds__(256) void idx_f32_to_i32_kernel(const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = (int32_t)s[i];
 }
 
+// nearest 2x upsampling; y (forward) / dy (backward) may be a channel slice of a wider tensor (pixel stride ld)
 __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int n, int h, int w, int c,
-                                                           float* __restrict__ y, int64_t total) {
+                                                           float* __restrict__ y, int y_ld, int64_t total) {
   const int H = 2 * h, W = 2 * w;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
     int64_t q = i / c;
+    const int64_t pix = q;
     const int ox = (int)(q % W);
     q /= W;
     const int oy = (int)(q % H);
     const int n_ = (int)(q / H);
-    y[i] = x[(((int64_t)n_ * h + (oy >> 1)) * w + (ox >> 1)) * c + ch];
+    y[pix * y_ld + ch] = x[(((int64_t)n_ * h + (oy >> 1)) * w + (ox >> 1)) * c + ch];
   }
 }
 
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int n, int h, int w, int c,
-                                                           float* __restrict__ dx, int64_t total) {
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int dy_ld, int n, int h, int w,
+                                                           int c, float* __restrict__ dx, int64_t total) {
   const int W = 2 * w;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
@@ -156,8 +158,30 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     q /= w;
     const int y_ = (int)(q % h);
     const int n_ = (int)(q / h);
-    const float* b = dy + ((((int64_t)n_ * 2 * h + 2 * y_) * W) + 2 * x_) * c + ch;
-    dx[i] = b[0] + b[c] + b[(int64_t)W * c] + b[(int64_t)W * c + c];
+    const float* b = dy + ((((int64_t)n_ * 2 * h + 2 * y_) * W) + 2 * x_) * dy_ld + ch;
+    dx[i] = b[0] + b[dy_ld] + b[(int64_t)W * dy_ld] + b[(int64_t)W * dy_ld + dy_ld];
+  }
+}
+
+// dst[p, 0:c] (=|+=) src[p, 0:c] with independent pixel strides: concat slices and their gradients
+__global__ __launch_bounds__(256) void copy_ld_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst,
+                                                      int dst_ld, int c, int accumulate, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const int64_t p = i / c;
+    const float v = src[p * src_ld + ch];
+    float* d = dst + p * dst_ld + ch;
+    *d = accumulate ? *d + v : v;
+  }
+}
+
+// y[n, p, c] = x[n, p, c] * table[n, c]   (SpatialDropout2D keep/scale table; its own gradient too)
+__global__ __launch_bounds__(256) void scale_nc_kernel(const float* __restrict__ x, const float* __restrict__ table,
+                                                       float* __restrict__ y, int64_t hw, int c, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const int64_t n_ = i / ((int64_t)c * hw);
+    y[i] = x[i] * table[n_ * c + ch];
   }
 }
 
@@ -249,18 +273,38 @@ ssmi_status ssmi_idx_f32_to_i32(const float* src, int32_t* dst, int64_t count, v
   return SSMI_OK;
 }
 
-ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, void* stream) {
-  SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "upsample_nn2x_fwd: bad argument");
+ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
+                                   void* stream) {
+  SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && y_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_fwd: bad argument");
   const int64_t total = (int64_t)n * h * w * c * 4;
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, total);
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, y_ld, total);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
 
-ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t n, int32_t h, int32_t w, int32_t c, float* dx, void* stream) {
-  SSMI_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0, SSMI_E_INVALID_ARG, "upsample_nn2x_bwd: bad argument");
+ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c, float* dx,
+                                   void* stream) {
+  SSMI_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && dy_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_bwd: bad argument");
   const int64_t total = (int64_t)n * h * w * c;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, n, h, w, c, dx, total);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, n, h, w, c, dx, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_copy_ld(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                         int32_t accumulate, void* stream) {
+  SSMI_REQUIRE(src && dst && npix > 0 && c > 0 && src_ld >= c && dst_ld >= c, SSMI_E_INVALID_ARG, "copy_ld: bad argument");
+  const int64_t total = npix * c;
+  hipLaunchKernelGGL(copy_ld_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld, c,
+                     accumulate, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t n, int64_t hw, int32_t c, void* stream) {
+  SSMI_REQUIRE(x && table && y && n > 0 && hw > 0 && c > 0, SSMI_E_INVALID_ARG, "scale_nc: bad argument");
+  const int64_t total = (int64_t)n * hw * c;
+  hipLaunchKernelGGL(scale_nc_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, table, y, hw, c, total);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }

@@ -245,12 +245,37 @@ class BatchNorm:
 
 
 class RunCfg:
-    """Per-call switches threaded through the blocks."""
-    __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws")
+    """Per-call switches threaded through the blocks.
 
-    def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws):
+    Weight gradients never feed the rest of the backward pass, so they run on a second HIP stream (`side`) with their
+    own workspace: `wgrad()` forks after the kernel that produced dy, `join()` makes the main stream wait for the side
+    stream.  Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the
+    latency-bound main chain (small BN / merge kernels) is running."""
+    __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws", "main", "side", "ws2",
+                 "_forked")
+
+    def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws, main=None, side=None, ws2=None):
         self.training, self.update_moving, self.unbiased_moving = training, update_moving, unbiased_moving
         self.use_dropout, self.st, self.ws = use_dropout, st, ws
+        self.main, self.side, self.ws2 = main, side, ws2
+        self._forked = False
+
+    def wgrad(self, conv, x, dy):
+        if self.side is None:
+            conv.bwd_weight(x, dy, self.ws, self.st)
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self.side.wait_event(ev)
+        conv.bwd_weight(x, dy, self.ws2, self.side.cuda_stream)
+        self._forked = True
+
+    def join(self):
+        if self.side is not None and self._forked:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.main.wait_event(ev)
+            self._forked = False
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -278,7 +303,7 @@ class InitialBlock(Block):
         self.conv = Conv(store, "initial_block_conv2d", 3, 3, 3, 13, stride=2, padding="same", bias=True,
                          init="glorot_uniform")
         self.bn = None
-        if variant == "naive":
+        if variant in ("naive", "enhanced"):
             self.bn = BatchNorm(store, "initial_block_bnorm", 16)
             self.bn.add_prelu(store, "initial_block_prelu")
 
@@ -317,7 +342,7 @@ class InitialBlock(Block):
             d = self.dcat
         else:
             d = dout
-        self.conv.bwd_weight(self.x, d, cfg.ws, cfg.st)
+        cfg.wgrad(self.conv, self.x, d)
         return None  # the images need no gradient
 
 
@@ -342,7 +367,11 @@ class Bottleneck(Block):
         self.bn1 = BatchNorm(store, prefix + "_bnorm_1", internal)
         self.bn1.add_prelu(store, prefix + "_prelu_1")
         self.conv2a = None
-        if upsample:
+        self.nn_resize = upsample and variant == "enhanced"
+        if self.nn_resize:
+            # NN-resize convolution of the enhanced decoder (src/models.py:1711-1719): nearest 2x upsampling + 3x3 conv
+            self.conv2 = Conv(store, prefix + "_nn_rs_conv_conv2d", 3, 3, internal, internal, bias=True)
+        elif upsample:
             self.conv2 = Conv(store, prefix + "_tconv2d_1", 3, 3, internal, internal, stride=2, bias=True, transpose=True)
         elif asymmetric:
             self.conv2a = Conv(store, prefix + "_aconv2d_1", 1, asymmetric, internal, internal, bias=False)
@@ -378,7 +407,7 @@ class Bottleneck(Block):
         if downsample:
             self.mode = 1
         elif upsample:
-            self.mode = 2 if variant == "naive" else 3
+            self.mode = 3 if variant == "unpool" else 2
         else:
             self.mode = 0
 
@@ -400,7 +429,12 @@ class Bottleneck(Block):
             self.conv2a.plan(n, h1, w1)
             self.t = torch.empty(n, h1, w1, self.internal, **f32)
             self.dt = torch.empty_like(self.t)
-        h2, w2 = self.conv2.plan(n, h1, w1)
+        if self.nn_resize:
+            self.a1u = torch.empty(n, 2 * h1, 2 * w1, self.internal, **f32)
+            self.da1u = torch.empty_like(self.a1u)
+            h2, w2 = self.conv2.plan(n, 2 * h1, 2 * w1)
+        else:
+            h2, w2 = self.conv2.plan(n, h1, w1)
         self.conv3.plan(n, h2, w2)
         self.hin, self.win, self.h1, self.w1, self.ho, self.wo = h, w, h1, w1, h2, w2
         self.np_in, self.np1, self.np_out = n * h * w, n * h1 * w1, n * h2 * w2
@@ -461,6 +495,9 @@ class Bottleneck(Block):
         if self.conv2a is not None:
             self.conv2a.fwd(self.a1, self.t, st)
             self.conv2.fwd(self.t, self.y2, st)
+        elif self.nn_resize:
+            L.upsample_nn2x_fwd(_ptr(self.a1), self.n, self.h1, self.w1, i, _ptr(self.a1u), i, st)
+            self.conv2.fwd(self.a1u, self.y2, st)
         else:
             self.conv2.fwd(self.a1, self.y2, st)
         self.bn2.stats(self.y2, self.np_out, i, tr, um, ub, ws, st)
@@ -490,21 +527,25 @@ class Bottleneck(Block):
                     _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
                     _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
         # conv3
-        self.conv3.bwd_weight(self.a2, self.dy3, ws, st)
+        cfg.wgrad(self.conv3, self.a2, self.dy3)
         self.conv3.bwd_data(self.dy3, self.da2, st)
         self.bn2.act_bwd(self.da2, self.y2, i, self.da2, self.np_out, ws, st)      # da2 -> dy2 (in place)
         # conv2
         if self.conv2a is not None:
-            self.conv2.bwd_weight(self.t, self.da2, ws, st)
+            cfg.wgrad(self.conv2, self.t, self.da2)
             self.conv2.bwd_data(self.da2, self.dt, st)
-            self.conv2a.bwd_weight(self.a1, self.dt, ws, st)
+            cfg.wgrad(self.conv2a, self.a1, self.dt)
             self.conv2a.bwd_data(self.dt, self.da1, st)
+        elif self.nn_resize:
+            cfg.wgrad(self.conv2, self.a1u, self.da2)
+            self.conv2.bwd_data(self.da2, self.da1u, st)
+            L.upsample_nn2x_bwd(_ptr(self.da1u), i, self.n, self.h1, self.w1, i, _ptr(self.da1), st)
         else:
-            self.conv2.bwd_weight(self.a1, self.da2, ws, st)
+            cfg.wgrad(self.conv2, self.a1, self.da2)
             self.conv2.bwd_data(self.da2, self.da1, st)
         self.bn1.act_bwd(self.da1, self.y1, i, self.da1, self.np1, ws, st)         # da1 -> dy1 (in place)
         # conv1 + skip branch
-        self.conv1.bwd_weight(self.x, self.da1, ws, st)
+        cfg.wgrad(self.conv1, self.x, self.da1)
         if self.mode == 0:
             self.conv1.bwd_data(self.da1, self.dx, st, add=self.dsum)
         elif self.mode == 1:
@@ -514,8 +555,64 @@ class Bottleneck(Block):
         else:
             self.conv1.bwd_data(self.da1, self.dx_main, st)
             self.bn_o.act_bwd(self.dyo_bn, self.yo, self.cout, self.dyo_bn, self.np_in, ws, st)   # -> d(yo) in place
-            self.conv_o.bwd_weight(self.x, self.dyo_bn, ws, st)
+            cfg.wgrad(self.conv_o, self.x, self.dyo_bn)
             self.conv_o.bwd_data(self.dyo_bn, self.dx, st, add=self.dx_main)
+        return self.dx
+
+
+class EnhancedHead(Block):
+    """Head of the enhanced decoder (src/models.py:1779-1794): nearest 2x upsampling -> 3x3 conv (16 -> classes) ->
+    BN -> PReLU -> 1x1 conv named 'logits'."""
+
+    def __init__(self, store, cin, num_classes):
+        self.name = "logits"
+        self.cin, self.num_classes = cin, num_classes
+        self.conv_a = Conv(store, "final_nn_rs_conv_conv2d", 3, 3, cin, num_classes, bias=True)
+        self.bn = BatchNorm(store, "final_nn_rs_conv_bnorm", num_classes)
+        self.bn.add_prelu(store, "final_nn_rs_conv_prelu")
+        self.conv = Conv(store, "logits", 1, 1, num_classes, num_classes, padding="valid", bias=True)
+
+    def convs(self):
+        return [self.conv_a, self.conv]
+
+    def plan(self, n, h, w, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.n, self.h, self.w = n, h, w
+        H, W, C_ = 2 * h, 2 * w, self.num_classes
+        self.conv_a.plan(n, H, W)
+        self.conv.plan(n, H, W)
+        self.bn.plan(dev)
+        self.npix = n * H * W
+        self.xu = torch.empty(n, H, W, self.cin, **f32)
+        self.ya = torch.empty(n, H, W, C_, **f32)
+        self.aa = torch.empty_like(self.ya)
+        self.out = torch.empty_like(self.ya)
+        self.dout = torch.empty_like(self.ya)
+        self.daa = torch.empty_like(self.ya)
+        self.dya = torch.empty_like(self.ya)
+        self.dxu = torch.empty_like(self.xu)
+        self.dx = torch.empty(n, h, w, self.cin, **f32)
+        return (H, W, C_)
+
+    def fwd(self, x, cfg):
+        L = lib()
+        C_ = self.num_classes
+        L.upsample_nn2x_fwd(_ptr(x), self.n, self.h, self.w, self.cin, _ptr(self.xu), self.cin, cfg.st)
+        self.conv_a.fwd(self.xu, self.ya, cfg.st)
+        self.bn.stats(self.ya, self.npix, C_, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws, cfg.st)
+        self.bn.act_fwd(self.ya, C_, self.aa, self.npix, cfg.st)
+        self.conv.fwd(self.aa, self.out, cfg.st)
+        return self.out
+
+    def bwd(self, dout, cfg):
+        L = lib()
+        C_ = self.num_classes
+        cfg.wgrad(self.conv, self.aa, dout)
+        self.conv.bwd_data(dout, self.daa, cfg.st)
+        self.bn.act_bwd(self.daa, self.ya, C_, self.dya, self.npix, cfg.ws, cfg.st)
+        cfg.wgrad(self.conv_a, self.xu, self.dya)
+        self.conv_a.bwd_data(self.dya, self.dxu, cfg.st)
+        L.upsample_nn2x_bwd(_ptr(self.dxu), self.cin, self.n, self.h, self.w, self.cin, _ptr(self.dx), cfg.st)
         return self.dx
 
 
@@ -543,7 +640,7 @@ class LogitsHead(Block):
         return self.out
 
     def bwd(self, dout, cfg):
-        self.conv.bwd_weight(self.x, dout, cfg.ws, cfg.st)
+        cfg.wgrad(self.conv, self.x, dout)
         self.conv.bwd_data(dout, self.dx, cfg.st)
         return self.dx
 
@@ -557,10 +654,11 @@ ENC_PATTERN = [("1", {}), ("2", {"dilated": 2}), ("3", {"asymmetric": 5}), ("4",
 
 
 class ENetGraph:
-    """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling`."""
+    """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling` /
+    `enet-naive-upsampling-enhanced`."""
 
     def __init__(self, variant: str, num_classes: int, device="cuda"):
-        assert variant in ("naive", "unpool")
+        assert variant in ("naive", "unpool", "enhanced")
         self.variant, self.num_classes = variant, num_classes
         self.device = torch.device(device)
         st = self.store = ParamStore()
@@ -573,17 +671,21 @@ class ENetGraph:
         for stage in (2, 3):
             for suffix, kw in ENC_PATTERN:
                 blocks.append(B(st, "en_bn_{}.{}".format(stage, suffix), 128, 128, "enc", variant, dropout_rate=0.1, **kw))
-        ddrop = 0.1 if variant == "naive" else None   # the max-unpooling decoder has no dropout (src/models.py:1576-1607)
+        ddrop = None if variant == "unpool" else 0.1   # the max-unpooling decoder has no dropout (src/models.py:1576-1607)
         blocks.append(B(st, "de_bn_4.0", 128, 64, "dec", variant, upsample=True, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_4.1", 64, 64, "dec", variant, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_4.2", 64, 64, "dec", variant, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_5.0", 64, 16, "dec", variant, upsample=True, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_5.1", 16, 16, "dec", variant, dropout_rate=ddrop))
-        blocks.append(LogitsHead(st, 16, num_classes))
+        blocks.append(EnhancedHead(st, 16, num_classes) if variant == "enhanced" else LogitsHead(st, 16, num_classes))
         self.blocks = blocks
         self.by_name = {b.name: b for b in blocks}
         st.materialise(self.device)
         self.shape = None
+        self.side_stream = None
+        # Forking the weight gradients onto a second stream was measured at 14.5 ms/step against 14.0 ms/step without
+        # (ENet 512x512, batch 16, graph replay): the HIP graph does not gain from the parallel branch, so it is off.
+        self.overlap_weight_gradients = False
         self.drop_layers = [b.dropout() for b in blocks if b.dropout() is not None]
 
     # -- planning -------------------------------------------------------------------------------------
@@ -625,14 +727,17 @@ class ENetGraph:
             d = b.dropout()
             if d is not None:
                 b.drop_mask = self.drop_views[d[0]]
-        # shared workspace
-        need = L.bn_workspace_bytes(0, 1024)
+        # workspaces: `ws` for the main stream (BN / merge / loss partial sums), `ws2` for the weight-gradient stream
+        need2 = 16
         for b in self.blocks:
             for cv in b.convs():
-                need = max(need, cv.ws_bytes)
+                need2 = max(need2, cv.ws_bytes)
         npix = n * h * w
-        need = max(need, L.softmax_xent_workspace_bytes(npix))
+        need = max(L.bn_workspace_bytes(0, 1024), L.softmax_xent_workspace_bytes(npix))
         self.ws = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
+        self.ws2 = torch.empty((need2 + 3) // 4 + 64, dtype=torch.float32, device=dev)
+        if self.side_stream is None and dev.type == "cuda":
+            self.side_stream = torch.cuda.Stream(device=dev)
         self.shape = (n, h, w)
 
     # -- execution ------------------------------------------------------------------------------------
@@ -641,9 +746,11 @@ class ENetGraph:
         n, h, w, c = images.shape
         assert c == 3 and images.dtype == torch.float32 and images.is_contiguous()
         self.plan(n, h, w)
-        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        main = torch.cuda.current_stream()
+        st = stream if stream is not None else main.cuda_stream
+        side = self.side_stream if (self.overlap_weight_gradients and training and st == main.cuda_stream and st != 0) else None
         cfg = RunCfg(training, update_moving and training, unbiased_moving,
-                     training if use_dropout is None else use_dropout, st, self.ws)
+                     training if use_dropout is None else use_dropout, st, self.ws, main, side, self.ws2)
         x = images
         for b in self.blocks:
             x = b.fwd(x, cfg)
@@ -655,6 +762,7 @@ class ENetGraph:
         d = dlogits
         for b in reversed(self.blocks):
             d = b.bwd(d, cfg)
+        cfg.join()
 
     def refresh_dropout(self, seed: int, step_block: torch.Tensor, stream: Optional[int] = None):
         st = stream if stream is not None else torch.cuda.current_stream().cuda_stream

@@ -258,12 +258,14 @@ class ExtendedModel(object):
             d = g.dlogits
             for b in reversed(blocks[split:]):
                 d = b.bwd(d, g._cfg)
+            g._cfg.join()
             self._d_mid = d
 
         def seg_b(st):
             d = self._d_mid
             for b in reversed(blocks[:split]):
                 d = b.bwd(d, g._cfg)
+            g._cfg.join()
 
         def seg_c(st):
             scale = 1.0 / self.grad_sync.world_size if self.grad_sync is not None else 1.0

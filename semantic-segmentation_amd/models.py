@@ -79,12 +79,26 @@ class ENetMaxUnpooling(ModelBase):
         return ENetGraph("unpool", self.num_classes, self.device)
 
 
+class ENetNaiveUpsamplingEnhanced(ModelBase):
+    """src/models.py:1642-1796."""
+
+    def __init__(self, input_shape, num_classes, encoder_only=False, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
+        if encoder_only:
+            raise NotImplementedError('encoder-only classification heads are outside the segmentation hot path')
+        super().__init__("ENet-Naive-Upsampling-Enhanced", input_shape, num_classes, model_lambda_loss_type, **kw)
+
+    def _build_model(self):
+        return ENetGraph("enhanced", self.num_classes, self.device)
+
+
 def get_model(model_name, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
     """src/models.py:54-128."""
     if model_name == 'enet-naive-upsampling':
         return ENetNaiveUpsampling(input_shape, num_classes, False, model_lambda_loss_type, **kw)
     if model_name == 'enet-max-unpooling':
         return ENetMaxUnpooling(input_shape, num_classes, False, model_lambda_loss_type, **kw)
+    if model_name == 'enet-naive-upsampling-enhanced':
+        return ENetNaiveUpsamplingEnhanced(input_shape, num_classes, False, model_lambda_loss_type, **kw)
     if model_name in _KNOWN:
         raise NotImplementedError('model {} is not built yet on this backend'.format(model_name))
     raise ValueError('Unknown model name: {}'.format(model_name))

@@ -425,3 +425,59 @@ def test_error_reporting_through_the_abi():
     d = lib_mod.ConvDesc(1, 4, 4, 3, 4, 4, 3, 3, 3, 1, 1, 1, 1, 2, 3)     # x_ld < cin
     with pytest.raises(lib_mod.SsmiError, match="leading dimension"):
         L.conv2d_fwd(C.byref(d), 1, 1, None, 1, None)
+
+
+@pytest.mark.parametrize("n,h,w,c,ld", [(2, 5, 7, 16, 16), (1, 4, 4, 8, 24), (2, 3, 5, 3, 7), (1, 8, 8, 64, 96)])
+def test_upsample_nn2x_into_channel_slice(n, h, w, c, ld):
+    """UpSampling2D(2) forward writes a channel slice of a wider buffer (the concat of the U-Net decoder is never
+    materialised); backward sums each 2x2 window.  Exact: copies and 4-term sums in a fixed order."""
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(n * 100 + c)
+    x = rng.standard_normal((n, h, w, c)).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    off = ld - c
+    y = torch.full((n, 2 * h, 2 * w, ld), -7.0, device=DEV)
+    xd = _t(x)
+    L.upsample_nn2x_fwd(xd.data_ptr(), n, h, w, c, y.data_ptr() + 4 * off, ld, st)
+    ref = K.upsample_nn2(torch.from_numpy(x)).numpy()
+    got = y.cpu().numpy()
+    assert np.array_equal(got[..., off:], ref)
+    assert (got[..., :off] == -7.0).all()                       # the neighbouring slice is untouched
+    dy = rng.standard_normal((n, 2 * h, 2 * w, ld)).astype(np.float32)
+    dx = torch.empty(n, h, w, c, device=DEV)
+    dyd = _t(dy)
+    L.upsample_nn2x_bwd(dyd.data_ptr() + 4 * off, ld, n, h, w, c, dx.data_ptr(), st)
+    d = dy[..., off:].astype(np.float64)
+    ref_dx = d[:, 0::2, 0::2] + d[:, 0::2, 1::2] + d[:, 1::2, 0::2] + d[:, 1::2, 1::2]
+    _check(dx, ref_dx, "upsample bwd", rtol=1e-6, atol_rel=1e-6)
+
+
+@pytest.mark.parametrize("npix,c,sld,dld", [(37, 16, 16, 48), (64, 8, 20, 8), (5, 3, 3, 5)])
+def test_copy_ld_and_accumulate(npix, c, sld, dld):
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(npix)
+    src = rng.standard_normal((npix, sld)).astype(np.float32)
+    dst0 = rng.standard_normal((npix, dld)).astype(np.float32)
+    st = torch.cuda.current_stream().cuda_stream
+    so, do = sld - c, dld - c
+    dst, srcd = _t(dst0), _t(src)
+    L.copy_ld(srcd.data_ptr() + 4 * so, sld, dst.data_ptr() + 4 * do, dld, npix, c, 0, st)
+    ref = dst0.copy()
+    ref[:, do:] = src[:, so:]
+    assert np.array_equal(dst.cpu().numpy(), ref)
+    L.copy_ld(srcd.data_ptr() + 4 * so, sld, dst.data_ptr() + 4 * do, dld, npix, c, 1, st)
+    ref[:, do:] += src[:, so:]
+    assert np.array_equal(dst.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("n,hw,c", [(2, 35, 16), (3, 16, 6), (1, 7, 3)])
+def test_scale_nc_spatial_dropout_table(n, hw, c):
+    """SpatialDropout2D: y[b, p, ch] = x[b, p, ch] * table[b, ch]."""
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(c)
+    x = rng.standard_normal((n, hw, c)).astype(np.float32)
+    tab = (rng.uniform(size=(n, c)) > 0.3).astype(np.float32) / 0.7
+    y = torch.empty(n, hw, c, device=DEV)
+    xd, td = _t(x), _t(tab)
+    L.scale_nc(xd.data_ptr(), td.data_ptr(), y.data_ptr(), n, hw, c, torch.cuda.current_stream().cuda_stream)
+    assert np.array_equal(y.cpu().numpy(), x * tab[:, None, :])

@@ -144,6 +144,14 @@ def test_enet_max_unpooling_train_step_parity_smooth():
     _run_case("enet-max-unpooling", 2, 64, 96, seed=5, steps=2, smooth=True)
 
 
+def test_enet_enhanced_train_step_parity_smooth():
+    _run_case("enet-naive-upsampling-enhanced", 2, 64, 64, seed=7, steps=2, smooth=True)
+
+
+def test_enet_enhanced_train_step_parity():
+    _run_case("enet-naive-upsampling-enhanced", 2, 48, 80, seed=9, steps=1)
+
+
 def test_enet_naive_train_step_parity():
     _run_case("enet-naive-upsampling", 2, 64, 64, seed=3, steps=2)
 
