@@ -118,6 +118,22 @@ ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const
                             float* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
                             size_t ws_bytes, void* stream);
 
+/* The convolution block of the U-Net / SegNet builders (src/models.py:828-878): BatchNormalization ->
+ * [LeakyReLU] -> SpatialDropout2D as ONE pass.  Same as ssmi_bn_act_fwd / _bwd with two additions:
+ *   drop  [n, c] table of 0 or 1/(1-rate) per (image, channel), nullable; hw = pixels per image (npix % hw == 0);
+ *   ld_y / ld_dy  pixel stride of the output / incoming gradient, so the result can land in a channel slice of a
+ *   concatenation buffer (src/models.py:927).
+ *   y = drop * act(bn(x));  backward: dz = dy * drop * act'(.), then the BN backward of ssmi_bn_act_bwd. */
+ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 const float* drop, int64_t hw, float* y, int32_t ld_y, int64_t npix, int32_t c,
+                                 void* stream);
+ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                 const float* alpha, float slope, const float* drop, int64_t hw, float* dx,
+                                 float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                 size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * Bottleneck merge (src/models.py:1150-1172, 1265-1296, 1594-1607): one fused pass for
  *   out = PReLU_alpha( dropscale[n,c] * BN3(main) + other' )

@@ -23,6 +23,9 @@ import numpy as np
 import torch
 
 from . import tf_keras_ops as K
+from . import unet_segnet_oracle as V
+
+VGG_STYLE = ("unet", "segnet")   # restated in unet_segnet_oracle.py; weights / step assembly are shared with the ENets
 
 ENC_PATTERN = [("1", {}), ("2", {"dilated": 2}), ("3", {"asymmetric": 5}), ("4", {"dilated": 4}),
                ("5", {}), ("6", {"dilated": 8}), ("7", {"asymmetric": 5}), ("8", {"dilated": 16})]
@@ -106,6 +109,8 @@ def _dec_bottleneck_spec(spec, p, cin, cout, upsample, variant):
 
 def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str, int]]:
     """[(key, shape, initializer, fan_in)] in layer-creation order."""
+    if model_name in VGG_STYLE:
+        return V.weight_spec(model_name, num_classes)
     if model_name == "enet-naive-upsampling":
         variant = "naive"
     elif model_name == "enet-max-unpooling":
@@ -176,6 +181,8 @@ def init_weights(model_name: str, num_classes: int, seed: int = 14874, perturb: 
 
 def dropout_layer_rates(model_name: str) -> "OrderedDict[str, Tuple[float, int]]":
     """{sdrop layer name: (rate, channels)} in creation order."""
+    if model_name in VGG_STYLE:
+        return V.dropout_layer_rates(model_name)
     out: "OrderedDict[str, Tuple[float, int]]" = OrderedDict()
     out["en_bn_1.0_sdrop2d_1"] = (0.01, 64)
     for i in range(4):
@@ -292,6 +299,9 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
                  drop_masks=None, collect: bool = False):
     """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
     ctx.acts the named intermediate tensors when collect=True."""
+    if model_name in VGG_STYLE:
+        c = _Ctx(params, training, drop_masks, collect)
+        return V.forward(model_name, c, images), c
     variant = {"enet-naive-upsampling": "naive", "enet-max-unpooling": "unpool",
                "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)
     if variant is None:

@@ -54,6 +54,9 @@ _PROTOS = {
     "ssmi_bn_act_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _i32, _vp]),
     "ssmi_bn_act_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
                                _sz, _vp]),
+    "ssmi_bn_act_drop_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _vp, _i32, _i64, _i32, _vp]),
+    "ssmi_bn_act_drop_bwd": (_i32, [_vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _vp, _vp, _vp, _vp,
+                                    _i64, _i32, _vp, _sz, _vp]),
     "ssmi_merge_fwd": (_i32, [_PM, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp]),
     "ssmi_merge_workspace_bytes": (_sz, [_PM]),
     "ssmi_merge_bwd": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -137,7 +137,8 @@ template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ alpha,
-                                                         float slope, float* __restrict__ y, int64_t total4, int c4n) {
+                                                         float slope, const float* __restrict__ drop, int64_t hw,
+                                                         float* __restrict__ y, int y_ld, int64_t total4, int c4n) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
     const int64_t p = i / c4n;
     const int c = (int)(i % c4n) * 4;
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
-    st4(y + i * 4, o);
+    if (drop) o = o * ld4(drop + (p / hw) * (c4n * 4) + c);
+    st4(y + p * y_ld + c, o);
   }
 }
 
@@ -157,8 +159,9 @@ template <int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, int ld,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         const float* __restrict__ alpha, float slope, int64_t npix,
-                                                         int c4n, float* __restrict__ part) {
+                                                         const float* __restrict__ alpha, float slope,
+                                                         const float* __restrict__ drop, int64_t hw, int dy_ld,
+                                                         int64_t npix, int c4n, float* __restrict__ part) {
   __shared__ f32x4 sm[3 * 256];
   const int ppi = 256 / c4n;
   const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
@@ -171,7 +174,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict
     if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
     for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
       const f32x4 xv = ld4(x + p * ld + c);
-      const f32x4 d = ld4(dy + (p * c4n + c4) * 4);
+      f32x4 d = ld4(dy + p * dy_ld + c);
+      if (drop) d = d * ld4(drop + (p / hw) * (c4n * 4) + c);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float xh = (xv[j] - m[j]) * is[j];
@@ -213,6 +217,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ alpha, float slope,
+                                                        const float* __restrict__ drop, int64_t hw, int dy_ld,
                                                         const float* __restrict__ coef, float* __restrict__ dx,
                                                         int64_t total4, int c4n) {
   const int cc = c4n * 4;
@@ -220,7 +225,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
     const int64_t p = i / c4n;
     const int c = (int)(i % c4n) * 4;
     const f32x4 xv = ld4(x + p * ld + c);
-    const f32x4 d = ld4(dy + i * 4);
+    f32x4 d = ld4(dy + p * dy_ld + c);
+    if (drop) d = d * ld4(drop + (p / hw) * cc + c);
     const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
     const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
     f32x4 a = {slope, slope, slope, slope};
@@ -453,14 +459,23 @@ ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_va
 ssmi_status ssmi_bn_act_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, int32_t act, const float* alpha, float slope, float* y, int64_t npix,
                             int32_t c, void* stream) {
+  return ssmi_bn_act_drop_fwd(x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, y, c, npix, c, stream);
+}
+
+ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 const float* drop, int64_t hw, float* y, int32_t ld_y, int64_t npix, int32_t c,
+                                 void* stream) {
   ssmi_status s = check_c(c, "bn_act_fwd");
   if (s) return s;
-  SSMI_REQUIRE(x && mean && invstd && gamma && beta && y && npix > 0 && ld_x >= c && ld_x % 4 == 0, SSMI_E_INVALID_ARG, "bn_act_fwd: bad argument");
+  SSMI_REQUIRE(x && mean && invstd && gamma && beta && y && npix > 0 && ld_x >= c && ld_x % 4 == 0 && ld_y >= c && ld_y % 4 == 0,
+               SSMI_E_INVALID_ARG, "bn_act_fwd: bad argument");
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_fwd: PReLU needs alpha");
+  SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_fwd: npix must be a multiple of hw");
   const int c4n = c / 4;
   const int64_t total4 = npix * c4n;
   const int nb = ew_blocks(total4);
-#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, y, total4, c4n)
+#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, total4, c4n)
   if (act == SSMI_ACT_NONE) L(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L(SSMI_ACT_LEAKY);
   else { set_error("bn_act_fwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L
@@ -472,9 +487,20 @@ ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const
                             const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
                             float* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
                             size_t ws_bytes, void* stream) {
+  return ssmi_bn_act_drop_bwd(dy, c, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, dx, dgamma, dbeta,
+                              dalpha, npix, c, ws, ws_bytes, stream);
+}
+
+ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                 const float* alpha, float slope, const float* drop, int64_t hw, float* dx,
+                                 float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                 size_t ws_bytes, void* stream) {
   ssmi_status s = check_c(c, "bn_act_bwd");
   if (s) return s;
-  SSMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && npix > 0 && ld_x >= c && ld_x % 4 == 0, SSMI_E_INVALID_ARG, "bn_act_bwd: bad argument");
+  SSMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && npix > 0 && ld_x >= c && ld_x % 4 == 0 && ld_dy >= c && ld_dy % 4 == 0,
+               SSMI_E_INVALID_ARG, "bn_act_bwd: bad argument");
+  SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_bwd: npix must be a multiple of hw");
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_bwd: PReLU needs alpha");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_act_bwd: workspace too small");
   const int c4n = c / 4;
@@ -482,7 +508,7 @@ ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const
   float* part = reinterpret_cast<float*>(ws);
   float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
   hipStream_t st = as_stream(stream);
-#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<A>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, npix, c4n, part)
+#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<A>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, npix, c4n, part)
   if (act == SSMI_ACT_NONE) L1(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L1(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L1(SSMI_ACT_LEAKY);
   else { set_error("bn_act_bwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L1
@@ -492,7 +518,7 @@ ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const
   SSMI_LAUNCH_CHECK();
   const int64_t total4 = npix * c4n;
   const int nb2 = ew_blocks(total4);
-#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, coef, dx, total4, c4n)
+#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, total4, c4n)
   if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
 #undef L2
   SSMI_LAUNCH_CHECK();

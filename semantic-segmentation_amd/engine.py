@@ -291,6 +291,15 @@ class Block:
     def dropout(self) -> Optional[Tuple[str, float, int]]:
         return None
 
+    def dropouts(self) -> List[Tuple[str, float, int]]:
+        d = self.dropout()
+        return [] if d is None else [d]
+
+    def bind_dropout(self, views: Dict[str, torch.Tensor]):
+        d = self.dropout()
+        if d is not None:
+            self.drop_mask = views[d[0]]
+
 
 class InitialBlock(Block):
     """conv3x3/s2 (3->13) || maxpool2x2 (3) -> concat(16) [-> BN -> PReLU in the naive variant]
@@ -649,94 +658,74 @@ class LogitsHead(Block):
 # the network
 # ----------------------------------------------------------------------------------------------------------
 
+def plan_dropout_arena(layers: List[Tuple[str, float, int]], n: int, dev):
+    """SpatialDropout2D tables [n, channels] of every layer in ONE arena, grouped by rate so that one launch per
+    distinct rate refreshes all of them.  Returns (arena, [(rate, offset, count)], {layer name: [n, ch] view})."""
+    order = sorted(range(len(layers)), key=lambda i: layers[i][1])
+    total = sum(n * layers[i][2] for i in order)
+    arena = torch.ones(max(total, 4), dtype=torch.float32, device=dev)
+    groups: List[Tuple[float, int, int]] = []
+    views: Dict[str, torch.Tensor] = {}
+    off = 0
+    for i in order:
+        name, rate, ch = layers[i]
+        cnt = n * ch
+        views[name] = arena[off:off + cnt].view(n, ch)
+        if groups and groups[-1][0] == rate:
+            r, o, k = groups[-1]
+            groups[-1] = (r, o, k + cnt)
+        else:
+            groups.append((rate, off, cnt))
+        off += cnt
+    return arena, groups, views
+
+
 ENC_PATTERN = [("1", {}), ("2", {"dilated": 2}), ("3", {"asymmetric": 5}), ("4", {"dilated": 4}),
                ("5", {}), ("6", {"dilated": 8}), ("7", {"asymmetric": 5}), ("8", {"dilated": 16})]
 
 
-class ENetGraph:
-    """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling` /
-    `enet-naive-upsampling-enhanced`."""
+class GraphBase:
+    """A list of blocks executed in order (forward) and in reverse (backward), the parameter arenas, the dropout-table
+    arena and the reduction workspaces.  Subclasses build `self.blocks` and implement `_plan_blocks`."""
 
-    def __init__(self, variant: str, num_classes: int, device="cuda"):
-        assert variant in ("naive", "unpool", "enhanced")
-        self.variant, self.num_classes = variant, num_classes
-        self.device = torch.device(device)
-        st = self.store = ParamStore()
-        B = Bottleneck
-        blocks: List[Block] = [InitialBlock(st, variant)]
-        blocks.append(B(st, "en_bn_1.0", 16, 64, "enc", variant, downsample=True, dropout_rate=0.01))
-        for i in range(4):
-            blocks.append(B(st, "en_bn_1.{}".format(i + 1), 64, 64, "enc", variant, dropout_rate=0.01))
-        blocks.append(B(st, "en_bn_2.0", 64, 128, "enc", variant, downsample=True, dropout_rate=0.1))
-        for stage in (2, 3):
-            for suffix, kw in ENC_PATTERN:
-                blocks.append(B(st, "en_bn_{}.{}".format(stage, suffix), 128, 128, "enc", variant, dropout_rate=0.1, **kw))
-        ddrop = None if variant == "unpool" else 0.1   # the max-unpooling decoder has no dropout (src/models.py:1576-1607)
-        blocks.append(B(st, "de_bn_4.0", 128, 64, "dec", variant, upsample=True, dropout_rate=ddrop))
-        blocks.append(B(st, "de_bn_4.1", 64, 64, "dec", variant, dropout_rate=ddrop))
-        blocks.append(B(st, "de_bn_4.2", 64, 64, "dec", variant, dropout_rate=ddrop))
-        blocks.append(B(st, "de_bn_5.0", 64, 16, "dec", variant, upsample=True, dropout_rate=ddrop))
-        blocks.append(B(st, "de_bn_5.1", 16, 16, "dec", variant, dropout_rate=ddrop))
-        blocks.append(EnhancedHead(st, 16, num_classes) if variant == "enhanced" else LogitsHead(st, 16, num_classes))
+    multiple = 16   # input height/width granularity
+
+    def _finish_init(self, blocks):
         self.blocks = blocks
         self.by_name = {b.name: b for b in blocks}
-        st.materialise(self.device)
+        self.store.materialise(self.device)
         self.shape = None
         self.side_stream = None
         # Forking the weight gradients onto a second stream was measured at 14.5 ms/step against 14.0 ms/step without
         # (ENet 512x512, batch 16, graph replay): the HIP graph does not gain from the parallel branch, so it is off.
         self.overlap_weight_gradients = False
-        self.drop_layers = [b.dropout() for b in blocks if b.dropout() is not None]
+        self.drop_layers = [d for b in blocks for d in b.dropouts()]
 
     # -- planning -------------------------------------------------------------------------------------
     def plan(self, n, h, w):
         if self.shape == (n, h, w):
             return
-        if h % 16 or w % 16:
-            raise ValueError("input height/width must be multiples of 16 (got {}x{})".format(h, w))
+        m = self.multiple
+        if h % m or w % m:
+            raise ValueError("input height/width must be multiples of {} (got {}x{})".format(m, h, w))
         dev = self.device
         L = lib()
-        hh, ww, c = self.blocks[0].plan(n, h, w, dev)
-        for b in self.blocks[1:]:
-            if isinstance(b, Bottleneck):
-                uidx = None
-                if b.mode == 3:
-                    src = self.by_name["en_bn_2.0" if b.name == "de_bn_4.0" else "en_bn_1.0"]
-                    uidx = src.idx   # LIFO index stack of src/models.py:1614,1617
-                hh, ww, c = b.plan(n, hh, ww, dev, unpool_idx=uidx)
-            else:
-                hh, ww, c = b.plan(n, hh, ww, dev)
-        # dropout tables: one arena, grouped by rate so that two launches refresh every table
-        order = sorted(range(len(self.drop_layers)), key=lambda i: self.drop_layers[i][1])
-        total = sum(n * self.drop_layers[i][2] for i in order)
-        self.drop_arena = torch.ones(max(total, 4), dtype=torch.float32, device=dev)
-        self.drop_groups: List[Tuple[float, int, int]] = []   # (rate, offset, count)
-        off = 0
-        self.drop_views: Dict[str, torch.Tensor] = {}
-        for i in order:
-            name, rate, ch = self.drop_layers[i]
-            cnt = n * ch
-            self.drop_views[name] = self.drop_arena[off:off + cnt].view(n, ch)
-            if self.drop_groups and self.drop_groups[-1][0] == rate:
-                r, o, k = self.drop_groups[-1]
-                self.drop_groups[-1] = (r, o, k + cnt)
-            else:
-                self.drop_groups.append((rate, off, cnt))
-            off += cnt
+        self._plan_blocks(n, h, w, dev)
+        self.drop_arena, self.drop_groups, self.drop_views = plan_dropout_arena(self.drop_layers, n, dev)
         for b in self.blocks:
-            d = b.dropout()
-            if d is not None:
-                b.drop_mask = self.drop_views[d[0]]
-        # workspaces: `ws` for the main stream (BN / merge / loss partial sums), `ws2` for the weight-gradient stream
+            b.bind_dropout(self.drop_views)
+        # workspaces: `ws` for the main stream (BN / merge / loss partial sums, weight-gradient partials), `ws2` for
+        # the weight-gradient stream
         need2 = 16
         for b in self.blocks:
             for cv in b.convs():
                 need2 = max(need2, cv.ws_bytes)
         npix = n * h * w
-        need = max(L.bn_workspace_bytes(0, 1024), L.softmax_xent_workspace_bytes(npix))
+        need = max(L.bn_workspace_bytes(0, 1024), L.softmax_xent_workspace_bytes(npix), need2)
         self.ws = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
-        self.ws2 = torch.empty((need2 + 3) // 4 + 64, dtype=torch.float32, device=dev)
-        if self.side_stream is None and dev.type == "cuda":
+        self.ws2 = torch.empty((need2 + 3) // 4 + 64, dtype=torch.float32, device=dev) if self.overlap_weight_gradients \
+            else self.ws
+        if self.side_stream is None and dev.type == "cuda" and self.overlap_weight_gradients:
             self.side_stream = torch.cuda.Stream(device=dev)
         self.shape = (n, h, w)
 
@@ -777,3 +766,43 @@ class ENetGraph:
     @property
     def dlogits(self):
         return self.blocks[-1].dout
+
+
+class ENetGraph(GraphBase):
+    """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling` /
+    `enet-naive-upsampling-enhanced`."""
+
+    def __init__(self, variant: str, num_classes: int, device="cuda"):
+        assert variant in ("naive", "unpool", "enhanced")
+        self.variant, self.num_classes = variant, num_classes
+        self.device = torch.device(device)
+        st = self.store = ParamStore()
+        B = Bottleneck
+        blocks: List[Block] = [InitialBlock(st, variant)]
+        blocks.append(B(st, "en_bn_1.0", 16, 64, "enc", variant, downsample=True, dropout_rate=0.01))
+        for i in range(4):
+            blocks.append(B(st, "en_bn_1.{}".format(i + 1), 64, 64, "enc", variant, dropout_rate=0.01))
+        blocks.append(B(st, "en_bn_2.0", 64, 128, "enc", variant, downsample=True, dropout_rate=0.1))
+        for stage in (2, 3):
+            for suffix, kw in ENC_PATTERN:
+                blocks.append(B(st, "en_bn_{}.{}".format(stage, suffix), 128, 128, "enc", variant, dropout_rate=0.1, **kw))
+        ddrop = None if variant == "unpool" else 0.1   # the max-unpooling decoder has no dropout (src/models.py:1576-1607)
+        blocks.append(B(st, "de_bn_4.0", 128, 64, "dec", variant, upsample=True, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_4.1", 64, 64, "dec", variant, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_4.2", 64, 64, "dec", variant, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_5.0", 64, 16, "dec", variant, upsample=True, dropout_rate=ddrop))
+        blocks.append(B(st, "de_bn_5.1", 16, 16, "dec", variant, dropout_rate=ddrop))
+        blocks.append(EnhancedHead(st, 16, num_classes) if variant == "enhanced" else LogitsHead(st, 16, num_classes))
+        self._finish_init(blocks)
+
+    def _plan_blocks(self, n, h, w, dev):
+        hh, ww, c = self.blocks[0].plan(n, h, w, dev)
+        for b in self.blocks[1:]:
+            if isinstance(b, Bottleneck):
+                uidx = None
+                if b.mode == 3:
+                    src = self.by_name["en_bn_2.0" if b.name == "de_bn_4.0" else "en_bn_1.0"]
+                    uidx = src.idx   # LIFO index stack of src/models.py:1614,1617
+                hh, ww, c = b.plan(n, hh, ww, dev, unpool_idx=uidx)
+            else:
+                hh, ww, c = b.plan(n, hh, ww, dev)

@@ -1,7 +1,8 @@
 """Model builders with the API of the reference's src/models.py: `get_model(model_name, input_shape, num_classes,
 model_lambda_loss_type) -> ModelBase`, `ModelBase.model -> ExtendedModel`.
 
-The builders produce the engine's fused block graph (engine.ENetGraph) instead of a Keras functional graph; layer and
+The builders produce the engine's fused block graphs (engine.ENetGraph, engine_unet.UNetSegNetGraph) instead of a
+Keras functional graph; layer and
 weight names, weight shapes and weight order are the reference's (see each builder's citation).  One deliberate
 deviation: the naive decoder's second PReLU is named `{prefix}_prelu_2`; the reference names both decoder PReLUs
 `{prefix}_prelu_1` (src/models.py:1231,1254), which Keras rejects as a duplicate layer name.
@@ -9,6 +10,7 @@ deviation: the naive decoder's second PReLU is named `{prefix}_prelu_2`; the ref
 from __future__ import annotations
 
 from .engine import ENetGraph
+from .engine_unet import UNetSegNetGraph
 from .keras_extensions.extended_model import ExtendedModel
 from .losses import ModelLambdaLossType
 from . import losses
@@ -91,6 +93,28 @@ class ENetNaiveUpsamplingEnhanced(ModelBase):
         return ENetGraph("enhanced", self.num_classes, self.device)
 
 
+class UNetModel(ModelBase):
+    """src/models.py:771-943."""
+
+    def __init__(self, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
+        super().__init__("UNet", input_shape, num_classes, model_lambda_loss_type, **kw)
+
+    def _build_model(self):
+        return UNetSegNetGraph("unet", self.num_classes, self.device)
+
+
+class SegNetBasicModel(ModelBase):
+    """src/models.py:951-1012."""
+
+    def __init__(self, input_shape, num_classes, encoder_only=False, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
+        if encoder_only:
+            raise NotImplementedError('encoder-only classification heads are outside the segmentation hot path')
+        super().__init__("SegNet-Basic", input_shape, num_classes, model_lambda_loss_type, **kw)
+
+    def _build_model(self):
+        return UNetSegNetGraph("segnet", self.num_classes, self.device)
+
+
 def get_model(model_name, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
     """src/models.py:54-128."""
     if model_name == 'enet-naive-upsampling':
@@ -99,6 +123,10 @@ def get_model(model_name, input_shape, num_classes, model_lambda_loss_type=Model
         return ENetMaxUnpooling(input_shape, num_classes, False, model_lambda_loss_type, **kw)
     if model_name == 'enet-naive-upsampling-enhanced':
         return ENetNaiveUpsamplingEnhanced(input_shape, num_classes, False, model_lambda_loss_type, **kw)
+    if model_name == 'unet':
+        return UNetModel(input_shape, num_classes, model_lambda_loss_type, **kw)
+    if model_name == 'segnet':
+        return SegNetBasicModel(input_shape, num_classes, False, model_lambda_loss_type, **kw)
     if model_name in _KNOWN:
-        raise NotImplementedError('model {} is not built yet on this backend'.format(model_name))
+        raise NotImplementedError('encoder-only classification heads ({}) are outside the segmentation hot path'.format(model_name))
     raise ValueError('Unknown model name: {}'.format(model_name))

@@ -65,7 +65,8 @@ def test_metrics_from_cm_match_reference_definitions():
         metrics.ignore_mask_bits([64])
 
 
-@pytest.mark.parametrize("name", ["enet-naive-upsampling", "enet-max-unpooling", "enet-naive-upsampling-enhanced"])
+@pytest.mark.parametrize("name", ["enet-naive-upsampling", "enet-max-unpooling", "enet-naive-upsampling-enhanced",
+                                  "unet", "segnet"])
 def test_builder_weight_names_shapes_and_order(name):
     models = pkg("models")
     m = models.get_model(name, (None, None, 3), 24, device="cpu").model
@@ -77,10 +78,11 @@ def test_builder_weight_names_shapes_and_order(name):
         assert st.specs[k].init == init
     n_train = sum(s.size for s in st.specs.values() if s.trainable)
     assert n_train == {"enet-naive-upsampling": 364972, "enet-max-unpooling": 364924,
-                       "enet-naive-upsampling-enhanced": 367564}[name]
+                       "enet-naive-upsampling-enhanced": 367564, "unet": 31390296, "segnet": 20771160}[name]
     # Keras layer view: one entry per layer, names unique
     names = [l.name for l in m.layers]
-    assert len(names) == len(set(names)) and names[0] == "initial_block_conv2d" and names[-1] == "logits"
+    assert len(names) == len(set(names)) and names[-1] == "logits"
+    assert names[0] == ("initial_block_conv2d" if name.startswith("enet") else "encoder_block1_conv1")
     # arena segments are 16-byte aligned and do not overlap
     offs = sorted((s.offset, s.size) for s in st.specs.values() if s.trainable)
     for (o, n), (o2, _) in zip(offs, offs[1:]):

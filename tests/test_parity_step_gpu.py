@@ -34,7 +34,7 @@ def _close(a, b, rtol, atol, what):
         what, int(bad.sum()), a.size, float(err.max()), float(np.abs(b).max()))
 
 
-def _run_case(model_name, B, H, W, seed, steps=2, smooth=False):
+def _run_case(model_name, B, H, W, seed, steps=2, smooth=False, monkeypatch=None):
     models = pkg("models")
     losses = pkg("losses")
     metrics = pkg("metrics")
@@ -45,6 +45,10 @@ def _run_case(model_name, B, H, W, seed, steps=2, smooth=False):
         for k in w0:
             if k.endswith("/alpha"):
                 w0[k] = np.ones_like(w0[k])
+        if model_name in E.VGG_STYLE:
+            # LeakyReLU slope 1 on both sides (the slope is a builder constant, src/models.py:840)
+            monkeypatch.setattr(E.V, "LEAKY_ALPHA", 1.0)
+            monkeypatch.setattr(pkg("engine_unet"), "LEAKY_ALPHA", 1.0)
     mb = models.get_model(model_name, (None, None, 3), nc, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
     model = mb.model
     assert model.weight_names() == list(w0.keys())
@@ -158,3 +162,19 @@ def test_enet_naive_train_step_parity():
 
 def test_enet_max_unpooling_train_step_parity():
     _run_case("enet-max-unpooling", 3, 64, 96, seed=5, steps=1)
+
+
+def test_unet_train_step_parity_smooth(monkeypatch):
+    _run_case("unet", 2, 32, 32, seed=11, steps=1, smooth=True, monkeypatch=monkeypatch)
+
+
+def test_segnet_train_step_parity_smooth(monkeypatch):
+    _run_case("segnet", 2, 32, 48, seed=13, steps=2, smooth=True, monkeypatch=monkeypatch)
+
+
+def test_segnet_train_step_parity():
+    _run_case("segnet", 3, 32, 32, seed=15, steps=1)
+
+
+def test_unet_train_step_parity():
+    _run_case("unet", 2, 48, 32, seed=17, steps=1)
