@@ -1,0 +1,67 @@
+"""The committed golden vectors (tests/golden/*.npz, written by tests/golden/make_golden.py) against the CPU oracle:
+guards the oracle against drift.  The fixtures are oracle outputs, not reference outputs (the reference ships no
+vectors for this path and cannot run offline): parity unpinned."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import enet_oracle as E
+from oracle import tf_keras_ops as K
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_maker():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def t(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def test_ops_fixture_matches_oracle():
+    g = np.load(os.path.join(GOLD, "ops.npz"))
+    close = lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-12)
+    close(K.conv2d(t(g["conv_s2_x"]), t(g["conv_s2_w"]), t(g["conv_s2_b"]), stride=2).numpy(), g["conv_s2_y"])
+    assert g["conv_s2_y"].shape == (2, 4, 5, 6)
+    close(K.conv2d(t(g["conv_d4_x"]), t(g["conv_d4_w"]), None, dil=4).numpy(), g["conv_d4_y"])
+    close(K.conv2d(t(g["conv_1x5_x"]), t(g["conv_1x5_w"]), None).numpy(), g["conv_1x5_y"])
+    close(K.conv2d_transpose(t(g["tconv3_x"]), t(g["tconv3_w"]), t(g["tconv3_b"]), stride=2).numpy(), g["tconv3_y"])
+    close(K.conv2d_transpose(t(g["tconv3_x"]), t(g["tconv2_w"]), t(g["tconv2_b"]), stride=2).numpy(), g["tconv2_y"])
+    y, mean, var = K.batch_norm_train(t(g["bn_x"]), t(g["bn_gamma"]), t(g["bn_beta"]))
+    close(y.numpy(), g["bn_y"])
+    close(var.numpy(), g["bn_x"].reshape(-1, 8).var(axis=0))          # biased variance
+    close(g["bn_moving_var_next"], 0.1 * 1.0 + 0.9 * g["bn_var"])      # momentum 0.1 weighs the OLD value
+    p, idx = K.max_pool_with_argmax_np(g["pool_x"])
+    assert np.array_equal(p, g["pool_y"]) and np.array_equal(idx, g["pool_idx"])
+    assert np.array_equal(K.max_unpool_np(p, idx), g["unpool_y"])
+    cm = K.confusion_matrix_np(g["xent_labels"], g["xent_logits"], 24, [0])
+    assert np.array_equal(cm, g["xent_cm"]) and cm[0].sum() == 0
+    # loss by hand: mean over ALL pixels of w * (logsumexp - logit[label])
+    lg, lab, w = g["xent_logits"], g["xent_labels"], g["xent_weights"]
+    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
+    ce = lse - np.take_along_axis(lg, lab[..., None], -1)[..., 0]
+    assert abs((w * ce).mean() - float(g["xent_loss"])) < 1e-12
+
+
+@pytest.mark.parametrize("model", ["enet-naive-upsampling", "enet-max-unpooling", "enet-naive-upsampling-enhanced", "segnet"])
+def test_step_fixture_matches_oracle(model):
+    mk = load_maker()
+    g = np.load(os.path.join(GOLD, "step_{}.npz".format(model)))
+    w0, images, labels, pw, masks = mk.step_inputs(model)
+    r = E.train_step(model, w0, images, labels, pw, masks, collect=True)
+    assert abs(r["loss"] - float(g["loss"])) < 1e-9
+    np.testing.assert_allclose(r["logits"], g["logits"], rtol=1e-5, atol=1e-5)
+    assert np.array_equal(r["cm"], g["cm"])
+    keys = [str(k) for k in g["grad_keys"]]
+    assert keys == list(r["grads"].keys())
+    np.testing.assert_allclose([r["grads"][k].sum() for k in keys], g["grad_sum"], rtol=1e-6, atol=1e-9)
+    for k in g.files:
+        if k.startswith("grad/"):
+            np.testing.assert_allclose(r["grads"][k[5:]], g[k], rtol=1e-7, atol=1e-10)

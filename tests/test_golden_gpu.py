@@ -1,0 +1,141 @@
+"""HIP path against the committed golden vectors (tests/golden/*.npz; fp64 oracle outputs, see make_golden.py).
+Tolerances: rtol 1e-3 for floating point (fp32 kernels against fp64 vectors), bit-exact for indices / matrices."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from test_golden_cpu import GOLD, load_maker
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
+
+
+def _close(got, ref, what, rtol=1e-3, atol_rel=1e-4):
+    got = got.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(got) else np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, what
+    err = np.abs(got - ref)
+    bad = err > atol_rel * np.abs(ref).max() + rtol * np.abs(ref)
+    assert not bad.any(), "{}: {} of {} off, max err {:.3e}".format(what, int(bad.sum()), ref.size, float(err.max()))
+
+
+def _conv(g, x, w, b, stride=1, dil=1, transpose=False):
+    eng = pkg("engine")
+    store = eng.ParamStore()
+    kh, kw = w.shape[:2]
+    if transpose:
+        cout, cin = w.shape[2], w.shape[3]
+    else:
+        cin, cout = w.shape[2], w.shape[3]
+    cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=stride, dil=dil, bias=b is not None, transpose=transpose)
+    store.materialise(DEV)
+    n, h, wd, _ = x.shape
+    ho, wo = cv.plan(n, h, wd)
+    store.views["c/kernel"].copy_(_t(w))
+    if b is not None:
+        store.views["c/bias"].copy_(_t(b))
+    y = torch.empty(n, ho, wo, cout, device=DEV)
+    xd = _t(x)
+    cv.fwd(xd, y, torch.cuda.current_stream().cuda_stream)
+    return y
+
+
+def test_operator_vectors():
+    g = np.load(os.path.join(GOLD, "ops.npz"))
+    L = pkg("_lib").lib()
+    st = torch.cuda.current_stream().cuda_stream
+    _close(_conv(g, g["conv_s2_x"], g["conv_s2_w"], g["conv_s2_b"], stride=2), g["conv_s2_y"], "conv s2")
+    _close(_conv(g, g["conv_d4_x"], g["conv_d4_w"], None, dil=4), g["conv_d4_y"], "conv dil 4")
+    _close(_conv(g, g["conv_1x5_x"], g["conv_1x5_w"], None), g["conv_1x5_y"], "conv 1x5")
+    _close(_conv(g, g["tconv3_x"], g["tconv3_w"], g["tconv3_b"], stride=2, transpose=True), g["tconv3_y"], "tconv 3x3")
+    _close(_conv(g, g["tconv3_x"], g["tconv2_w"], g["tconv2_b"], stride=2, transpose=True), g["tconv2_y"], "tconv 2x2")
+    # BN (training statistics) + PReLU
+    x = _t(g["bn_x"])
+    npix, c = 60, 8
+    ws = torch.empty(L.bn_workspace_bytes(npix, c) // 4 + 16, device=DEV)
+    mean, invstd = torch.empty(c, device=DEV), torch.empty(c, device=DEV)
+    mm, mv = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    L.bn_train_stats(x.data_ptr(), npix, c, c, 1e-3, 0.1, 0, mm.data_ptr(), mv.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                     ws.data_ptr(), ws.numel() * 4, st)
+    _close(mean, g["bn_mean"], "bn mean")
+    _close(mv, g["bn_moving_var_next"], "bn moving variance")
+    gam, bet, al = _t(g["bn_gamma"]), _t(g["bn_beta"]), _t(g["prelu_alpha"])
+    y = torch.empty_like(x)
+    L.bn_act_fwd(x.data_ptr(), c, mean.data_ptr(), invstd.data_ptr(), gam.data_ptr(), bet.data_ptr(), 1, al.data_ptr(), 0.0,
+                 y.data_ptr(), npix, c, st)
+    _close(y, g["prelu_y"], "bn + prelu")
+    # pooling: bit-exact values and indices, ties included
+    px = _t(g["pool_x"])
+    n, h, w, c = g["pool_x"].shape
+    py = torch.empty(n, h // 2, w // 2, c, device=DEV)
+    pi = torch.empty(n, h // 2, w // 2, c, dtype=torch.int32, device=DEV)
+    pf = torch.empty(n, h // 2, w // 2, c, device=DEV)
+    L.maxpool_argmax_fwd(px.data_ptr(), n, h, w, c, py.data_ptr(), c, pi.data_ptr(), pf.data_ptr(), st)
+    assert np.array_equal(py.cpu().numpy(), g["pool_y"])
+    assert np.array_equal(pi.cpu().numpy(), g["pool_idx"]) and np.array_equal(pf.cpu().numpy(), g["pool_idx"])
+    up = torch.empty(n, h, w, c, device=DEV)
+    L.maxunpool_fwd(py.data_ptr(), pi.data_ptr(), n, h // 2, w // 2, c, up.data_ptr(), st)
+    assert np.array_equal(up.cpu().numpy(), g["unpool_y"])
+    # loss, gradient, confusion matrix
+    lg, lab, wt = _t(g["xent_logits"]), _t(g["xent_labels"], torch.int32), _t(g["xent_weights"])
+    npix = 128
+    dl = torch.empty_like(lg)
+    loss = torch.zeros(1, device=DEV)
+    cm = torch.zeros(24, 24, dtype=torch.int64, device=DEV)
+    bad = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(L.softmax_xent_workspace_bytes(npix) // 4 + 16, device=DEV)
+    L.softmax_xent_fwd_bwd(lg.data_ptr(), lab.data_ptr(), wt.data_ptr(), npix, 24, 1.0, dl.data_ptr(), loss.data_ptr(),
+                           cm.data_ptr(), npix, 1, None, bad.data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
+    assert abs(loss.item() - float(g["xent_loss"])) < 1e-3 * float(g["xent_loss"])
+    _close(dl, g["xent_dlogits"], "dlogits")
+    assert np.array_equal(cm.cpu().numpy(), g["xent_cm"])
+    out6 = (C.c_double * 6)()
+    cmh = np.ascontiguousarray(g["xent_cm"])
+    L.metrics_from_cm(cmh.ctypes.data, 24, 1, out6)
+    np.testing.assert_allclose(list(out6), g["metrics"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("model", ["enet-naive-upsampling", "enet-max-unpooling", "enet-naive-upsampling-enhanced", "unet", "segnet"])
+def test_training_step_vectors(model):
+    mk = load_maker()
+    g = np.load(os.path.join(GOLD, "step_{}.npz".format(model)))
+    models, losses, opt = pkg("models"), pkg("losses"), pkg("keras_extensions.extended_optimizers")
+    w0, images, labels, pw, masks = mk.step_inputs(model)
+    B, H, W, _ = mk.STEP_CASES[model]
+    m = models.get_model(model, (None, None, 3), 24, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY).model
+    m.set_weights([w0[k] for k in m.weight_names()])
+    m.compile(optimizer=opt.SGD(lr=0.0), loss={'loss': losses.dummy_loss, 'logits': lambda t, p: 0 * p},
+              loss_weights={'loss': 1.0, 'logits': 0.0})
+    m.use_hip_graph = False
+    m._ensure_buffers(B, H, W)
+    gr = m.graph
+    gr.drop_groups = []
+    for name, mask in masks.items():
+        gr.drop_views[name].copy_(torch.from_numpy(mask.astype(np.float32)))
+    with torch.cuda.stream(torch.cuda.Stream()):
+        outs = m.train_on_batch([images, labels, pw, np.zeros((B, 1), dtype=np.int32)],
+                                [np.zeros(B, dtype=np.int32), labels[..., None]])
+    torch.cuda.synchronize()
+    assert abs(outs[0] - float(g["loss"])) < 1e-3 * float(g["loss"])
+    _close(gr.logits, g["logits"], "logits")
+    _close(gr.dlogits, g["dlogits"], "dlogits")
+    # gradients: norms within 2 %, stored tensors within 5 % of their largest element (general PReLU slopes: a pixel
+    # whose pre-activation rounds to the other side of zero in fp32 moves upstream sums by more than rounding error)
+    gv = gr.store.gviews
+    keys = [str(k) for k in g["grad_keys"]]
+    for k, ss, amax in zip(keys, g["grad_sumsq"], g["grad_absmax"]):
+        got = float((gv[k].double() ** 2).sum().item())
+        assert abs(np.sqrt(got) - np.sqrt(ss)) <= 2e-2 * np.sqrt(ss) + 1e-5 * max(amax, 1e-3) * np.sqrt(gv[k].numel()) + 2e-6, k
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = g[k]
+            err = np.abs(gv[k[5:]].cpu().numpy().astype(np.float64) - ref).max()
+            assert err <= 5e-2 * np.abs(ref).max() + 2e-6, "{}: {:.3e}".format(k, err)
