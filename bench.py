@@ -69,11 +69,16 @@ def cpu_baseline(seconds_budget=20.0):
                           len(times), med)}
 
 
+CONV_ENTRY_POINTS = ("conv2d_fwd", "conv2d_bwd_data", "conv2d_transpose_fwd", "conv2d_transpose_bwd_data")
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (MI355X_MICROARCH.md, MFMA table)
+
+
 class KernelTimer:
-    """Brackets every call of selected C-ABI entry points with HIP events on the launch stream (eager pass)."""
+    """Brackets every call of the single-kernel convolution entry points with HIP events recorded on the stream the
+    kernel is launched on (torch's current stream = the launch stream here), and notes which kernel variant ran."""
 
     def __init__(self, L, names):
-        self.L, self.names, self.records = L, names, {n: [] for n in names}
+        self.L, self.names, self.records = L, names, []
         self._orig = {}
 
     def __enter__(self):
@@ -86,7 +91,7 @@ class KernelTimer:
                 e0.record()
                 r = _o(*a)
                 e1.record()
-                self.records[_n].append((e0, e1, a))
+                self.records.append((_n, self.L.last_kernel().decode(), e0, e1, a))
                 return r
             setattr(self.L, n, wrapped)
         return self
@@ -94,6 +99,22 @@ class KernelTimer:
     def __exit__(self, *exc):
         for n, o in self._orig.items():
             setattr(self.L, n, o)
+
+
+def conv_algorithmic_work(entry, args):
+    """(bytes, flops) one launch must move / compute, from its descriptor (fp32).
+    forward:        read x [n,h,w,cin] + kernel, write y [n,ho,wo,cout]
+    data gradient:  read dy [n,ho,wo,cout] + kernel (+ the fused skip-gradient addend), write dx [n,h,w,cin]
+    (a transposed convolution's forward is the data gradient of the convolution its descriptor names, its backward
+    that convolution's forward); flops = 2 * output pixels * taps * cin * cout."""
+    d = args[0]._obj
+    xin = d.n * d.h * d.w * d.cin
+    yout = d.n * d.ho * d.wo * d.cout
+    wts = d.kh * d.kw * d.cin * d.cout
+    elems = xin + yout + wts
+    if entry == "conv2d_bwd_data" and args[3]:
+        elems += xin
+    return 4 * elems, 2 * d.n * d.ho * d.wo * d.kh * d.kw * d.cin * d.cout
 
 
 def main():
@@ -106,6 +127,7 @@ def main():
     ap.add_argument("--model", default="enet-naive-upsampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels directly instead of replaying HIP graphs")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -123,6 +145,8 @@ def main():
     images, labels, weights = synthetic_batch(args.batch, args.size, args.size, 24, 14874 + rank, dev)
     nu = np.zeros((args.batch, 1), dtype=np.int32)
     stream = torch.cuda.Stream(device=dev)
+    if args.eager:
+        model.use_hip_graph = False
     with torch.cuda.stream(stream):
         model.set_batch([images, labels, weights, nu])
         for _ in range(max(args.warmup, 1)):
@@ -168,42 +192,50 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(model, stream):
-    """Eager instrumented steps: HIP events around every launch of the dominant kernel family on the launch stream.
-    Dominant family: the fused bottleneck-merge backward (ssmi_merge_bwd), pure HBM streaming.
-    Algorithmic bytes per launch (fp32, T = n*h*w*c elements of the block output):
-      pass 1 reads dout, main, other and writes dsum; pass 2 reads dsum, main and writes dmain -> 7*T*4 bytes
-      (+ the half-resolution skip tensor for the up-sampling blocks, + its gradient)."""
+def measure_roofline(model, stream, steps=3):
+    """Eager instrumented steps (same buffers and kernels as the graph replay): HIP events around every convolution
+    launch.  The dominant kernel is the convolution kernel variant with the largest summed duration per step; its
+    roofline entry is  sum(algorithmic bytes of its launches) / sum(their durations), i.e. average algorithmic bytes per
+    launch over average launch duration, against the HBM peak when its arithmetic intensity is below the fp32-matrix
+    ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) and against the fp32 MFMA peak otherwise."""
     L = pkg("_lib").lib()
-    names = ["merge_bwd"]
     model.use_hip_graph = False
     with torch.cuda.stream(stream):
         model.train_step_async()
         stream.synchronize()
-        with KernelTimer(L, names) as kt:
-            for _ in range(3):
+        with KernelTimer(L, CONV_ENTRY_POINTS) as kt:
+            for _ in range(steps):
                 model.train_step_async()
             stream.synchronize()
     model.use_hip_graph = True
-    MergeDesc = pkg("_lib").MergeDesc
-    import ctypes as C
-    tot_bytes, tot_ms, n = 0.0, 0.0, 0
-    for e0, e1, a in kt.records["merge_bwd"]:
-        d = a[0]._obj   # the MergeDesc behind ctypes.byref()
-        T = d.n * d.h * d.w * d.c
-        b = 7 * T * 4
-        if d.other_mode == 1:
-            b += -T * 4 + d.n * d.h * d.w * d.c_other * 4
-        elif d.other_mode >= 2:
-            b += -T * 4 + (T // 4) * 4 * 2
-        tot_bytes += b
-        tot_ms += e0.elapsed_time(e1)
-        n += 1
-    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "ssmi_merge_bwd (merge_bwd_reduce + bn_bwd_final + merge_bwd_apply)",
-            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "launches": n, "avg_launch_us": round(tot_ms / n * 1e3, 2),
-            "algorithmic_bytes_per_launch_avg": round(tot_bytes / n)}
+    agg = {}
+    for entry, kernel, e0, e1, a in kt.records:
+        by, fl = conv_algorithmic_work(entry, a)
+        r = agg.setdefault(kernel, [0.0, 0.0, 0.0, 0])
+        r[0] += e0.elapsed_time(e1)
+        r[1] += by
+        r[2] += fl
+        r[3] += 1
+    kernel, (ms, by, fl, n) = max(agg.items(), key=lambda kv: kv[1][0])
+    conv_ms = sum(v[0] for v in agg.values()) / steps
+    ai = fl / by
+    gbs = by / (ms * 1e-3) / 1e9
+    tfs = fl / (ms * 1e-3) / 1e12
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    common = {"kernel": "ssmi::" + kernel, "launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
+              "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
+              "arithmetic_intensity_flop_per_byte": round(ai, 2), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),
+              "kernel_ms_per_step": round(ms / steps, 3), "all_conv_fwd_bwd_data_ms_per_step": round(conv_ms, 3),
+              "traffic": traffic}
+    if ai < F32_MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
+        return dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs / HBM_PEAK_GBS, 4)}, **common)
+    return dict({"bound": "mfma", "achieved": round(tfs, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": round(tfs / F32_MFMA_PEAK_TFLOPS, 4)}, **common)
 
 
 if __name__ == "__main__":

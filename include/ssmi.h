@@ -38,6 +38,9 @@ enum {
 };
 
 const char* ssmi_last_error(void);
+/* Name of the kernel variant the calling thread's last convolution entry point dispatched, as it appears in a
+ * rocprofv3 kernel trace (e.g. "conv_gemm_lds<true, 4, 1, true>"); profiling aid, no reference counterpart. */
+const char* ssmi_last_kernel(void);
 int32_t ssmi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -38,6 +38,7 @@ _PB = C.POINTER(BnParams)
 # name -> (restype, argtypes); status-returning functions are wrapped to raise SsmiError
 _PROTOS = {
     "ssmi_last_error": (C.c_char_p, []),
+    "ssmi_last_kernel": (C.c_char_p, []),
     "ssmi_version": (_i32, []),
     "ssmi_same_pad": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "ssmi_conv2d_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
@@ -85,7 +86,7 @@ _PROTOS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_last_error", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_last_error", "ssmi_last_kernel", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes"}
 

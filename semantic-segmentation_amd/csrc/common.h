@@ -10,6 +10,8 @@
 namespace ssmi {
 
 void set_error(const char* fmt, ...);
+// Records which kernel variant the calling thread's last convolution entry point dispatched (profiling aid).
+void set_last_kernel(const char* fmt, ...);
 
 #define SSMI_REQUIRE(cond, code, ...)      \
   do {                                     \

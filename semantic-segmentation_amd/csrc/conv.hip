@@ -39,6 +39,10 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
 }
 
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);   // dropped when out of range
+}
+
 struct Sizes {
   unsigned x_bytes, y_bytes, w_bytes;   // byte sizes of the x-like, y-like and kernel tensors
 };
@@ -122,17 +126,20 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
     }
   }
 
+  // branch-free epilogue: rows past the end and masked columns get an out-of-range offset, which the store drops
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, sz.y_bytes);
+  unsigned rowoff[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t po = tile0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+    rowoff[i] = po < M ? (unsigned)(po * g.y_ld) * 4u : kOOB;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (!colv[t]) continue;
     const int c = cbase + t * 32 + r;
-    const float bv = bias ? bias[c] : 0.f;
+    const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cout * 4u), colv[t] ? (unsigned)c * 4u : kOOB) : 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const int64_t po = tile0 + row;
-      if (po < M) y[po * g.y_ld + c] = acc[t][i] + bv;
-    }
+    for (int i = 0; i < 16; ++i) bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
   }
 }
 
@@ -228,26 +235,34 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
     }
   }
 
+  // branch-free epilogue: every skip-gradient load is issued before the first store; rows past the end and masked
+  // columns use an out-of-range offset (loads return 0, stores are dropped)
+  const __amdgpu_buffer_rsrc_t rdx = make_rsrc(dx, sz.x_bytes);
+  const __amdgpu_buffer_rsrc_t radd = make_rsrc(add ? add : dx, add ? sz.x_bytes : 0u);
+  unsigned rowoff[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int64_t po = tile0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+    const int64_t pq = po < M ? po : 0;
+    int64_t pix = pq;
+    if (s != 1) {
+      const int ox_ = (int)(pq % qw);
+      const int64_t t2 = pq / qw;
+      const int oy_ = (int)(t2 % qh);
+      const int nn = (int)(t2 / qh);
+      pix = ((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb);
+    }
+    rowoff[i] = po < M ? (unsigned)(pix * g.x_ld) * 4u : kOOB;
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    if (!colv[t]) continue;
     const int c = cbase + t * 32 + r;
-    const float bv = bias ? bias[c] : 0.f;
+    const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cin * 4u), colv[t] ? (unsigned)c * 4u : kOOB) : 0.f;
+    float av[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-      const int64_t po = tile0 + row;
-      if (po < M) {
-        const int ox_ = (int)(po % qw);
-        const int64_t t2 = po / qw;
-        const int oy_ = (int)(t2 % qh);
-        const int nn = (int)(t2 / qh);
-        const int64_t off = (((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb)) * g.x_ld + c;
-        float v = acc[t][i] + bv;
-        if (add) v += add[off];
-        dx[off] = v;
-      }
-    }
+    for (int i = 0; i < 16; ++i) av[i] = bload(radd, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bstore(rdx, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv + av[i]);
   }
 }
 
@@ -352,6 +367,10 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   const int K = nvt * a.C_r;
   const int nblk = (K + KB - 1) / KB;
   const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, bwd ? sz.y_bytes : sz.x_bytes);
+  const unsigned out_bytes = bwd ? sz.x_bytes : sz.y_bytes;
+  const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
+  const __amdgpu_buffer_rsrc_t radd = make_rsrc(add ? add : out, add ? out_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : out, bias ? (unsigned)a.C_o * 4u : 0u);
   const int sm_ = bwd ? 1 : s;       // input coordinate = q * sm_ + tap offset
   const int64_t M = (int64_t)g.n * qh * qw;
   const int64_t ngroups = (M + MT * TS - 1) / (MT * TS);
@@ -433,35 +452,40 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
       mma(A1, wb1);
     }
 
-    // ---- epilogue ----
+    // ---- epilogue (branch-free: out-of-range offsets make masked loads return 0 and masked stores vanish) ----
+    unsigned rowoff[MT][NR];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < NR; ++i) {
+        const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
+        const int64_t po = tile0 + m * TS + row;
+        const int64_t pq = po < M ? po : 0;
+        int64_t pix = pq;
+        if (bwd && s != 1) {
+          const int ox_ = (int)(pq % qw);
+          const int64_t t2 = pq / qw;
+          const int oy_ = (int)(t2 % qh);
+          const int nn = (int)(t2 / qh);
+          pix = ((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb);
+        }
+        rowoff[m][i] = po < M ? (unsigned)(pix * a.out_ld) * 4u : kOOB;
+      }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       const int col = cbase0 + t * TS + c;
-      if (col >= a.C_o) continue;
-      const float bvv = bias ? bias[col] : 0.f;
+      const bool cv = col < a.C_o;
+      const float bvv = bias ? bload(rbias, cv ? (unsigned)col * 4u : kOOB) : 0.f;
+      float av[MT][NR];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < NR; ++i) {
-          const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
-          const int64_t po = tile0 + m * TS + row;
-          if (po < M) {
-            int64_t off;
-            if (!bwd || s == 1) {
-              off = po * a.out_ld + col;
-            } else {
-              const int ox_ = (int)(po % qw);
-              const int64_t t2 = po / qw;
-              const int oy_ = (int)(t2 % qh);
-              const int nn = (int)(t2 / qh);
-              off = (((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb)) * a.out_ld + col;
-            }
-            float v = acc[m][t][i] + bvv;
-            if (add) v += add[off];
-            out[off] = v;
-          }
-        }
-      }
+        for (int i = 0; i < NR; ++i) av[m][i] = bload(radd, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+          bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, acc[m][t][i] + bvv + av[m][i]);
     }
   }
 }
@@ -944,6 +968,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
 #define LG(M16_, MT_, NT_, V_) \
   hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out)
+  set_last_kernel("conv_gemm_lds<%s, %d, %d, %s>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false");
   if (m16) { if (vec) LG(true, 4, 1, true); else LG(true, 4, 1, false); }
   else if (nt == 1) { if (vec) LG(false, 2, 1, true); else LG(false, 2, 1, false); }
   else if (nt == 2) { if (vec) LG(false, 2, 2, true); else LG(false, 2, 2, false); }
@@ -969,6 +994,7 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  set_last_kernel("conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
 #define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
@@ -993,6 +1019,7 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cin + 32 * nt - 1) / (32 * nt)), (unsigned)(s * s));
   const bool vec = (g.cout % 8 == 0) && (g.y_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+  set_last_kernel("conv_bwd_data_kernel<%d, %s>", nt, vec ? "true" : "false");
 #define L(NT, V) hipLaunchKernelGGL((conv_bwd_data_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);

@@ -6,6 +6,14 @@
 namespace ssmi {
 
 static thread_local char g_err[512] = "";
+static thread_local char g_kernel[128] = "";
+
+void set_last_kernel(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+  va_end(ap);
+}
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -108,6 +116,7 @@ struct ssmi_graph {
 extern "C" {
 
 const char* ssmi_last_error(void) { return g_err; }
+const char* ssmi_last_kernel(void) { return g_kernel; }
 int32_t ssmi_version(void) { return 100; }
 
 ssmi_status ssmi_adam_step(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,
