@@ -127,6 +127,9 @@ def main():
     ap.add_argument("--model", default="enet-naive-upsampling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="eval: inference-phase forward + loss + confusion matrix (e.g. --size 1024 --batch 10), the matrices "
+                         "of all ranks summed at the end")
     ap.add_argument("--eager", action="store_true", help="launch kernels directly instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -149,15 +152,19 @@ def main():
         model.use_hip_graph = False
     with torch.cuda.stream(stream):
         model.set_batch([images, labels, weights, nu])
+        step = model.train_step_async if args.mode == "train" else model.eval_step_async
         for _ in range(max(args.warmup, 1)):
-            model.train_step_async()
+            step()
         stream.synchronize()
+        model.reset_metrics()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            model.train_step_async()
+            step()
+        if args.mode == "eval":
+            ev = tr.reduce_evaluation(0.0, args.batch * args.steps)   # sums the int64 matrices over the ranks
         stream.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -170,6 +177,21 @@ def main():
     loss = float(model._loss_buf.item())
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
+
+    if args.mode == "eval":
+        if rank == 0:
+            cm = ev["confusion_matrix"]
+            print(json.dumps({"metric": "eval images/sec @{0}x{0} ENet".format(args.size), "value": round(value, 2),
+                              "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": "{} 24 classes {}x{} per-GPU batch {} inference + loss + confusion matrix, "
+                                                     "matrices summed over ranks".format(args.model, args.size, args.size, args.batch),
+                                         "parallelism": "dp{}".format(world), "pixels_counted": int(cm.sum()),
+                                         "miou": round(ev["miou"], 6), "accuracy": round(ev["accuracy"], 6)}}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     roof = None
     if rank == 0 and not args.no_roofline:

@@ -290,7 +290,7 @@ struct GemmArgs {
 };
 static constexpr int kMaxTaps = 32;
 
-template <bool M16, int MT, int NT, bool VEC>
+template <bool M16, int MT, int NT, bool VEC, int D>
 __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      const float* __restrict__ add, float* __restrict__ out) {
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         for (int i = 0; i < NR; ++i) acc[m][t][i] = 0.f;
 
     int tapi = kq_tap0, r0 = kq_r0;
-    f32x4 A0[MT], A1[MT];
-    int wb0, wb1;
+    f32x4 A[D][MT];
+    int wb[D];
     // the tap-table entry of the NEXT fetch is read at the end of the current one, off the critical path
     int nty, ntx, nwb;
     auto lookup = [&]() {
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
       nwb = tab[3 + 3 * ts_];
     };
     lookup();
-    auto fetch = [&](f32x4 (&A)[MT], int& wbase) {
+    auto fetch = [&](f32x4 (&Ab)[MT], int& wbase) {
       const bool tv = tapi < nvt;
       const int ty = nty, tx = ntx;
       wbase = nwb + r0 * a.WS + cbase0 + c;
@@ -421,15 +421,15 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         const int iy = by[m] + ty, ix = bx[m] + tx;
         const bool ok = tv && pv[m] && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
         const unsigned off = ok ? ((unsigned)(img[m] + iy * a.in_w + ix) * (unsigned)a.in_ld + (unsigned)r0) * 4u : kOOB;
-        if (VEC) A[m] = bload4(rin, off);
-        else A[m][0] = bload(rin, off);
+        if (VEC) Ab[m] = bload4(rin, off);
+        else Ab[m][0] = bload(rin, off);
       }
       tapi += a.q_blk;
       r0 += a.r_blk;
       if (r0 >= a.C_r) { r0 -= a.C_r; ++tapi; }
       lookup();
     };
-    auto mma = [&](f32x4 (&A)[MT], int wbase) {
+    auto mma = [&](f32x4 (&Ab)[MT], int wbase) {
 #pragma unroll
       for (int j = 0; j < EW; ++j) {
         float b[NT];
@@ -439,17 +439,21 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
-            if constexpr (M16) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][j], b[t], acc[m][t], 0, 0, 0);
-            else acc[m][t] = MFMA32(A[m][j], b[t], acc[m][t]);
+            if constexpr (M16) acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ab[m][j], b[t], acc[m][t], 0, 0, 0);
+            else acc[m][t] = MFMA32(Ab[m][j], b[t], acc[m][t]);
           }
       }
     };
-    fetch(A0, wb0);
-    for (int blk = 0; blk < nblk; blk += 2) {
-      fetch(A1, wb1);          // past the end: every lane reads zeros (tapi >= nvt)
-      mma(A0, wb0);
-      fetch(A0, wb0);
-      mma(A1, wb1);
+    // D k-blocks of operand loads are in flight ahead of the multiply: a wave that owns a single pixel group (the usual
+    // case: the launch is one round of waves) pays one memory round trip for up to D blocks instead of one per block
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch(A[d], wb[d]);
+    for (int blk = 0; blk < nblk; blk += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (blk + d < nblk) mma(A[d], wb[d]);
+        fetch(A[d], wb[d]);          // block blk + d + D; past the end every lane reads zeros (tapi >= nvt)
+      }
     }
 
     // ---- epilogue (branch-free: out-of-range offsets make masked loads return 0 and masked stores vanish) ----
@@ -939,10 +943,15 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   a.out_ld = mode == 0 ? g.y_ld : g.x_ld;
   const int ntaps = g.kh * g.kw;
   if (ntaps > kMaxTaps) return false;
-  // Measured on MI355X (ENet layer shapes, batch 16): the LDS-weight kernel wins for narrow outputs (16x16 MFMA tiles
-  // waste no columns) and for the data gradient into >= 128 channels (the direct kernel reads the transposed kernel
-  // matrix with a 4*cout-byte lane stride); elsewhere the direct kernel's larger wave count hides latency better.
-  if (mode == 0 ? a.C_o > 16 : (a.C_o > 16 && a.C_o < 128)) return false;
+  // Measured on MI355X (ENet layer shapes, batch 16): the LDS-weight kernel wins for outputs of <= 16 channels (16x16
+  // MFMA tiles waste no columns) unless the reduction is a single 4-channel tap; elsewhere the direct kernel's larger
+  // wave count hides latency better.
+  static const int force = [] {
+    const char* e = getenv("SSMI_CONV_KERNEL");     // "lds" / "direct": override for A/B measurements
+    return e == nullptr ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : 0));
+  }();
+  if (force == 2) return false;
+  if (force == 0 && (a.C_o > 16 || (mode == 0 && ntaps * a.C_r <= 4))) return false;
   const bool m16 = a.C_o <= 16;
   const int ts = m16 ? 16 : 32;
   const int nt = m16 ? 1 : (a.C_o <= 32 ? 1 : (a.C_o <= 64 ? 2 : 4));
@@ -966,13 +975,24 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   // enough workgroups to fill the chip, few enough that each stages the kernel matrix for several pixel groups
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
-#define LG(M16_, MT_, NT_, V_) \
-  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out)
-  set_last_kernel("conv_gemm_lds<%s, %d, %d, %s>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false");
-  if (m16) { if (vec) LG(true, 4, 1, true); else LG(true, 4, 1, false); }
-  else if (nt == 1) { if (vec) LG(false, 2, 1, true); else LG(false, 2, 1, false); }
-  else if (nt == 2) { if (vec) LG(false, 2, 2, true); else LG(false, 2, 2, false); }
-  else { if (vec) LG(false, 1, 4, true); else LG(false, 1, 4, false); }
+#define LG(M16_, MT_, NT_, V_, D_) \
+  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_, D_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out)
+  // prefetch depth: cover the whole reduction when it is short, else as deep as the register budget allows
+  const int nblk = (staged_taps * a.C_r + kb - 1) / kb;
+  set_last_kernel("conv_gemm_lds<%s, %d, %d, %s, %d>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false",
+                  m16 ? (nblk <= 2 ? 2 : 4) : (nt == 1 ? (nblk <= 4 ? 4 : 8) : (nt == 2 ? 4 : (nblk <= 4 ? 4 : 8))));
+  if (m16) {
+    if (nblk <= 2) { if (vec) LG(true, 4, 1, true, 2); else LG(true, 4, 1, false, 2); }
+    else { if (vec) LG(true, 4, 1, true, 4); else LG(true, 4, 1, false, 4); }
+  } else if (nt == 1) {
+    if (nblk <= 4) { if (vec) LG(false, 2, 1, true, 4); else LG(false, 2, 1, false, 4); }
+    else { if (vec) LG(false, 2, 1, true, 8); else LG(false, 2, 1, false, 8); }
+  } else if (nt == 2) {
+    if (vec) LG(false, 2, 2, true, 4); else LG(false, 2, 2, false, 4);
+  } else {
+    if (nblk <= 4) { if (vec) LG(false, 1, 4, true, 4); else LG(false, 1, 4, false, 4); }
+    else { if (vec) LG(false, 1, 4, true, 8); else LG(false, 1, 4, false, 8); }
+  }
 #undef LG
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

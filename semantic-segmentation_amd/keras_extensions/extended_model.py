@@ -349,6 +349,12 @@ class ExtendedModel(object):
             raise RuntimeError("compile() the model before training")
         self._run(True)
 
+    def eval_step_async(self):
+        """Forward + loss + confusion-matrix update on the staged batch (inference phase); does not synchronise."""
+        if not self._compiled:
+            raise RuntimeError("compile() the model before evaluating")
+        self._run(False)
+
     def train_on_batch(self, x, y=None, sample_weight=None, class_weight=None):
         """Keras Model.train_on_batch: returns [total_loss, loss_loss, logits_loss, *metrics] (metrics_names order)."""
         if not self._compiled:

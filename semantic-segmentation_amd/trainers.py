@@ -59,6 +59,19 @@ class GradientBucketReducer:
         return t
 
 
+def all_reduce_evaluation(cm: torch.Tensor, loss_sum: float, count: int, group=None):
+    """Sums a rank's int64 confusion matrix and its (loss * images, images) pair over the process group (no-op without
+    one).  Returns (matrix as numpy int64, mean loss, images).  Integer sums are exact, so the matrix is the one a
+    single process would have accumulated over all shards."""
+    cm = cm.clone()
+    tot = torch.tensor([loss_sum, float(count)], dtype=torch.float64, device=cm.device)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(cm, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    tot = tot.cpu().numpy()
+    return cm.cpu().numpy(), float(tot[0] / max(tot[1], 1.0)), int(tot[1])
+
+
 def shard_range(global_batch: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Contiguous equal shards of the global batch (global batch 128 -> 8 x 16)."""
     if global_batch % world_size:
@@ -164,6 +177,32 @@ class SegmentationTrainer(object):
         if self.reducer is not None:
             self.reducer.sum_int64_(cm)
         return cm.cpu().numpy()
+
+    def evaluate(self, generator, steps) -> Dict[str, object]:
+        """Sharded evaluation: every rank runs the evaluation loop of the reference
+        (src/keras_extensions/extended_model.py:1223-1298) over ITS share of the batches, then the int64 confusion
+        matrices and the (loss * images, images) pairs are summed over the ranks.  Integer sums do not depend on the
+        order of addition, so the matrix and every metric derived from it are identical for any rank count."""
+        from . import metrics
+        m = self.model
+        m.reset_metrics()
+        get = generator.__next__ if hasattr(generator, "__next__") else None
+        loss_sum, count = 0.0, 0
+        for b in range(steps):
+            batch = get() if get else generator.get_batch(0, b)
+            x, y = self.modify_batch_data(b, batch[0], batch[1], validation=True)
+            outs = m.test_on_batch(x, y)
+            n = int(x[0].shape[0])
+            loss_sum += float(outs[0]) * n
+            count += n
+        return self.reduce_evaluation(loss_sum, count)
+
+    def reduce_evaluation(self, loss_sum: float, count: int) -> Dict[str, object]:
+        from . import metrics
+        cm, loss, images = all_reduce_evaluation(self.model._cm, loss_sum, count, self.reducer.group if self.reducer else None)
+        out = {"loss": loss, "images": images, "confusion_matrix": cm}
+        out.update(metrics.metrics_from_confusion_matrix(cm, self.ignore_classes))
+        return out
 
     def train(self, generator, steps_per_epoch, validation_data=None, validation_steps=None):
         return self.model.fit_generator(generator, steps_per_epoch, epochs=self.num_epochs, validation_data=validation_data,

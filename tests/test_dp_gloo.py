@@ -47,12 +47,15 @@ def _worker(rank, world, port, out_dir):
     flat /= red.world_size
     cm = torch.from_numpy(ref["cm"].copy())
     red.sum_int64_(cm)
+    # sharded evaluation: matrix and mean loss over all shards
+    ecm, eloss, eimg = trainers.all_reduce_evaluation(torch.from_numpy(ref["cm"].copy()), ref["loss"] * (hi - lo), hi - lo)
     t = torch.full((3,), float(rank))
     red.broadcast_([t], src=0)
     if rank == 0:
-        np.savez(os.path.join(out_dir, "r0.npz"), flat=flat.numpy(), cm=cm.numpy(), bytes=red.bytes_reduced, t=t.numpy())
+        np.savez(os.path.join(out_dir, "r0.npz"), flat=flat.numpy(), cm=cm.numpy(), bytes=red.bytes_reduced, t=t.numpy(),
+                 ecm=ecm, eloss=eloss, eimg=eimg)
     else:
-        np.savez(os.path.join(out_dir, "r1.npz"), flat=flat.numpy(), cm=cm.numpy(), t=t.numpy())
+        np.savez(os.path.join(out_dir, "r1.npz"), flat=flat.numpy(), cm=cm.numpy(), t=t.numpy(), ecm=ecm, eloss=eloss, eimg=eimg)
     dist.destroy_process_group()
 
 
@@ -74,6 +77,10 @@ def test_two_rank_gradient_average_and_cm_sum(tmp_path):
     assert np.allclose(r0["flat"], exp, rtol=1e-12, atol=1e-15)
     assert np.array_equal(r0["cm"], g[0]["cm"] + g[1]["cm"])
     assert int(r0["bytes"]) == exp.size * 8
+    # evaluation reduce: identical on both ranks, exact matrix, image-weighted mean loss
+    assert np.array_equal(r0["ecm"], r1["ecm"]) and np.array_equal(r0["ecm"], g[0]["cm"] + g[1]["cm"])
+    assert int(r0["eimg"]) == 4 and float(r0["eloss"]) == float(r1["eloss"])
+    assert abs(float(r0["eloss"]) - 0.5 * (g[0]["loss"] + g[1]["loss"])) < 1e-12
 
 
 def test_shard_range():
