@@ -69,6 +69,16 @@ ssmi_status ssmi_same_pad(int32_t in, int32_t k, int32_t stride, int32_t dil, in
 /* Keras Conv2D forward (src/models.py:1056-1060, 1090-1096, 1105-1133, 1142-1147).  bias may be NULL. */
 ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                             void* stream);
+/* Convolution whose output feeds a training-phase BatchNormalization (every conv -> BN pair of src/models.py, e.g.
+ * :1096-1100): same y as ssmi_conv2d_fwd plus the statistics ssmi_bn_train_stats would compute from y (save_mean,
+ * save_invstd, moving-average update), with the per-channel sums taken in the convolution kernel's epilogue instead of
+ * a second pass over y.  ws: ssmi_conv2d_fwd_bn_stats_workspace_bytes(d). */
+size_t ssmi_conv2d_fwd_bn_stats_workspace_bytes(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                     float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
+                                     float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                     void* stream);
+
 /* Gradient w.r.t. x (tf.gradients through Conv2D).  dx[n,h,w,cin] (pixel stride x_ld) is fully overwritten:
  * dx = conv_bwd_data(dy, w) + (add ? add : 0), where `add` (nullable) has the layout of dx.  The `add` operand
  * carries the gradient of the block's skip branch (src/models.py:1171). */

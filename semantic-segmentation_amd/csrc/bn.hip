@@ -48,10 +48,22 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   const bool active = pl < ppi;
   f32x4 v[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (active) {
-    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
-      const f32x4 a = ld4(x + p * ld + c4 * 4);
-      v[0] += a;
-      v[1] += a * a;
+    // eight pixels per round with all loads in flight at once (a one-load-per-iteration loop costs one memory round
+    // trip per pixel); pixels past the end read zeros through the buffer bounds check
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)(npix * ld * 4));
+    const int64_t stride = (int64_t)gridDim.x * ppi;
+    for (int64_t p0 = (int64_t)blockIdx.x * ppi + pl; p0 < npix; p0 += stride * 8) {
+      f32x4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int64_t p = p0 + u * stride;
+        a[u] = bload4(rx, p < npix ? (unsigned)((p * ld + c4 * 4) * 4) : kOOB);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v[0] += a[u];
+        v[1] += a[u] * a[u];
+      }
     }
   }
   block_reduce_groups<2>(v, sm, c4n, ppi, active);
@@ -62,42 +74,59 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   }
 }
 
-// Sums NR rows of per-block partials for 8 channels per block: thread (chl = tid & 7, slice = tid >> 3) adds the blocks
-// slice, slice+32, ... in double, then the 32 slices are combined through LDS.  Result valid for tid < 8.
-template <int NR>
+// Sums the rows of per-block partials for CH channels per workgroup: thread (chl = tid % CH, slice = tid / CH) adds
+// the rows slice, slice + 256/CH, ... in double (eight rows per round, their loads issued together; rows past the end
+// and channels past c read zeros through the buffer bounds check), then the slices are combined through LDS in a fixed
+// order.  Result valid for tid < CH.  Fewer channels per workgroup = more slices = fewer serial rounds for many rows.
+template <int NR, int CH>
 __device__ __forceinline__ void final_reduce(const float* __restrict__ part, int nblocks, int c, int ch, double (&out)[NR]) {
   __shared__ double sm[NR][256];
-  const int slice = threadIdx.x >> 3;
+  constexpr int NS = 256 / CH;
+  const int slice = threadIdx.x / CH;
   double acc[NR];
 #pragma unroll
   for (int k = 0; k < NR; ++k) acc[k] = 0.0;
-  if (ch < c) {
-    for (int b = slice; b < nblocks; b += 32) {
+  {
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(part, (unsigned)((int64_t)nblocks * NR * c * 4));
+    const unsigned cho = ch < c ? (unsigned)ch * 4u : kOOB;
+    const unsigned rowb = (unsigned)(NR * c) * 4u;
+    for (int b0 = slice; b0 < nblocks; b0 += NS * 8) {
+      float v[8][NR];
 #pragma unroll
-      for (int k = 0; k < NR; ++k) acc[k] += (double)part[((int64_t)b * NR + k) * c + ch];
+      for (int u = 0; u < 8; ++u) {
+        const int b = b0 + NS * u;
+        const unsigned ro = b < nblocks ? cho + (unsigned)b * rowb : kOOB;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) v[u][k] = bload(rp, ro + (unsigned)(k * c) * 4u);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) acc[k] += (double)v[u][k];
     }
   }
 #pragma unroll
   for (int k = 0; k < NR; ++k) sm[k][threadIdx.x] = acc[k];
   __syncthreads();
-  if (threadIdx.x < 8) {
+  if (threadIdx.x < CH) {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       double s = 0.0;
-      for (int q = 0; q < 32; ++q) s += sm[k][q * 8 + threadIdx.x];
+      for (int q = 0; q < NS; ++q) s += sm[k][q * CH + threadIdx.x];
       out[k] = s;
     }
   }
 }
 
+template <int CH>
 __global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ part, int nblocks, int c, int64_t npix,
                                                       float eps, float momentum, int unbiased,
                                                       float* __restrict__ moving_mean, float* __restrict__ moving_var,
                                                       float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int ch = blockIdx.x * CH + (threadIdx.x % CH);
   double r[2];
-  final_reduce<2>(part, nblocks, c, ch, r);
-  if (threadIdx.x >= 8 || ch >= c) return;
+  final_reduce<2, CH>(part, nblocks, c, ch, r);
+  if (threadIdx.x >= CH || ch >= c) return;
   const double n = (double)npix;
   const double mean = r[0] / n;
   double var = r[1] / n - mean * mean;
@@ -109,6 +138,18 @@ __global__ __launch_bounds__(256) void bn_stats_final(const float* __restrict__ 
     const double mv = (unbiased && npix > 1) ? var * n / (n - 1.0) : var;
     moving_var[ch] = momentum * moving_var[ch] + (1.f - momentum) * (float)mv;
   }
+}
+
+ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t npix, float eps, float momentum,
+                                  int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                  float* save_invstd, hipStream_t stream) {
+  SSMI_REQUIRE((int64_t)rows * 2 * c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn statistics: partial-sum table too large");
+#define LF(CH) hipLaunchKernelGGL((bn_stats_final<CH>), dim3((c + CH - 1) / CH), dim3(256), 0, stream, part, rows, c, npix, \
+                                  eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean, save_invstd)
+  if (rows <= 512) LF(8); else if (rows <= 1024) LF(4); else if (rows <= 2048) LF(2); else LF(1);
+#undef LF
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
 }
 
 __global__ void bn_infer_stats_kernel(const float* __restrict__ mm, const float* __restrict__ mv, int c, float eps,
@@ -172,18 +213,37 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict
     const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
     f32x4 a = {slope, slope, slope, slope};
     if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
-    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
-      const f32x4 xv = ld4(x + p * ld + c);
-      f32x4 d = ld4(dy + p * dy_ld + c);
-      if (drop) d = d * ld4(drop + (p / hw) * (c4n * 4) + c);
+    // four pixels per round, their eight loads in flight together
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)(npix * ld * 4));
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, (unsigned)(npix * dy_ld * 4));
+    const int64_t stride = (int64_t)gridDim.x * ppi;
+    for (int64_t p0 = (int64_t)blockIdx.x * ppi + pl; p0 < npix; p0 += stride * 4) {
+      f32x4 xv[4], d[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xh = (xv[j] - m[j]) * is[j];
-        const float z = g[j] * xh + b[j];
-        const float dz = d[j] * act_grad<ACT>(z, a[j]);
-        v[0][j] += dz;
-        v[1][j] += dz * xh;
-        if (ACT == SSMI_ACT_PRELU) v[2][j] += d[j] * (z < 0.f ? z : 0.f);
+      for (int u = 0; u < 4; ++u) {
+        const int64_t p = p0 + u * stride;
+        const bool ok = p < npix;
+        xv[u] = bload4(rx, ok ? (unsigned)((p * ld + c) * 4) : kOOB);
+        d[u] = bload4(rd, ok ? (unsigned)((p * dy_ld + c) * 4) : kOOB);   // zero gradient for pixels past the end
+      }
+      if (drop) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int64_t p = p0 + u * stride;
+          d[u] = d[u] * ld4(drop + ((p < npix ? p : npix - 1) / hw) * (c4n * 4) + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[u][j] - m[j]) * is[j];
+          const float z = g[j] * xh + b[j];
+          const float dz = d[u][j] * act_grad<ACT>(z, a[j]);
+          v[0][j] += dz;
+          v[1][j] += dz * xh;
+          if (ACT == SSMI_ACT_PRELU) v[2][j] += d[u][j] * (z < 0.f ? z : 0.f);
+        }
       }
     }
   }
@@ -202,7 +262,7 @@ __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ pa
                                                     float* __restrict__ dalpha, float* __restrict__ coef) {
   const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
   double r[3];
-  final_reduce<3>(part, nblocks, c, ch, r);
+  final_reduce<3, 8>(part, nblocks, c, ch, r);
   if (threadIdx.x >= 8 || ch >= c) return;
   if (dbeta) dbeta[ch] = (float)r[0];
   if (dgamma) dgamma[ch] = (float)r[1];
@@ -435,16 +495,15 @@ ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t
   ssmi_status s = check_c(c, "bn_train_stats");
   if (s) return s;
   SSMI_REQUIRE(x && save_mean && save_invstd && npix > 0 && ld >= c && ld % 4 == 0, SSMI_E_INVALID_ARG, "bn_train_stats: bad argument");
+  SSMI_REQUIRE(npix * ld * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn_train_stats: tensors of 2 GiB or more are not supported");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_train_stats: workspace too small");
   const int c4n = c / 4;
   const int nb = red_blocks(npix, c4n);
   float* part = reinterpret_cast<float*>(ws);
   hipLaunchKernelGGL(bn_stats_partial, dim3(nb), dim3(256), 0, as_stream(stream), x, npix, c4n, ld, part);
   SSMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_stats_final, dim3((c + 7) / 8), dim3(256), 0, as_stream(stream), part, nb, c, npix, eps,
-                     momentum, unbiased_moving, moving_mean, moving_var, save_mean, save_invstd);
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return launch_bn_stats_final(part, nb, c, npix, eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean,
+                               save_invstd, as_stream(stream));
 }
 
 ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_var, int32_t c, float eps,
@@ -501,6 +560,8 @@ ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x,
   SSMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && npix > 0 && ld_x >= c && ld_x % 4 == 0 && ld_dy >= c && ld_dy % 4 == 0,
                SSMI_E_INVALID_ARG, "bn_act_bwd: bad argument");
   SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_bwd: npix must be a multiple of hw");
+  SSMI_REQUIRE(npix * ld_x * 4 < 0x7FFFFFFFLL && npix * ld_dy * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
+               "bn_act_bwd: tensors of 2 GiB or more are not supported");
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_bwd: PReLU needs alpha");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_act_bwd: workspace too small");
   const int c4n = c / 4;

@@ -39,12 +39,39 @@ void set_last_kernel(const char* fmt, ...);
     }                                                                              \
   } while (0)
 
+// Finalises per-workgroup column sums part[rows][2][c] (sum, sum of squares) into BatchNormalization statistics and the
+// moving-average update (bn.hip); shared by ssmi_bn_train_stats and the convolution with fused statistics.
+ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t npix, float eps, float momentum,
+                                  int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                  float* save_invstd, hipStream_t stream);
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// All operand loads are raw buffer loads: the descriptor carries the tensor's byte size, and a lane that must read a
+// zero (padding, tile tail, masked channel) simply passes an out-of-range offset - the hardware bounds check returns 0.
+// This keeps every load unconditional, so they issue back to back and overlap (a `valid ? load : 0` select makes hipcc
+// branch around each load and drain the memory counter after it).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned kOOB = 0x80000000u;   // >= any descriptor size (tensors are limited to 2 GiB - 1)
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);   // dropped when out of range
+}
 
 // Wave-wide (64 lanes) sum.
 __device__ __forceinline__ float wave_sum(float v) {

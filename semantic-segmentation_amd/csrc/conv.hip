@@ -22,27 +22,6 @@ static Geo to_geo(const ssmi_conv_desc* d) {
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-// All operand loads are raw buffer loads: the descriptor carries the tensor's byte size, and a lane that must read a
-// zero (padding, tile tail, masked channel) simply passes an out-of-range offset - the hardware bounds check returns 0.
-// This keeps every load unconditional, so they issue back to back and overlap (a `valid ? load : 0` select makes hipcc
-// branch around each load and drain the memory counter after it).
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-static constexpr unsigned kOOB = 0x80000000u;   // >= any descriptor size (tensors are limited to 2 GiB - 1)
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
-
-__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);   // dropped when out of range
-}
-
 struct Sizes {
   unsigned x_bytes, y_bytes, w_bytes;   // byte sizes of the x-like, y-like and kernel tensors
 };
@@ -55,12 +34,13 @@ struct Sizes {
 template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y) {
+                                                       float* __restrict__ y, float* __restrict__ part) {
+  __shared__ float stat_sm[4 * 2 * NT * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  if (tile0 >= M) return;
+  if (tile0 >= M && part == nullptr) return;   // with statistics every wave reaches the barrier (its rows are masked)
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
   const int64_t p = tile0 + r;
@@ -140,6 +120,37 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
     const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cout * 4u), colv[t] ? (unsigned)c * 4u : kOOB) : 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
+    if (part) {   // per-wave column sums of y and y^2 over the valid rows (BatchNormalization statistics)
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float v = rowoff[i] != kOOB ? acc[t][i] + bv : 0.f;
+        s1 += v;
+        s2 += v * v;
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      if (hh == 0) {
+        stat_sm[(wave * 2 + 0) * (NT * 32) + t * 32 + r] = s1;
+        stat_sm[(wave * 2 + 1) * (NT * 32) + t * 32 + r] = s2;
+      }
+    }
+  }
+  if (part) {
+    __syncthreads();
+    if (threadIdx.x < NT * 32) {
+      const int c = cbase + threadIdx.x;
+      if (c < g.cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          s1 += stat_sm[(wv * 2 + 0) * (NT * 32) + threadIdx.x];
+          s2 += stat_sm[(wv * 2 + 1) * (NT * 32) + threadIdx.x];
+        }
+        part[((int64_t)blockIdx.x * 2 + 0) * g.cout + c] = s1;
+        part[((int64_t)blockIdx.x * 2 + 1) * g.cout + c] = s2;
+      }
+    }
   }
 }
 
@@ -293,7 +304,8 @@ static constexpr int kMaxTaps = 32;
 template <bool M16, int MT, int NT, bool VEC, int D>
 __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                     const float* __restrict__ add, float* __restrict__ out) {
+                                                     const float* __restrict__ add, float* __restrict__ out,
+                                                     float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TS = M16 ? 16 : 32;
   constexpr int KQ = 64 / TS;
@@ -376,6 +388,10 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   const int64_t ngroups = (M + MT * TS - 1) / (MT * TS);
   const int cbase0 = blockIdx.y * NT * TS;
   const int kq_tap0 = (kq * EW) / a.C_r, kq_r0 = (kq * EW) % a.C_r;
+
+  float st1[NT], st2[NT];   // running column sums of the output and its square (forward with statistics only)
+#pragma unroll
+  for (int t = 0; t < NT; ++t) st1[t] = st2[t] = 0.f;
 
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
     const int64_t tile0 = grp * (MT * TS);
@@ -490,6 +506,47 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 #pragma unroll
         for (int i = 0; i < NR; ++i)
           bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, acc[m][t][i] + bvv + av[m][i]);
+      if (part) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const float v = rowoff[m][i] != kOOB ? acc[m][t][i] + bvv : 0.f;
+            st1[t] += v;
+            st2[t] += v * v;
+          }
+      }
+    }
+  }
+  if (part) {   // uniform: combine the lane groups that share a column, then the four waves through LDS
+    __syncthreads();             // every wave is done with the kernel matrix in LDS
+    float* red = smem;           // [4 waves][2][NT*TS]
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float s1 = st1[t], s2 = st2[t];
+#pragma unroll
+      for (int o = TS; o < 64; o <<= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+      }
+      if (kq == 0) {
+        red[(wave * 2 + 0) * (NT * TS) + t * TS + c] = s1;
+        red[(wave * 2 + 1) * (NT * TS) + t * TS + c] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < NT * TS) {
+      const int col = cbase0 + tid;
+      if (col < a.C_o) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+          s1 += red[(wv * 2 + 0) * (NT * TS) + tid];
+          s2 += red[(wv * 2 + 1) * (NT * TS) + tid];
+        }
+        part[((int64_t)blockIdx.x * 2 + 0) * a.C_o + col] = s1;
+        part[((int64_t)blockIdx.x * 2 + 1) * a.C_o + col] = s2;
+      }
     }
   }
 }
@@ -822,16 +879,18 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __res
   const int e = blockIdx.x * 16 + (threadIdx.x & 15);
   const int slice = threadIdx.x >> 4;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < E) {
-    const float* p = part + e;
-    int c = slice;
-    for (; c + 48 < nstrips; c += 64) {
-      s0 += p[(int64_t)c * E];
-      s1 += p[(int64_t)(c + 16) * E];
-      s2 += p[(int64_t)(c + 32) * E];
-      s3 += p[(int64_t)(c + 48) * E];
+  {
+    // four strips per round, loads issued together; strips past the end read zeros through the bounds check
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(part, (unsigned)((int64_t)nstrips * E * 4));
+    const unsigned eo = e < E ? (unsigned)e * 4u : kOOB;
+    const unsigned rowb = (unsigned)E * 4u;
+    for (int c = slice; c < nstrips; c += 64) {
+      const float v0 = bload(rp, eo + (unsigned)c * rowb);
+      const float v1 = bload(rp, c + 16 < nstrips ? eo + (unsigned)(c + 16) * rowb : kOOB);
+      const float v2 = bload(rp, c + 32 < nstrips ? eo + (unsigned)(c + 32) * rowb : kOOB);
+      const float v3 = bload(rp, c + 48 < nstrips ? eo + (unsigned)(c + 48) * rowb : kOOB);
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
     }
-    for (; c < nstrips; c += 16) s0 += p[(int64_t)c * E];
   }
   sm[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
@@ -932,7 +991,8 @@ static ssmi_status make_sizes(const Geo& g, Sizes* sz) {
 
 // Picks the LDS-weight kernel when the kernel matrix fits in 64 KiB of LDS; returns false otherwise.
 static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float* in, const float* w, const float* bias,
-                            const float* add, float* out, hipStream_t st, ssmi_status* status) {
+                            const float* add, float* out, hipStream_t st, ssmi_status* status, float* part = nullptr,
+                            int* part_rows = nullptr) {
   GemmArgs a;
   a.mode = mode;
   a.C_r = mode == 0 ? g.cin : g.cout;
@@ -960,8 +1020,9 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   a.WS = m16 ? copad + 4 : copad;
   // a stride phase of the data gradient sees at most ceil(k/s)^2 taps (all of them when dilated)
   const int staged_taps = (mode == 0 || g.dil > 1) ? ntaps : ((g.kh + g.stride - 1) / g.stride) * ((g.kw + g.stride - 1) / g.stride);
-  const size_t lds = (size_t)(4 + 4 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
+  size_t lds = (size_t)(4 + 4 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
   if (lds > 64 * 1024) return false;
+  if (part && lds < (size_t)8 * nt * ts * 4) lds = (size_t)8 * nt * ts * 4;   // room for the statistics combine
   const bool vec = (a.C_r % 4 == 0) && (a.in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   const int kb = (64 / ts) * (vec ? 4 : 1);
   a.q_blk = kb / a.C_r;
@@ -976,7 +1037,8 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
 #define LG(M16_, MT_, NT_, V_, D_) \
-  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_, D_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out)
+  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_, D_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out, part)
+  if (part_rows) *part_rows = (int)bx;
   // prefetch depth: cover the whole reduction when it is short, else as deep as the register budget allows
   const int nblk = (staged_taps * a.C_r + kb - 1) / kb;
   set_last_kernel("conv_gemm_lds<%s, %d, %d, %s, %d>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false",
@@ -1004,18 +1066,20 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   return true;
 }
 
+// part != nullptr: the kernel also writes per-workgroup column sums of y and y^2, part[row][2][cout]; *part_rows = rows.
 static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, const float* bias, float* y,
-                              hipStream_t st) {
+                              hipStream_t st, float* part = nullptr, int* part_rows = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
-  if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e)) return e;
+  if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e, part, part_rows)) return e;
+  if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   set_last_kernel("conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
-#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y)
+#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
   } else {
@@ -1181,6 +1245,29 @@ ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float
   if (s) return s;
   SSMI_REQUIRE(x && w && y, SSMI_E_INVALID_ARG, "conv2d_fwd: NULL tensor");
   return launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream));
+}
+
+size_t ssmi_conv2d_fwd_bn_stats_workspace_bytes(const ssmi_conv_desc* d) {
+  if (check_desc(d) != SSMI_OK) return 0;
+  const int64_t rows = ceil_div64((int64_t)d->n * d->ho * d->wo, 128) + 1024;   // direct kernel: one row per 128 pixels
+  return (size_t)rows * 2 * d->cout * sizeof(float);
+}
+
+ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                                     float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
+                                     float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
+                                     void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(x && w && y && save_mean && save_invstd, SSMI_E_INVALID_ARG, "conv2d_fwd_bn_stats: NULL tensor");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_fwd_bn_stats_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_fwd_bn_stats: workspace too small");
+  int rows = 0;
+  float* part = reinterpret_cast<float*>(ws);
+  s = launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream), part, &rows);
+  if (s) return s;
+  return launch_bn_stats_final(part, rows, d->cout, (int64_t)d->n * d->ho * d->wo, eps, momentum, unbiased_moving,
+                               moving_mean, moving_var, save_mean, save_invstd, as_stream(stream));
 }
 
 ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,

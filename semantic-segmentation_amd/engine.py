@@ -149,7 +149,8 @@ class Conv:
             d.y_ld = y_ld or self.cout
             out_hw = (ho, wo)
             d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l = self.kh, self.kw, self.stride, self.dil, pt, pl
-            self.ws_bytes = L.conv2d_bwd_weight_workspace_bytes(C.byref(d))
+            self.ws_bytes = max(L.conv2d_bwd_weight_workspace_bytes(C.byref(d)),
+                                L.conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)))
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
             H, W = h * self.stride, w * self.stride
@@ -176,6 +177,18 @@ class Conv:
             L.conv2d_transpose_fwd(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), st)
         else:
             L.conv2d_fwd(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), st)
+
+    def fwd_bn(self, x, y, bn: "BatchNorm", npix, training, update_moving, unbiased, ws, st):
+        """Convolution followed by the statistics of the BatchNormalization that consumes it.  In the training phase
+        the column sums come out of the convolution kernel's epilogue (no second pass over y)."""
+        if self.transpose or not training:
+            self.fwd(x, y, st)
+            bn.stats(y, npix, self.cout, training, update_moving, unbiased, ws, st)
+            return
+        lib().conv2d_fwd_bn_stats(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), BN_EPS, BN_MOMENTUM,
+                                  1 if unbiased else 0, _ptr(bn.mm) if update_moving else None,
+                                  _ptr(bn.mv) if update_moving else None, _ptr(bn.mean), _ptr(bn.invstd), _ptr(ws),
+                                  ws.numel() * 4, st)
 
     def bwd_data(self, dy, dx, st, add=None):
         L = lib()
@@ -498,27 +511,23 @@ class Bottleneck(Block):
         tr, um, ub = cfg.training, cfg.update_moving, cfg.unbiased_moving
         self.x = x
         i = self.internal
-        self.conv1.fwd(x, self.y1, st)
-        self.bn1.stats(self.y1, self.np1, i, tr, um, ub, ws, st)
+        self.conv1.fwd_bn(x, self.y1, self.bn1, self.np1, tr, um, ub, ws, st)
         self.bn1.act_fwd(self.y1, i, self.a1, self.np1, st)
         if self.conv2a is not None:
             self.conv2a.fwd(self.a1, self.t, st)
-            self.conv2.fwd(self.t, self.y2, st)
+            self.conv2.fwd_bn(self.t, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
         elif self.nn_resize:
             L.upsample_nn2x_fwd(_ptr(self.a1), self.n, self.h1, self.w1, i, _ptr(self.a1u), i, st)
-            self.conv2.fwd(self.a1u, self.y2, st)
+            self.conv2.fwd_bn(self.a1u, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
         else:
-            self.conv2.fwd(self.a1, self.y2, st)
-        self.bn2.stats(self.y2, self.np_out, i, tr, um, ub, ws, st)
+            self.conv2.fwd_bn(self.a1, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
         self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
-        self.conv3.fwd(self.a2, self.y3, st)
-        self.bn3.stats(self.y3, self.np_out, self.cout, tr, um, ub, ws, st)
+        self.conv3.fwd_bn(self.a2, self.y3, self.bn3, self.np_out, tr, um, ub, ws, st)
         if self.mode == 1:
             L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin,
                                  _ptr(self.idx), None, st)
         elif self.mode >= 2:
-            self.conv_o.fwd(x, self.yo, st)
-            self.bn_o.stats(self.yo, self.np_in, self.cout, tr, um, ub, ws, st)
+            self.conv_o.fwd_bn(x, self.yo, self.bn_o, self.np_in, tr, um, ub, ws, st)
         other, bn_o, idx = self._merge_other()
         drop = self.drop_mask if (cfg.use_dropout and self.drop_mask is not None) else None
         self._drop_used = drop
@@ -607,8 +616,8 @@ class EnhancedHead(Block):
         L = lib()
         C_ = self.num_classes
         L.upsample_nn2x_fwd(_ptr(x), self.n, self.h, self.w, self.cin, _ptr(self.xu), self.cin, cfg.st)
-        self.conv_a.fwd(self.xu, self.ya, cfg.st)
-        self.bn.stats(self.ya, self.npix, C_, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws, cfg.st)
+        self.conv_a.fwd_bn(self.xu, self.ya, self.bn, self.npix, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws,
+                           cfg.st)
         self.bn.act_fwd(self.ya, C_, self.aa, self.npix, cfg.st)
         self.conv.fwd(self.aa, self.out, cfg.st)
         return self.out

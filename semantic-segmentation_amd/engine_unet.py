@@ -49,8 +49,7 @@ class ConvUnit:
         L = lib()
         bn = self.bn
         self.x = x
-        self.conv.fwd(x, self.y, cfg.st)
-        bn.stats(self.y, self.npix, self.cout, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws, cfg.st)
+        self.conv.fwd_bn(x, self.y, bn, self.npix, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws, cfg.st)
         drop = self.drop_mask if cfg.use_dropout else None
         L.bn_act_drop_fwd(_ptr(self.y), self.cout, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), self.act,
                           None, LEAKY_ALPHA, _ptr(drop), self.h * self.w, _ptr(self.out), self.cout, self.npix, self.cout,

@@ -481,3 +481,43 @@ def test_scale_nc_spatial_dropout_table(n, hw, c):
     xd, td = _t(x), _t(tab)
     L.scale_nc(xd.data_ptr(), td.data_ptr(), y.data_ptr(), n, hw, c, torch.cuda.current_stream().cuda_stream)
     assert np.array_equal(y.cpu().numpy(), x * tab[:, None, :])
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES] + [(1, 1, 16, 64, 1, 1, "valid", False, 3, 37, 41),
+                                                             (3, 3, 16, 16, 1, 1, "same", True, 2, 50, 70),
+                                                             (1, 1, 64, 256, 1, 1, "valid", True, 1, 20, 24)],
+                         ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}".format(*c[:7]))
+def test_conv2d_fwd_with_fused_bn_statistics(case):
+    """The fused entry point must give the convolution output of ssmi_conv2d_fwd and the statistics
+    ssmi_bn_train_stats computes from it (oracle: biased batch variance, Keras moving-average update)."""
+    kh, kw, cin, cout, stride, dil, padding, bias, N, H, W = case
+    eng = pkg("engine")
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(kh * 100 + cin + cout)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=stride, dil=dil, padding=padding, bias=bias)
+    store.materialise(DEV)
+    ho, wo = cv.plan(N, H, W)
+    w = rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)
+    b = rng.standard_normal(cout) if bias else None
+    x = rng.standard_normal((N, H, W, cin)) + 0.3
+    store.views["c/kernel"].copy_(_t(w))
+    if bias:
+        store.views["c/bias"].copy_(_t(b))
+    xd = _t(x)
+    y = torch.empty(N, ho, wo, cout, device=DEV)
+    mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+    mm, mv = torch.full((cout,), 0.25, device=DEV), torch.full((cout,), 2.0, device=DEV)
+    ws = torch.empty(cv.ws_bytes // 4 + 16, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    L.conv2d_fwd_bn_stats(C.byref(cv.desc), xd.data_ptr(), cv.w.data_ptr(), cv.b.data_ptr() if bias else None, y.data_ptr(),
+                          1e-3, 0.1, 0, mm.data_ptr(), mv.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(),
+                          ws.numel() * 4, st)
+    ref = K.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b) if bias else None, stride, dil, padding)
+    _check(y, ref, "y")
+    flat = ref.reshape(-1, cout).numpy()
+    rm, rv = flat.mean(0), flat.var(0)
+    _check(mean, rm, "mean", rtol=1e-4, atol_rel=1e-5)
+    _check(invstd, 1.0 / np.sqrt(rv + 1e-3), "invstd", rtol=1e-4, atol_rel=1e-5)
+    _check(mm, 0.1 * 0.25 + 0.9 * rm, "moving mean", rtol=1e-4, atol_rel=1e-5)
+    _check(mv, 0.1 * 2.0 + 0.9 * rv, "moving variance", rtol=1e-4, atol_rel=1e-5)
