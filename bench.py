@@ -69,52 +69,7 @@ def cpu_baseline(seconds_budget=20.0):
                           len(times), med)}
 
 
-CONV_ENTRY_POINTS = ("conv2d_fwd", "conv2d_bwd_data", "conv2d_transpose_fwd", "conv2d_transpose_bwd_data")
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (MI355X_MICROARCH.md, MFMA table)
-
-
-class KernelTimer:
-    """Brackets every call of the single-kernel convolution entry points with HIP events recorded on the stream the
-    kernel is launched on (torch's current stream = the launch stream here), and notes which kernel variant ran."""
-
-    def __init__(self, L, names):
-        self.L, self.names, self.records = L, names, []
-        self._orig = {}
-
-    def __enter__(self):
-        for n in self.names:
-            orig = getattr(self.L, n)
-            self._orig[n] = orig
-
-            def wrapped(*a, _o=orig, _n=n):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                r = _o(*a)
-                e1.record()
-                self.records.append((_n, self.L.last_kernel().decode(), e0, e1, a))
-                return r
-            setattr(self.L, n, wrapped)
-        return self
-
-    def __exit__(self, *exc):
-        for n, o in self._orig.items():
-            setattr(self.L, n, o)
-
-
-def conv_algorithmic_work(entry, args):
-    """(bytes, flops) one launch must move / compute, from its descriptor (fp32).
-    forward:        read x [n,h,w,cin] + kernel, write y [n,ho,wo,cout]
-    data gradient:  read dy [n,ho,wo,cout] + kernel (+ the fused skip-gradient addend), write dx [n,h,w,cin]
-    (a transposed convolution's forward is the data gradient of the convolution its descriptor names, its backward
-    that convolution's forward); flops = 2 * output pixels * taps * cin * cout."""
-    d = args[0]._obj
-    xin = d.n * d.h * d.w * d.cin
-    yout = d.n * d.ho * d.wo * d.cout
-    wts = d.kh * d.kw * d.cin * d.cout
-    elems = xin + yout + wts
-    if entry == "conv2d_bwd_data" and args[3]:
-        elems += xin
-    return 4 * elems, 2 * d.n * d.ho * d.wo * d.kh * d.kw * d.cin * d.cout
 
 
 def main():
@@ -130,10 +85,14 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: inference-phase forward + loss + confusion matrix (e.g. --size 1024 --batch 10), the matrices "
                          "of all ranks summed at the end")
+    ap.add_argument("--overlap-wgrad", action="store_true", help="weight gradients on a second stream (one fork per block)")
     ap.add_argument("--eager", action="store_true", help="launch kernels directly instead of replaying HIP graphs")
     args = ap.parse_args()
 
     import torch.distributed as dist
+    if os.environ.get("SSMI_BENCH_WATCHDOG"):      # dump every thread's stack and exit if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SSMI_BENCH_WATCHDOG"]), exit=True)
     trainers = pkg("trainers")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
@@ -144,18 +103,30 @@ def main():
     tr = trainers.SegmentationTrainer("segmentation_supervised", args.model, "bench", config=cfg, num_classes=24)
     rank, world = tr.rank, tr.world_size
     dev = torch.device(tr.device)
+    t_begin = time.time()
+
+    def note(msg):      # progress on stderr (a silent multi-rank run is indistinguishable from a hung one)
+        if world > 1 or os.environ.get("SSMI_BENCH_VERBOSE"):
+            print("[bench rank {} +{:.1f}s] {}".format(rank, time.time() - t_begin, msg), file=sys.stderr, flush=True)
+    note("trainer ready on {}".format(dev))
     model = tr.model
     images, labels, weights = synthetic_batch(args.batch, args.size, args.size, 24, 14874 + rank, dev)
     nu = np.zeros((args.batch, 1), dtype=np.int32)
     stream = torch.cuda.Stream(device=dev)
     if args.eager:
         model.use_hip_graph = False
+    if args.overlap_wgrad:
+        model.graph.overlap_weight_gradients = True
     with torch.cuda.stream(stream):
         model.set_batch([images, labels, weights, nu])
         step = model.train_step_async if args.mode == "train" else model.eval_step_async
-        for _ in range(max(args.warmup, 1)):
+        for i in range(max(args.warmup, 1)):
             step()
+            if i == 0:
+                stream.synchronize()
+                note("first step done")
         stream.synchronize()
+        note("warm-up done")
         model.reset_metrics()
         if world > 1:
             dist.barrier()
@@ -215,26 +186,35 @@ def main():
 
 
 def measure_roofline(model, stream, steps=3):
-    """Eager instrumented steps (same buffers and kernels as the graph replay): HIP events around every convolution
-    launch.  The dominant kernel is the convolution kernel variant with the largest summed duration per step; its
-    roofline entry is  sum(algorithmic bytes of its launches) / sum(their durations), i.e. average algorithmic bytes per
-    launch over average launch duration, against the HBM peak when its arithmetic intensity is below the fp32-matrix
-    ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) and against the fp32 MFMA peak otherwise."""
+    """Eager instrumented steps (same buffers and kernels as the graph replay).  The library brackets every convolution
+    kernel launch (forward and data gradient) with HIP events on the launch stream and records the kernel variant with
+    the algorithmic bytes / flops of that launch (ssmi_profile_*).  The dominant kernel is the variant with the largest
+    summed duration per step; its roofline entry is  sum(algorithmic work of its launches) / sum(their durations),
+    i.e. average work per launch over average launch duration, against the HBM peak when its arithmetic intensity is
+    below the fp32-matrix ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) and against the fp32 MFMA peak otherwise."""
+    import ctypes as C
     L = pkg("_lib").lib()
     model.use_hip_graph = False
     with torch.cuda.stream(stream):
         model.train_step_async()
         stream.synchronize()
-        with KernelTimer(L, CONV_ENTRY_POINTS) as kt:
-            for _ in range(steps):
-                model.train_step_async()
-            stream.synchronize()
+        L.profile_begin()
+        for _ in range(steps):
+            model.train_step_async()
+        stream.synchronize()
+        cnt = C.c_int32()
+        L.profile_end(C.byref(cnt))
     model.use_hip_graph = True
+    records = []
+    name = C.create_string_buffer(128)
+    ms, by, fl = C.c_float(), C.c_double(), C.c_double()
+    for i in range(cnt.value):
+        L.profile_get(i, name, 128, C.byref(ms), C.byref(by), C.byref(fl))
+        records.append((name.value.decode(), ms.value, by.value, fl.value))
     agg = {}
-    for entry, kernel, e0, e1, a in kt.records:
-        by, fl = conv_algorithmic_work(entry, a)
+    for kernel, ms_, by, fl in records:
         r = agg.setdefault(kernel, [0.0, 0.0, 0.0, 0])
-        r[0] += e0.elapsed_time(e1)
+        r[0] += ms_
         r[1] += by
         r[2] += fl
         r[3] += 1

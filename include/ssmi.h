@@ -41,6 +41,13 @@ const char* ssmi_last_error(void);
 /* Name of the kernel variant the calling thread's last convolution entry point dispatched, as it appears in a
  * rocprofv3 kernel trace (e.g. "conv_gemm_lds<true, 4, 1, true>"); profiling aid, no reference counterpart. */
 const char* ssmi_last_kernel(void);
+/* Per-launch timing of the convolution kernels (forward and data gradient), for roofline reports; no reference
+ * counterpart.  Between ssmi_profile_begin() and ssmi_profile_end() every such launch is bracketed by HIP events on
+ * its own stream (do not use under graph capture); _end synchronises on them and returns the number of records;
+ * _get returns a record: kernel variant name, duration in ms, algorithmic bytes and flops of that launch. */
+ssmi_status ssmi_profile_begin(void);
+ssmi_status ssmi_profile_end(int32_t* count);
+ssmi_status ssmi_profile_get(int32_t index, char* name, int32_t name_len, float* ms, double* bytes, double* flops);
 int32_t ssmi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -39,6 +39,9 @@ _PB = C.POINTER(BnParams)
 _PROTOS = {
     "ssmi_last_error": (C.c_char_p, []),
     "ssmi_last_kernel": (C.c_char_p, []),
+    "ssmi_profile_begin": (_i32, []),
+    "ssmi_profile_end": (_i32, [C.POINTER(_i32)]),
+    "ssmi_profile_get": (_i32, [_i32, C.c_char_p, _i32, C.POINTER(_f32), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ssmi_version": (_i32, []),
     "ssmi_same_pad": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "ssmi_conv2d_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),

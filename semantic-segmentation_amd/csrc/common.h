@@ -45,6 +45,16 @@ ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t np
                                   int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, hipStream_t stream);
 
+// Optional per-launch timing (ssmi_profile_begin / _end): while enabled, a ProfileScope brackets ONE kernel launch with
+// HIP events on the launch stream and records the kernel name (set_last_kernel) with its algorithmic bytes and flops.
+struct ProfileScope {
+  ProfileScope(hipStream_t st, double bytes, double flops);
+  ~ProfileScope();
+  hipStream_t st_;
+  hipEvent_t e0_ = nullptr, e1_ = nullptr;
+  double bytes_, flops_;
+};
+
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

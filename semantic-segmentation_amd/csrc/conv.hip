@@ -43,14 +43,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
   if (tile0 >= M && part == nullptr) return;   // with statistics every wave reaches the barrier (its rows are masked)
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
-  const int64_t p = tile0 + r;
-  const bool pv = p < M;
-  const int64_t pp = pv ? p : 0;
-  const int ox = (int)(pp % g.wo);
-  const int64_t t1 = pp / g.wo;
-  const int oy = (int)(t1 % g.ho);
-  const int n_ = (int)(t1 / g.ho);
-  const unsigned img_off = (unsigned)n_ * (unsigned)(g.h * g.w) * (unsigned)g.x_ld * 4u;
+  const unsigned p = (unsigned)tile0 + (unsigned)r;       // M < 2^31: 32-bit pixel arithmetic
+  const bool pv = p < (unsigned)M;
+  const unsigned pp = pv ? p : 0u;
+  const unsigned t1 = pp / (unsigned)g.wo;
+  const int ox = (int)(pp - t1 * (unsigned)g.wo);
+  const unsigned n_ = t1 / (unsigned)g.ho;
+  const int oy = (int)(t1 - n_ * (unsigned)g.ho);
+  const unsigned img_off = n_ * (unsigned)(g.h * g.w) * (unsigned)g.x_ld * 4u;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
   unsigned rowoff[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int64_t po = tile0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-    rowoff[i] = po < M ? (unsigned)(po * g.y_ld) * 4u : kOOB;
+    const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+    rowoff[i] = po < (unsigned)M ? po * (unsigned)g.y_ld * 4u : kOOB;
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -178,15 +178,15 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
 
-  const int64_t p = tile0 + r;
-  const bool pv = p < M;
-  const int64_t pp = pv ? p : 0;
-  const int qx = (int)(pp % qw);
-  const int64_t t1 = pp / qw;
-  const int qy = (int)(t1 % qh);
-  const int n_ = (int)(t1 / qh);
+  const unsigned p = (unsigned)tile0 + (unsigned)r;       // M < 2^31: 32-bit pixel arithmetic
+  const bool pv = p < (unsigned)M;
+  const unsigned pp = pv ? p : 0u;
+  const unsigned t1 = pp / (unsigned)qw;
+  const int qx = (int)(pp - t1 * (unsigned)qw);
+  const unsigned n_ = t1 / (unsigned)qh;
+  const int qy = (int)(t1 - n_ * (unsigned)qh);
   const int iy = qy * s + pa, ix = qx * s + pb;
-  const unsigned img_off = (unsigned)n_ * (unsigned)(g.ho * g.wo) * (unsigned)g.y_ld * 4u;
+  const unsigned img_off = n_ * (unsigned)(g.ho * g.wo) * (unsigned)g.y_ld * 4u;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -253,17 +253,17 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
   unsigned rowoff[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const int64_t po = tile0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-    const int64_t pq = po < M ? po : 0;
-    int64_t pix = pq;
+    const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+    const unsigned pq = po < (unsigned)M ? po : 0u;
+    unsigned pix = pq;
     if (s != 1) {
-      const int ox_ = (int)(pq % qw);
-      const int64_t t2 = pq / qw;
-      const int oy_ = (int)(t2 % qh);
-      const int nn = (int)(t2 / qh);
-      pix = ((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb);
+      const unsigned t2 = pq / (unsigned)qw;
+      const unsigned ox_ = pq - t2 * (unsigned)qw;
+      const unsigned nn = t2 / (unsigned)qh;
+      const unsigned oy_ = t2 - nn * (unsigned)qh;
+      pix = (nn * (unsigned)g.h + (oy_ * (unsigned)s + (unsigned)pa)) * (unsigned)g.w + (ox_ * (unsigned)s + (unsigned)pb);
     }
-    rowoff[i] = po < M ? (unsigned)(pix * g.x_ld) * 4u : kOOB;
+    rowoff[i] = po < (unsigned)M ? pix * (unsigned)g.x_ld * 4u : kOOB;
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -397,16 +397,18 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
     const int64_t tile0 = grp * (MT * TS);
     bool pv[MT];
     int by[MT], bx[MT], img[MT];
+    // pixel coordinates in 32-bit arithmetic (M < 2^31: tensors are below 2 GiB); two divisions per pixel
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int64_t p = tile0 + m * TS + c;
-      pv[m] = p < M;
-      const int64_t pp = pv[m] ? p : 0;
-      const int qx = (int)(pp % qw);
-      const int64_t t1 = pp / qw;
-      by[m] = (int)(t1 % qh) * sm_;
-      bx[m] = qx * sm_;
-      img[m] = (int)(t1 / qh) * a.in_h * a.in_w;
+      const unsigned p = (unsigned)tile0 + (unsigned)(m * TS + c);
+      pv[m] = p < (unsigned)M;
+      const unsigned pp = pv[m] ? p : 0u;
+      const unsigned t1 = pp / (unsigned)qw;
+      const unsigned qx = pp - t1 * (unsigned)qw;
+      const unsigned n_ = t1 / (unsigned)qh;
+      by[m] = (int)(t1 - n_ * (unsigned)qh) * sm_;
+      bx[m] = (int)qx * sm_;
+      img[m] = (int)n_ * a.in_h * a.in_w;
     }
     accv acc[MT][NT];
 #pragma unroll
@@ -479,17 +481,17 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
-        const int64_t po = tile0 + m * TS + row;
-        const int64_t pq = po < M ? po : 0;
-        int64_t pix = pq;
+        const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
+        const unsigned pq = po < (unsigned)M ? po : 0u;
+        unsigned pix = pq;
         if (bwd && s != 1) {
-          const int ox_ = (int)(pq % qw);
-          const int64_t t2 = pq / qw;
-          const int oy_ = (int)(t2 % qh);
-          const int nn = (int)(t2 / qh);
-          pix = ((int64_t)nn * g.h + (oy_ * s + pa)) * g.w + (ox_ * s + pb);
+          const unsigned t2 = pq / (unsigned)qw;
+          const unsigned ox_ = pq - t2 * (unsigned)qw;
+          const unsigned nn = t2 / (unsigned)qh;
+          const unsigned oy_ = t2 - nn * (unsigned)qh;
+          pix = (nn * (unsigned)g.h + (oy_ * (unsigned)s + (unsigned)pa)) * (unsigned)g.w + (ox_ * (unsigned)s + (unsigned)pb);
         }
-        rowoff[m][i] = po < M ? (unsigned)(pix * a.out_ld) * 4u : kOOB;
+        rowoff[m][i] = po < (unsigned)M ? pix * (unsigned)a.out_ld * 4u : kOOB;
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -977,6 +979,16 @@ static ssmi_status check_desc(const ssmi_conv_desc* d) {
   return SSMI_OK;
 }
 
+// Algorithmic work of one launch (fp32): forward reads x and the kernel and writes y; the data gradient reads dy, the
+// kernel and the fused addend and writes dx.  flops = 2 * output pixels * taps * cin * cout.
+static double conv_bytes(const Geo& g, bool with_add) {
+  const double xin = (double)g.n * g.h * g.w * g.cin, yout = (double)g.n * g.ho * g.wo * g.cout;
+  return 4.0 * (xin + yout + (double)g.kh * g.kw * g.cin * g.cout + (with_add ? xin : 0.0));
+}
+static double conv_flops(const Geo& g) {
+  return 2.0 * g.n * g.ho * g.wo * (double)g.kh * g.kw * g.cin * g.cout;
+}
+
 static int pick_nt(int c) { return c <= 32 ? 1 : (c <= 64 ? 2 : 4); }
 
 // byte sizes for the buffer descriptors; tensors above 2 GiB - 1 are rejected (32-bit buffer offsets)
@@ -1072,6 +1084,7 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  ProfileScope prof(st, conv_bytes(g, false), conv_flops(g));
   if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e, part, part_rows)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
@@ -1095,6 +1108,7 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  ProfileScope prof(st, conv_bytes(g, add != nullptr), conv_flops(g));
   if (launch_gemm_lds(g, sz, 1, dy, w, bias, add, dx, st, &e)) return e;
   const int s = g.stride;
   const int qh = (g.h + s - 1) / s, qw = (g.w + s - 1) / s;

@@ -1,6 +1,8 @@
 // Error reporting, optimizers over the flat parameter arena, dropout tables and HIP-graph capture.
 #include <stdarg.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace ssmi {
@@ -104,6 +106,30 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ m
   mask[i] = (u >= rate) ? 1.f / (1.f - rate) : 0.f;
 }
 
+struct ProfileRecord {
+  char name[128];
+  hipEvent_t e0, e1;
+  double bytes, flops;
+  float ms;
+};
+static bool g_profiling = false;
+static std::vector<ProfileRecord> g_records;
+
+ProfileScope::ProfileScope(hipStream_t st, double bytes, double flops) : st_(st), bytes_(bytes), flops_(flops) {
+  if (!g_profiling) return;
+  if (hipEventCreate(&e0_) != hipSuccess || hipEventCreate(&e1_) != hipSuccess) { e0_ = e1_ = nullptr; return; }
+  hipEventRecord(e0_, st_);
+}
+
+ProfileScope::~ProfileScope() {
+  if (!e0_ || !e1_) return;
+  hipEventRecord(e1_, st_);
+  ProfileRecord r;
+  snprintf(r.name, sizeof(r.name), "%s", g_kernel);
+  r.e0 = e0_; r.e1 = e1_; r.bytes = bytes_; r.flops = flops_; r.ms = -1.f;
+  g_records.push_back(r);
+}
+
 }  // namespace ssmi
 
 using namespace ssmi;
@@ -117,6 +143,33 @@ extern "C" {
 
 const char* ssmi_last_error(void) { return g_err; }
 const char* ssmi_last_kernel(void) { return g_kernel; }
+
+ssmi_status ssmi_profile_begin(void) {
+  for (auto& r : g_records) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  g_records.clear();
+  g_profiling = true;
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_profile_end(int32_t* count) {
+  SSMI_REQUIRE(count != nullptr, SSMI_E_INVALID_ARG, "profile_end: count is NULL");
+  g_profiling = false;
+  for (auto& r : g_records) {
+    SSMI_HIP(hipEventSynchronize(r.e1));
+    SSMI_HIP(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+  }
+  *count = (int32_t)g_records.size();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_profile_get(int32_t index, char* name, int32_t name_len, float* ms, double* bytes, double* flops) {
+  SSMI_REQUIRE(index >= 0 && index < (int32_t)g_records.size() && name && name_len > 0 && ms && bytes && flops,
+               SSMI_E_INVALID_ARG, "profile_get: bad argument");
+  const ProfileRecord& r = g_records[index];
+  snprintf(name, (size_t)name_len, "%s", r.name);
+  *ms = r.ms; *bytes = r.bytes; *flops = r.flops;
+  return SSMI_OK;
+}
 int32_t ssmi_version(void) { return 100; }
 
 ssmi_status ssmi_adam_step(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,

@@ -265,25 +265,36 @@ class RunCfg:
     stream.  Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the
     latency-bound main chain (small BN / merge kernels) is running."""
     __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws", "main", "side", "ws2",
-                 "_forked")
+                 "_forked", "_pending")
 
     def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws, main=None, side=None, ws2=None):
         self.training, self.update_moving, self.unbiased_moving = training, update_moving, unbiased_moving
         self.use_dropout, self.st, self.ws = use_dropout, st, ws
         self.main, self.side, self.ws2 = main, side, ws2
         self._forked = False
+        self._pending = []
 
     def wgrad(self, conv, x, dy):
         if self.side is None:
             conv.bwd_weight(x, dy, self.ws, self.st)
             return
+        self._pending.append((conv, x, dy))
+
+    def flush(self):
+        """Launches the weight gradients collected since the last flush on the side stream, behind everything the main
+        stream has queued so far (one fork per block instead of one per convolution)."""
+        if self.side is None or not self._pending:
+            return
         ev = torch.cuda.Event()
         ev.record(self.main)
         self.side.wait_event(ev)
-        conv.bwd_weight(x, dy, self.ws2, self.side.cuda_stream)
+        for conv, x, dy in self._pending:
+            conv.bwd_weight(x, dy, self.ws2, self.side.cuda_stream)
+        self._pending = []
         self._forked = True
 
     def join(self):
+        self.flush()
         if self.side is not None and self._forked:
             ev = torch.cuda.Event()
             ev.record(self.side)
@@ -760,6 +771,7 @@ class GraphBase:
         d = dlogits
         for b in reversed(self.blocks):
             d = b.bwd(d, cfg)
+            cfg.flush()
         cfg.join()
 
     def refresh_dropout(self, seed: int, step_block: torch.Tensor, stream: Optional[int] = None):

@@ -258,6 +258,7 @@ class ExtendedModel(object):
             d = g.dlogits
             for b in reversed(blocks[split:]):
                 d = b.bwd(d, g._cfg)
+                g._cfg.flush()
             g._cfg.join()
             self._d_mid = d
 
@@ -265,6 +266,7 @@ class ExtendedModel(object):
             d = self._d_mid
             for b in reversed(blocks[:split]):
                 d = b.bwd(d, g._cfg)
+                g._cfg.flush()
             g._cfg.join()
 
         def seg_c(st):
@@ -302,7 +304,9 @@ class ExtendedModel(object):
             return
         L = lib()
         if key not in self._graphs:
-            # one eager pass first (plans buffers, warms up), then capture each segment
+            # nothing of this process may still be running on the device while the segments are recorded (parameter
+            # broadcast, a previous step's collectives)
+            torch.cuda.synchronize()
             glist = []
             for s in segs:
                 L.graph_begin_capture(st)

@@ -43,6 +43,9 @@ class GradientBucketReducer:
             return
         view = grad[lo:hi]
         self.bytes_reduced += view.numel() * view.element_size()
+        if os.environ.get("SSMI_SYNC_ALLREDUCE"):       # debugging aid: blocking collectives
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            return
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
@@ -85,18 +88,23 @@ def init_distributed_from_env(backend: Optional[str] = None) -> Tuple[int, int, 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    dev_index = local % ndev if ndev else 0     # more ranks than devices only happens in single-GPU rehearsals (gloo)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("SSMI_DIST_BACKEND") or ("nccl" if ndev else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
+            if ndev:
+                torch.cuda.set_device(dev_index)
             dist.init_process_group(backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
+    elif ndev:
+        torch.cuda.set_device(dev_index)
+    local = dev_index
     return rank, local, world
 
 
