@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ beta, const float* __restrict__ alpha,
                                                          float slope, const float* __restrict__ drop, int64_t hw,
                                                          float* __restrict__ y, int y_ld, int64_t total4, int c4n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / c4n;
-    const int c = (int)(i % c4n) * 4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
+    const unsigned p = i / (unsigned)c4n;
+    const int c = (int)(i - p * (unsigned)c4n) * 4;
     const f32x4 xv = ld4(x + p * ld + c);
     const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
     f32x4 a = {slope, slope, slope, slope};
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
-    if (drop) o = o * ld4(drop + (p / hw) * (c4n * 4) + c);
+    if (drop) o = o * ld4(drop + (p / (unsigned)hw) * (unsigned)(c4n * 4) + c);
     st4(y + p * y_ld + c, o);
   }
 }
@@ -281,12 +281,12 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
                                                         const float* __restrict__ coef, float* __restrict__ dx,
                                                         int64_t total4, int c4n) {
   const int cc = c4n * 4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / c4n;
-    const int c = (int)(i % c4n) * 4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
+    const unsigned p = i / (unsigned)c4n;
+    const int c = (int)(i - p * (unsigned)c4n) * 4;
     const f32x4 xv = ld4(x + p * ld + c);
     f32x4 d = ld4(dy + p * dy_ld + c);
-    if (drop) d = d * ld4(drop + (p / hw) * cc + c);
+    if (drop) d = d * ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
     const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
     const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
     f32x4 a = {slope, slope, slope, slope};
@@ -319,13 +319,13 @@ struct MergeArgs {
 
 // pre-activation sum s and (optionally) the BN3 intermediates for element group (p, c..c+3)
 template <int MODE>
-__device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, int64_t p, int c, f32x4& xh3, f32x4& dropv) {
-  const int64_t hw = (int64_t)a.h * a.w;
-  const int n_ = (int)(p / hw);
+__device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, unsigned p, int c, f32x4& xh3, f32x4& dropv) {
+  const unsigned hw = (unsigned)(a.h * a.w);     // every tensor is below 2 GiB: 32-bit element arithmetic
+  const unsigned n_ = p / hw;
   const f32x4 mv = ld4(a.main + p * a.c + c);
   const f32x4 m = ld4(a.mean3 + c), is = ld4(a.invstd3 + c), g = ld4(a.gamma3 + c), b = ld4(a.beta3 + c);
   dropv = f32x4{1.f, 1.f, 1.f, 1.f};
-  if (a.drop) dropv = ld4(a.drop + (int64_t)n_ * a.c + c);
+  if (a.drop) dropv = ld4(a.drop + n_ * (unsigned)a.c + c);
   f32x4 s;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -337,10 +337,10 @@ __device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, int64_t p, int c,
   } else if (MODE == 1) {
     if (c < a.c_other) s += ld4(a.other + p * a.c_other + c);
   } else {
-    const int rem = (int)(p - (int64_t)n_ * hw);
-    const int y = rem / a.w, x = rem % a.w;
+    const unsigned rem = p - n_ * hw;
+    const int y = (int)(rem / (unsigned)a.w), x = (int)(rem - (unsigned)y * (unsigned)a.w);
     const int h2 = a.h >> 1, w2 = a.w >> 1;
-    const int64_t q = ((int64_t)n_ * h2 + (y >> 1)) * w2 + (x >> 1);
+    const unsigned q = (n_ * (unsigned)h2 + (unsigned)(y >> 1)) * (unsigned)w2 + (unsigned)(x >> 1);
     const f32x4 ov = ld4(a.other + q * a.c + c);
     const f32x4 mo = ld4(a.mean_o + c), iso = ld4(a.invstd_o + c), go = ld4(a.gamma_o + c), bo = ld4(a.beta_o + c);
     f32x4 o;
@@ -361,9 +361,9 @@ __device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, int64_t p, int c,
 
 template <int MODE>
 __global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, float* __restrict__ out, int64_t total4, int c4n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / c4n;
-    const int c = (int)(i % c4n) * 4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
+    const unsigned p = i / (unsigned)c4n;
+    const int c = (int)(i - p * (unsigned)c4n) * 4;
     f32x4 xh3, dv;
     const f32x4 s = merge_sum<MODE>(a, p, c, xh3, dv);
     const f32x4 al = ld4(a.alpha + c);
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const float
   f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (active) {
     const f32x4 al = ld4(a.alpha + c);
-    for (int64_t p = (int64_t)blockIdx.x * ppi + pl; p < npix; p += (int64_t)gridDim.x * ppi) {
+    for (unsigned p = blockIdx.x * (unsigned)ppi + (unsigned)pl; p < (unsigned)npix; p += gridDim.x * (unsigned)ppi) {
       f32x4 xh3, dv;
       const f32x4 s = merge_sum<MODE>(a, p, c, xh3, dv);
-      const f32x4 d = ld4(dout + (p * c4n + c4) * 4);
+      const f32x4 d = ld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
       f32x4 ds;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -417,14 +417,14 @@ __global__ __launch_bounds__(256) void merge_bwd_apply(const float* __restrict__
                                                        const float* __restrict__ drop, const float* __restrict__ coef,
                                                        float* __restrict__ dmain, int64_t total4, int c4n, int64_t hw) {
   const int cc = c4n * 4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t p = i / c4n;
-    const int c = (int)(i % c4n) * 4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
+    const unsigned p = i / (unsigned)c4n;
+    const int c = (int)(i - p * (unsigned)c4n) * 4;
     const f32x4 ds = ld4(dsum + i * 4), mv = ld4(main + i * 4);
     const f32x4 m = ld4(mean3 + c), is = ld4(invstd3 + c);
     const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
     f32x4 dv = {1.f, 1.f, 1.f, 1.f};
-    if (drop) dv = ld4(drop + (p / hw) * cc + c);
+    if (drop) dv = ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -442,9 +442,9 @@ __global__ __launch_bounds__(256) void merge_bwd_other(const float* __restrict__
                                                        int64_t total4) {
   const int c = c4n * 4;
   const int h2 = h >> 1, w2 = w >> 1;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    const int64_t q = i / c4n;
-    const int ch = (int)(i % c4n) * 4;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
+    const unsigned q = i / (unsigned)c4n;
+    const int ch = (int)(i - q * (unsigned)c4n) * 4;
     const int x2 = (int)(q % w2);
     const int64_t t = q / w2;
     const int y2 = (int)(t % h2);
@@ -531,6 +531,8 @@ ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean
                SSMI_E_INVALID_ARG, "bn_act_fwd: bad argument");
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_fwd: PReLU needs alpha");
   SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_fwd: npix must be a multiple of hw");
+  SSMI_REQUIRE(npix * ld_x * 4 < 0x7FFFFFFFLL && npix * ld_y * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
+               "bn_act_fwd: tensors of 2 GiB or more are not supported");
   const int c4n = c / 4;
   const int64_t total4 = npix * c4n;
   const int nb = ew_blocks(total4);
@@ -591,6 +593,8 @@ static ssmi_status fill_merge(const ssmi_merge_desc* d, const float* main, const
                               MergeArgs* a) {
   SSMI_REQUIRE(d && main && bn3 && other && alpha, SSMI_E_INVALID_ARG, "merge: NULL argument");
   SSMI_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, SSMI_E_SHAPE, "merge: bad shape");
+  SSMI_REQUIRE((int64_t)d->n * d->h * d->w * d->c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
+               "merge: tensors of 2 GiB or more are not supported");
   ssmi_status s = check_c(d->c, "merge");
   if (s) return s;
   SSMI_REQUIRE(d->other_mode >= 0 && d->other_mode <= 3, SSMI_E_INVALID_ARG, "merge: other_mode %d", d->other_mode);
