@@ -68,29 +68,59 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
   }
   const unsigned wrow = (unsigned)g.cout * 4u;   // bytes per (tap, ci) kernel row
 
-  for (int ky = 0; ky < g.kh; ++ky) {
-    const int iy = oy * g.stride + ky * g.dil - g.pad_t;
-    for (int kx = 0; kx < g.kw; ++kx) {
-      const int ix = ox * g.stride + kx * g.dil - g.pad_l;
-      const bool inb = pv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
-      const unsigned xo = inb ? img_off + (unsigned)(iy * g.w + ix) * (unsigned)g.x_ld * 4u : kOOB;
-      const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
-      if (VEC) {
-#pragma unroll 2
-        for (int c0 = 0; c0 < g.cin; c0 += 8) {
-          const int ci = c0 + 4 * hh;
-          const f32x4 a = bload4(rx, xo + (unsigned)ci * 4u);
-          float b[4][NT];
+  if (VEC) {
+    // Flattened (tap, 8-channel block) reduction, software pipelined: the operands of step i+1 are in flight while
+    // step i is multiplied (one A load of 16 bytes + 4*NT kernel words per step, double buffered in registers).
+    const int ntaps = g.kh * g.kw;
+    int tap = 0, ky = 0, kx = 0, c0 = 0;            // state of the NEXT fetch
+    unsigned xo = 0, wtap = 0;
+    auto settap = [&]() {
+      const int iy = oy * g.stride + ky * g.dil - g.pad_t, ix = ox * g.stride + kx * g.dil - g.pad_l;
+      const bool inb = pv && tap < ntaps && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+      xo = inb ? img_off + (unsigned)(iy * g.w + ix) * (unsigned)g.x_ld * 4u : kOOB;
+      wtap = tap < ntaps ? (unsigned)(tap * g.cin) * wrow : kOOB;
+    };
+    settap();
+    auto fetch = [&](f32x4& a, float (&b)[4][NT]) {
+      const int ci = c0 + 4 * hh;
+      a = bload4(rx, xo == kOOB ? kOOB : xo + (unsigned)ci * 4u);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) b[j][t] = bload(rw, wtap + (unsigned)(ci + j) * wrow + wcol[t]);
+        for (int t = 0; t < NT; ++t)
+          b[j][t] = bload(rw, (wtap == kOOB || wcol[t] == kOOB) ? kOOB : wtap + (unsigned)(ci + j) * wrow + wcol[t]);
+      c0 += 8;
+      if (c0 >= g.cin) {
+        c0 = 0;
+        ++tap;
+        if (++kx == g.kw) { kx = 0; ++ky; }
+        settap();
+      }
+    };
+    auto mma = [&](const f32x4& a, const float (&b)[4][NT]) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[j][t], acc[t]);
-        }
-      } else {
+        for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[j][t], acc[t]);
+    };
+    const int nsteps = ntaps * (g.cin >> 3);
+    f32x4 a0, a1;
+    float b0[4][NT], b1[4][NT];
+    fetch(a0, b0);
+    for (int i = 0; i < nsteps; i += 2) {
+      fetch(a1, b1);               // past the end: zeros (tap >= ntaps)
+      mma(a0, b0);
+      fetch(a0, b0);
+      if (i + 1 < nsteps) mma(a1, b1);
+    }
+  } else {
+    for (int ky = 0; ky < g.kh; ++ky) {
+      const int iy = oy * g.stride + ky * g.dil - g.pad_t;
+      for (int kx = 0; kx < g.kw; ++kx) {
+        const int ix = ox * g.stride + kx * g.dil - g.pad_l;
+        const bool inb = pv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        const unsigned xo = inb ? img_off + (unsigned)(iy * g.w + ix) * (unsigned)g.x_ld * 4u : kOOB;
+        const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
 #pragma unroll 4
         for (int c0 = 0; c0 < g.cin; c0 += 2) {
           const int ci = c0 + hh;
@@ -204,33 +234,73 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
     wci[t] = colv[t] ? (unsigned)c * wrow : kOOB;
   }
 
-  for (int ky = 0; ky < g.kh; ++ky) {
-    const int ty0 = pa + g.pad_t - ky * g.dil;
-    if (((ty0 % s) + s) % s != 0) continue;  // uniform
-    const int ty = iy + g.pad_t - ky * g.dil;
-    const int oy = ty / s;  // exact when ty >= 0
-    for (int kx = 0; kx < g.kw; ++kx) {
-      const int tx0 = pb + g.pad_l - kx * g.dil;
-      if (((tx0 % s) + s) % s != 0) continue;  // uniform
-      const int tx = ix + g.pad_l - kx * g.dil;
-      const int ox = tx / s;
-      const bool inb = pv && ty >= 0 && tx >= 0 && oy < g.ho && ox < g.wo;
-      const unsigned yo = inb ? img_off + (unsigned)(oy * g.wo + ox) * (unsigned)g.y_ld * 4u : kOOB;
-      const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
-      if (VEC) {
-#pragma unroll 2
-        for (int c0 = 0; c0 < g.cout; c0 += 8) {
-          const unsigned co4 = (unsigned)(c0 + 4 * hh) * 4u;
-          const f32x4 a = bload4(ry, yo + co4);
-          f32x4 b[NT];
+  if (VEC) {
+    // Flattened (valid tap of this phase, 8-channel block) reduction, software pipelined like the forward kernel.
+    const int ntaps = g.kh * g.kw;
+    int tap = -1, c0 = 0;                           // state of the NEXT fetch
+    unsigned yo = kOOB, wtap = kOOB;
+    auto nexttap = [&]() {                          // advance to the next tap that contributes to this phase (uniform)
+      for (++tap; tap < ntaps; ++tap) {
+        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+        const int ty0 = pa + g.pad_t - ky * g.dil, tx0 = pb + g.pad_l - kx * g.dil;
+        if (((ty0 % s) + s) % s != 0 || ((tx0 % s) + s) % s != 0) continue;
+        const int ty = iy + g.pad_t - ky * g.dil, tx = ix + g.pad_l - kx * g.dil;
+        const int oy = ty / s, ox = tx / s;         // exact when ty, tx >= 0
+        const bool inb = pv && ty >= 0 && tx >= 0 && oy < g.ho && ox < g.wo;
+        yo = inb ? img_off + (unsigned)(oy * g.wo + ox) * (unsigned)g.y_ld * 4u : kOOB;
+        wtap = (unsigned)(tap * g.cin) * wrow;
+        return;
+      }
+      yo = kOOB;
+      wtap = kOOB;
+    };
+    nexttap();
+    int nvalid = 0;
+    for (int t = 0; t < ntaps; ++t) {
+      const int ky = t / g.kw, kx = t - ky * g.kw;
+      const int ty0 = pa + g.pad_t - ky * g.dil, tx0 = pb + g.pad_l - kx * g.dil;
+      nvalid += (((ty0 % s) + s) % s == 0 && ((tx0 % s) + s) % s == 0) ? 1 : 0;
+    }
+    auto fetch = [&](f32x4& a, f32x4 (&b)[NT]) {
+      const unsigned co4 = (unsigned)(c0 + 4 * hh) * 4u;
+      a = bload4(ry, yo == kOOB ? kOOB : yo + co4);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) b[t] = bload4(rw, wtap + wci[t] + co4);
+      for (int t = 0; t < NT; ++t) b[t] = bload4(rw, (wtap == kOOB || wci[t] == kOOB) ? kOOB : wtap + wci[t] + co4);
+      c0 += 8;
+      if (c0 >= g.cout) {
+        c0 = 0;
+        nexttap();
+      }
+    };
+    auto mma = [&](const f32x4& a, const f32x4 (&b)[NT]) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[t][j], acc[t]);
-        }
-      } else {
+        for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[t][j], acc[t]);
+    };
+    const int nsteps = nvalid * (g.cout >> 3);
+    f32x4 a0, a1, b0[NT], b1[NT];
+    fetch(a0, b0);
+    for (int i = 0; i < nsteps; i += 2) {
+      fetch(a1, b1);               // past the end: zeros
+      mma(a0, b0);
+      fetch(a0, b0);
+      if (i + 1 < nsteps) mma(a1, b1);
+    }
+  } else {
+    for (int ky = 0; ky < g.kh; ++ky) {
+      const int ty0 = pa + g.pad_t - ky * g.dil;
+      if (((ty0 % s) + s) % s != 0) continue;  // uniform
+      const int ty = iy + g.pad_t - ky * g.dil;
+      const int oy = ty / s;  // exact when ty >= 0
+      for (int kx = 0; kx < g.kw; ++kx) {
+        const int tx0 = pb + g.pad_l - kx * g.dil;
+        if (((tx0 % s) + s) % s != 0) continue;  // uniform
+        const int tx = ix + g.pad_l - kx * g.dil;
+        const int ox = tx / s;
+        const bool inb = pv && ty >= 0 && tx >= 0 && oy < g.ho && ox < g.wo;
+        const unsigned yo = inb ? img_off + (unsigned)(oy * g.wo + ox) * (unsigned)g.y_ld * 4u : kOOB;
+        const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
 #pragma unroll 4
         for (int c0 = 0; c0 < g.cout; c0 += 2) {
           const int co = c0 + hh;
@@ -357,20 +427,45 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
       for (int e = tid; e < rows * padw; e += 256) Wl[(e / padw) * a.WS + a.C_o + e % padw] = 0.f;
     }
     const int per_tap = g.cin * g.cout;
+    const __amdgpu_buffer_rsrc_t rwt = make_rsrc(w, sz.w_bytes);
+    // Eight elements per thread and round, their loads issued together (a load-then-store loop costs one L2 round trip
+    // per element); elements past the end read zeros and are not stored.
     if (!bwd && a.WS == g.cout && (g.cout & 3) == 0 && ((reinterpret_cast<uintptr_t>(w) & 15) == 0)) {
       // forward, unpadded rows: the LDS image is the kernel itself (all taps are valid and in order)
-      const f32x4* src = reinterpret_cast<const f32x4*>(w);
       f32x4* dst = reinterpret_cast<f32x4*>(Wl);
-      for (int e = tid; e < (nv * per_tap) >> 2; e += 256) dst[e] = src[e];
-    } else {
-      for (int vi = 0; vi < nv; ++vi) {
-        const float* src = w + (int64_t)tab[4 + 3 * kMaxTaps + vi] * per_tap;
-        float* dst = Wl + vi * a.C_r * a.WS;
-        for (int e = tid; e < per_tap; e += 256) {
-          const int co = e % g.cout, ci = e / g.cout;
-          if (!bwd) dst[ci * a.WS + co] = src[e];
-          else dst[co * a.WS + ci] = src[e];
+      const int n4 = (nv * per_tap) >> 2;
+      for (int e0 = tid; e0 < n4; e0 += 256 * 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256;
+          v[u] = bload4(rwt, e < n4 ? (unsigned)e * 16u : kOOB);
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256;
+          if (e < n4) dst[e] = v[u];
+        }
+      }
+    } else {
+      const int total = nv * per_tap;
+      for (int e0 = tid; e0 < total; e0 += 256 * 8) {
+        float v[8];
+        int di[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int e = e0 + u * 256;
+          const bool ok = e < total;
+          const int es = ok ? e : 0;
+          const int vi = es / per_tap, q = es - vi * per_tap;
+          const int ci = q / g.cout, co = q - ci * g.cout;
+          const int srct = tab[4 + 3 * kMaxTaps + vi];
+          v[u] = bload(rwt, ok ? (unsigned)(srct * per_tap + q) * 4u : kOOB);
+          di[u] = ok ? vi * a.C_r * a.WS + (bwd ? co * a.WS + ci : ci * a.WS + co) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (di[u] >= 0) Wl[di[u]] = v[u];
       }
     }
   }
@@ -747,24 +842,35 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
   const int cin_e = g.cin / EW;   // elements per pixel (VEC requires cin % 4 == 0)
 #pragma unroll
   for (int i = 0; i < kXvMax; ++i) {
-    const int e = tid + i * 256;
-    const int es = e < l.x_elems ? e : 0;
-    const int c = (es % cin_e) * EW;
-    const int t = es / cin_e;
-    x_colp[i] = t % l.Wp;
-    x_kyd[i] = (t / l.Wp) * g.dil;
-    x_rel[i] = (unsigned)c * 4u;
-    if (e >= l.x_elems) x_kyd[i] = -(1 << 28);   // always out of range -> loads nothing
+    x_colp[i] = 0;
+    x_kyd[i] = -(1 << 28);   // always out of range -> loads nothing
+    x_rel[i] = 0u;
+    if (i < l.xv_n) {        // uniform: the unused slots cost no divisions
+      const unsigned e = (unsigned)(tid + i * 256);
+      if (e < (unsigned)l.x_elems) {
+        const unsigned t = e / (unsigned)cin_e;
+        const unsigned ky = t / (unsigned)l.Wp;
+        x_rel[i] = (e - t * (unsigned)cin_e) * (unsigned)EW * 4u;
+        x_colp[i] = (int)(t - ky * (unsigned)l.Wp);
+        x_kyd[i] = (int)ky * g.dil;
+      }
+    }
   }
   int y_p[kYvMax];
   unsigned y_rel[kYvMax];
   const int cout_e = (g.cout + EW - 1) / EW;
 #pragma unroll
   for (int i = 0; i < kYvMax; ++i) {
-    const int e = tid + i * 256;
-    const int es = e < l.y_elems ? e : 0;
-    y_p[i] = e < l.y_elems ? es / cout_e : (1 << 28);
-    y_rel[i] = (unsigned)((es % cout_e) * EW) * 4u;
+    y_p[i] = 1 << 28;
+    y_rel[i] = 0u;
+    if (i < l.yv_n) {
+      const unsigned e = (unsigned)(tid + i * 256);
+      if (e < (unsigned)l.y_elems) {
+        const unsigned q = e / (unsigned)cout_e;
+        y_p[i] = (int)q;
+        y_rel[i] = (e - q * (unsigned)cout_e) * (unsigned)EW * 4u;
+      }
+    }
   }
   // zero the whole block once (pad columns of the dy chunk, the zero word)
   for (int i = tid; i < l.lds_words; i += 256) smem[i] = 0.f;
