@@ -91,6 +91,20 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, co
  * carries the gradient of the block's skip branch (src/models.py:1171). */
 ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
                                  void* stream);
+/* Data gradient whose result is the gradient of a BatchNormalization(+activation, +SpatialDropout2D) OUTPUT, i.e. every
+ * "BN -> act -> conv" chain walked backwards (src/models.py:1096-1118 and the convolution blocks :846-876).  Same `da`
+ * as ssmi_conv2d_bwd_data (desc = the convolution; da has the x-like shape [n,h,w,cin], pixel stride x_ld) followed by
+ * ssmi_bn_act_drop_bwd on it (bn_x = the raw input of that BN, pixel stride ld_x): dx_bn, dgamma, dbeta, dalpha.  For
+ * stride-1 convolutions the per-channel sums are taken in the data-gradient kernel's epilogue, which saves one pass over
+ * da and bn_x; other shapes run the two plain passes.  ws: ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d). */
+size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add,
+                                        float* da, const float* bn_x, int32_t ld_x, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                        const float* alpha, float slope, const float* drop, int64_t hw, float* dx_bn,
+                                        float* dgamma, float* dbeta, float* dalpha, void* ws, size_t ws_bytes,
+                                        void* stream);
+
 /* Gradient w.r.t. the kernel (and bias when dbias != NULL).  dw/dbias are overwritten.  Deterministic
  * two-stage reduction through `ws`. */
 size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d);

@@ -48,6 +48,9 @@ _PROTOS = {
     "ssmi_conv2d_fwd_bn_stats_workspace_bytes": (_sz, [_PD]),
     "ssmi_conv2d_fwd_bn_stats": (_i32, [_PD, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_bwd_data": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes": (_sz, [_PD]),
+    "ssmi_conv2d_bwd_data_bn_bwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64,
+                                           _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_bwd_weight_workspace_bytes": (_sz, [_PD]),
     "ssmi_conv2d_bwd_weight": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_transpose_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
@@ -91,7 +94,7 @@ _PROTOS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes"}
 

@@ -256,14 +256,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict
 }
 
 // finalize: parameter gradients + coefficients for the apply pass: coef[0]=gamma*invstd, coef[1]=mean(dz), coef[2]=mean(dz*xhat)
+template <int CH>
 __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ part, int nblocks, int c, int64_t npix,
                                                     const float* __restrict__ gamma, const float* __restrict__ invstd,
                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                     float* __restrict__ dalpha, float* __restrict__ coef) {
-  const int ch = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int ch = blockIdx.x * CH + (threadIdx.x % CH);
   double r[3];
-  final_reduce<3, 8>(part, nblocks, c, ch, r);
-  if (threadIdx.x >= 8 || ch >= c) return;
+  final_reduce<3, CH>(part, nblocks, c, ch, r);
+  if (threadIdx.x >= CH || ch >= c) return;
   if (dbeta) dbeta[ch] = (float)r[0];
   if (dgamma) dgamma[ch] = (float)r[1];
   if (dalpha) dalpha[ch] = (float)r[2];
@@ -465,6 +466,18 @@ __global__ __launch_bounds__(256) void merge_bwd_other(const float* __restrict__
   }
 }
 
+static ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64_t npix, const float* gamma,
+                                       const float* invstd, float* dgamma, float* dbeta, float* dalpha, float* coef,
+                                       hipStream_t st) {
+  SSMI_REQUIRE((int64_t)rows * 3 * c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn backward: partial-sum table too large");
+#define LF(CH) hipLaunchKernelGGL((bn_bwd_final<CH>), dim3((c + CH - 1) / CH), dim3(256), 0, st, part, rows, c, npix, gamma, \
+                                  invstd, dgamma, dbeta, dalpha, coef)
+  if (rows <= 512) LF(8); else if (rows <= 1024) LF(4); else if (rows <= 2048) LF(2); else LF(1);
+#undef LF
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
 static inline int ew_blocks(int64_t total4) {
   int64_t b = ceil_div64(total4, 256 * 4);
   if (b > 4096) b = 4096;
@@ -474,6 +487,23 @@ static inline int ew_blocks(int64_t total4) {
 
 static ssmi_status check_c(int c, const char* who) {
   SSMI_REQUIRE(c > 0 && c % 4 == 0 && c <= 1024, SSMI_E_UNSUPPORTED, "%s: channel count %d must be a multiple of 4 and <= 1024", who, c);
+  return SSMI_OK;
+}
+
+ssmi_status launch_bn_bwd_tail(const float* part, int rows, const float* dy, int ld_dy, const float* x, int ld_x,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                               const float* alpha, float slope, const float* drop, int64_t hw, float* dx, float* dgamma,
+                               float* dbeta, float* dalpha, int64_t npix, int c, float* coef, hipStream_t st) {
+  ssmi_status e = launch_bn_bwd_final(part, rows, c, npix, gamma, invstd, dgamma, dbeta,
+                                      act == SSMI_ACT_PRELU ? dalpha : nullptr, coef, st);
+  if (e) return e;
+  const int c4n = c / 4;
+  const int64_t total4 = npix * c4n;
+  const int nb2 = ew_blocks(total4);
+#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, total4, c4n)
+  if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
+#undef L2
+  SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
 
@@ -576,16 +606,8 @@ ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x,
   else { set_error("bn_act_bwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L1
   SSMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 7) / 8), dim3(256), 0, st, part, nb, c, npix, gamma, invstd, dgamma, dbeta,
-                     act == SSMI_ACT_PRELU ? dalpha : nullptr, coef);
-  SSMI_LAUNCH_CHECK();
-  const int64_t total4 = npix * c4n;
-  const int nb2 = ew_blocks(total4);
-#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, total4, c4n)
-  if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
-#undef L2
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return launch_bn_bwd_tail(part, nb, dy, ld_dy, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx, dgamma,
+                            dbeta, dalpha, npix, c, coef, st);
 }
 
 static ssmi_status fill_merge(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
@@ -655,9 +677,8 @@ ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const fl
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
   SSMI_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_final, dim3((c + 7) / 8), dim3(256), 0, st, part, nb, c, npix, bn3->gamma, bn3->invstd,
-                     dgamma3, dbeta3, dalpha, coef);
-  SSMI_LAUNCH_CHECK();
+  s = launch_bn_bwd_final(part, nb, c, npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
+  if (s) return s;
   const int64_t total4 = npix * c4n;
   hipLaunchKernelGGL(merge_bwd_apply, dim3(ew_blocks(total4)), dim3(256), 0, st, dsum, main, bn3->mean, bn3->invstd, drop,
                      coef, dmain, total4, c4n, (int64_t)d->h * d->w);

@@ -45,6 +45,26 @@ ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t np
                                   int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, hipStream_t stream);
 
+// Backward of a BatchNormalization(+activation, +spatial dropout) fused into the epilogue of the data-gradient kernel that
+// produces the gradient of the BN's output: the kernel adds per-workgroup column sums of dz, dz*xhat and d*min(z,0) to
+// part[row][3][c] (x == nullptr: disabled).
+struct BnBwdArgs {
+  const float* x;          // raw input of the BN (the producing convolution's output), pixel stride ld
+  int ld;
+  const float *mean, *invstd, *gamma, *beta, *alpha;
+  float slope;
+  int act;
+  const float* drop;       // [n, c] dropout table or nullptr
+  unsigned hw;             // pixels per image
+  float* part;
+};
+
+// Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.
+ssmi_status launch_bn_bwd_tail(const float* part, int rows, const float* dy, int ld_dy, const float* x, int ld_x,
+                               const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
+                               const float* alpha, float slope, const float* drop, int64_t hw, float* dx, float* dgamma,
+                               float* dbeta, float* dalpha, int64_t npix, int c, float* coef, hipStream_t stream);
+
 // Optional per-launch timing (ssmi_profile_begin / _end): while enabled, a ProfileScope brackets ONE kernel launch with
 // HIP events on the launch stream and records the kernel name (set_last_kernel) with its algorithmic bytes and flops.
 struct ProfileScope {

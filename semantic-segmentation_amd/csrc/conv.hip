@@ -195,7 +195,9 @@ template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ add,
-                                                            const float* __restrict__ bias, float* __restrict__ dx) {
+                                                            const float* __restrict__ bias, float* __restrict__ dx,
+                                                            BnBwdArgs bb) {
+  __shared__ float bb_sm[4 * 3 * NT * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int s = g.stride;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
   if (qh <= 0 || qw <= 0) return;
   const int64_t M = (int64_t)g.n * qh * qw;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  if (tile0 >= M) return;
+  if (tile0 >= M && bb.x == nullptr) return;   // with the fused BN backward every wave reaches the barrier
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
 
@@ -344,6 +346,57 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
     for (int i = 0; i < 16; ++i) av[i] = bload(radd, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB);
 #pragma unroll
     for (int i = 0; i < 16; ++i) bstore(rdx, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv + av[i]);
+    if (bb.x) {   // uniform; stride 1: the output pixel index is the row index
+      const int cc = colv[t] ? c : 0;
+      const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
+      const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
+      const __amdgpu_buffer_rsrc_t rbx = make_rsrc(bb.x, (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4));
+      float xr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+        xr[i] = bload(rbx, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)c) * 4u : kOOB);
+      }
+      float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool ok = colv[t] && rowoff[i] != kOOB;
+        float d = acc[t][i] + bv + av[i];
+        if (bb.drop) {
+          const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+          d *= bb.drop[(ok ? po / bb.hw : 0u) * (unsigned)g.cin + (unsigned)cc];
+        }
+        const float xh = (xr[i] - mu) * is;
+        const float z = ga * xh + be;
+        const float gr = bb.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al : 0.f));
+        const float dz = ok ? d * gr : 0.f;
+        s1 += dz;
+        s2 += dz * xh;
+        s3 += ok ? d * (z < 0.f ? z : 0.f) : 0.f;
+      }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      s3 += __shfl_xor(s3, 32, 64);
+      if (hh == 0) {
+        bb_sm[(wave * 3 + 0) * (NT * 32) + t * 32 + r] = s1;
+        bb_sm[(wave * 3 + 1) * (NT * 32) + t * 32 + r] = s2;
+        bb_sm[(wave * 3 + 2) * (NT * 32) + t * 32 + r] = s3;
+      }
+    }
+  }
+  if (bb.x) {
+    __syncthreads();
+    if (threadIdx.x < NT * 32) {
+      const int c = cbase + threadIdx.x;
+      if (c < g.cin) {
+        for (int k = 0; k < 3; ++k) {
+          float sk = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < 4; ++wv) sk += bb_sm[(wv * 3 + k) * (NT * 32) + threadIdx.x];
+          bb.part[((int64_t)blockIdx.x * 3 + k) * g.cin + c] = sk;
+        }
+      }
+    }
   }
 }
 
@@ -375,7 +428,7 @@ template <bool M16, int MT, int NT, bool VEC, int D>
 __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      const float* __restrict__ add, float* __restrict__ out,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, BnBwdArgs bb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TS = M16 ? 16 : 32;
   constexpr int KQ = 64 / TS;
@@ -484,9 +537,11 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   const int cbase0 = blockIdx.y * NT * TS;
   const int kq_tap0 = (kq * EW) / a.C_r, kq_r0 = (kq * EW) % a.C_r;
 
-  float st1[NT], st2[NT];   // running column sums of the output and its square (forward with statistics only)
+  // running column sums: forward with statistics: y, y^2; data gradient with the fused BN backward: dz, dz*xhat, d*min(z,0)
+  float st1[NT], st2[NT], st3[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) st1[t] = st2[t] = 0.f;
+  for (int t = 0; t < NT; ++t) st1[t] = st2[t] = st3[t] = 0.f;
+  const __amdgpu_buffer_rsrc_t rbx = make_rsrc(bb.x ? bb.x : out, bb.x ? (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4) : 0u);
 
   for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
     const int64_t tile0 = grp * (MT * TS);
@@ -613,36 +668,71 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
             st2[t] += v * v;
           }
       }
+      if (bb.x) {   // uniform; stride-1 data gradient: the output pixel index is the row index
+        const int cc = cv ? col : 0;
+        const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
+        const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
+        float xr[MT][NR];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
+            const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
+            xr[m][i] = bload(rbx, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)col) * 4u : kOOB);
+          }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            const bool ok = cv && rowoff[m][i] != kOOB;
+            float d = acc[m][t][i] + bvv + av[m][i];
+            if (bb.drop) {
+              const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
+              const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
+              d *= bb.drop[(ok ? po / bb.hw : 0u) * (unsigned)a.C_o + (unsigned)cc];
+            }
+            const float xh = (xr[m][i] - mu) * is;
+            const float z = ga * xh + be;
+            const float gr = bb.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al : 0.f));
+            const float dz = ok ? d * gr : 0.f;
+            st1[t] += dz;
+            st2[t] += dz * xh;
+            st3[t] += ok ? d * (z < 0.f ? z : 0.f) : 0.f;
+          }
+      }
     }
   }
-  if (part) {   // uniform: combine the lane groups that share a column, then the four waves through LDS
+  if (part || bb.x) {   // uniform: combine the lane groups that share a column, then the four waves through LDS
+    const int ns = bb.x ? 3 : 2;
+    float* dst = bb.x ? bb.part : part;
     __syncthreads();             // every wave is done with the kernel matrix in LDS
-    float* red = smem;           // [4 waves][2][NT*TS]
+    float* red = smem;           // [4 waves][3][NT*TS]
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      float s1 = st1[t], s2 = st2[t];
+      float s1 = st1[t], s2 = st2[t], s3 = st3[t];
 #pragma unroll
       for (int o = TS; o < 64; o <<= 1) {
         s1 += __shfl_xor(s1, o, 64);
         s2 += __shfl_xor(s2, o, 64);
+        s3 += __shfl_xor(s3, o, 64);
       }
       if (kq == 0) {
-        red[(wave * 2 + 0) * (NT * TS) + t * TS + c] = s1;
-        red[(wave * 2 + 1) * (NT * TS) + t * TS + c] = s2;
+        red[(wave * 3 + 0) * (NT * TS) + t * TS + c] = s1;
+        red[(wave * 3 + 1) * (NT * TS) + t * TS + c] = s2;
+        red[(wave * 3 + 2) * (NT * TS) + t * TS + c] = s3;
       }
     }
     __syncthreads();
     if (tid < NT * TS) {
       const int col = cbase0 + tid;
       if (col < a.C_o) {
-        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < ns; ++k) {
+          float sk = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-          s1 += red[(wv * 2 + 0) * (NT * TS) + tid];
-          s2 += red[(wv * 2 + 1) * (NT * TS) + tid];
+          for (int wv = 0; wv < 4; ++wv) sk += red[(wv * 3 + k) * (NT * TS) + tid];
+          dst[((int64_t)blockIdx.x * ns + k) * a.C_o + col] = sk;
         }
-        part[((int64_t)blockIdx.x * 2 + 0) * a.C_o + col] = s1;
-        part[((int64_t)blockIdx.x * 2 + 1) * a.C_o + col] = s2;
       }
     }
   }
@@ -1110,7 +1200,7 @@ static ssmi_status make_sizes(const Geo& g, Sizes* sz) {
 // Picks the LDS-weight kernel when the kernel matrix fits in 64 KiB of LDS; returns false otherwise.
 static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float* in, const float* w, const float* bias,
                             const float* add, float* out, hipStream_t st, ssmi_status* status, float* part = nullptr,
-                            int* part_rows = nullptr) {
+                            int* part_rows = nullptr, BnBwdArgs bb = BnBwdArgs{}) {
   GemmArgs a;
   a.mode = mode;
   a.C_r = mode == 0 ? g.cin : g.cout;
@@ -1140,7 +1230,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   const int staged_taps = (mode == 0 || g.dil > 1) ? ntaps : ((g.kh + g.stride - 1) / g.stride) * ((g.kw + g.stride - 1) / g.stride);
   size_t lds = (size_t)(4 + 4 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
   if (lds > 64 * 1024) return false;
-  if (part && lds < (size_t)8 * nt * ts * 4) lds = (size_t)8 * nt * ts * 4;   // room for the statistics combine
+  if ((part || bb.x) && lds < (size_t)12 * nt * ts * 4) lds = (size_t)12 * nt * ts * 4;   // room for the column-sum combine
   const bool vec = (a.C_r % 4 == 0) && (a.in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   const int kb = (64 / ts) * (vec ? 4 : 1);
   a.q_blk = kb / a.C_r;
@@ -1155,7 +1245,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
 #define LG(M16_, MT_, NT_, V_, D_) \
-  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_, D_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out, part)
+  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_, D_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out, part, bb)
   if (part_rows) *part_rows = (int)bx;
   // prefetch depth: cover the whole reduction when it is short, else as deep as the register budget allows
   const int nblk = (staged_taps * a.C_r + kb - 1) / kb;
@@ -1209,13 +1299,16 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
   return SSMI_OK;
 }
 
+// bb.x != nullptr (stride 1 only): the kernel also writes the column sums of the fused BN backward to bb.part[row][3][cin];
+// *part_rows = rows.
 static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w, const float* add, const float* bias,
-                                   float* dx, hipStream_t st) {
+                                   float* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
   ProfileScope prof(st, conv_bytes(g, add != nullptr), conv_flops(g));
-  if (launch_gemm_lds(g, sz, 1, dy, w, bias, add, dx, st, &e)) return e;
+  if (launch_gemm_lds(g, sz, 1, dy, w, bias, add, dx, st, &e, nullptr, part_rows, bb)) return e;
+  if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.h * g.w, 128);
   const int s = g.stride;
   const int qh = (g.h + s - 1) / s, qw = (g.w + s - 1) / s;
   const int64_t M = (int64_t)g.n * qh * qw;
@@ -1224,7 +1317,7 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
   const bool vec = (g.cout % 8 == 0) && (g.y_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
   set_last_kernel("conv_bwd_data_kernel<%d, %s>", nt, vec ? "true" : "false");
-#define L(NT, V) hipLaunchKernelGGL((conv_bwd_data_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx)
+#define L(NT, V) hipLaunchKernelGGL((conv_bwd_data_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx, bb)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
   } else {
@@ -1396,6 +1489,52 @@ ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const
   if (s) return s;
   SSMI_REQUIRE(dy && w && dx, SSMI_E_INVALID_ARG, "conv2d_bwd_data: NULL tensor");
   return launch_bwd_data(to_geo(d), dy, w, add, nullptr, dx, as_stream(stream));
+}
+
+size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d) {
+  if (check_desc(d) != SSMI_OK) return 0;
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const size_t fused = (size_t)((ceil_div64(npix, 128) + 1024) * 3 + 3) * d->cin * sizeof(float);
+  const size_t plain = ssmi_bn_workspace_bytes(npix, d->cin);
+  return fused > plain ? fused : plain;
+}
+
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add,
+                                        float* da, const float* bn_x, int32_t ld_x, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                        const float* alpha, float slope, const float* drop, int64_t hw, float* dx_bn,
+                                        float* dgamma, float* dbeta, float* dalpha, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(dy && w && da && bn_x && mean && invstd && gamma && beta && dx_bn, SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd: NULL tensor");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_bwd_data_bn_bwd: workspace too small");
+  SSMI_REQUIRE(act >= SSMI_ACT_NONE && act <= SSMI_ACT_LEAKY && (act != SSMI_ACT_PRELU || alpha), SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd: bad activation");
+  const Geo g = to_geo(d);
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const int c = d->cin;
+  hipStream_t st = as_stream(stream);
+  static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;   // A/B switch for measurements
+  if (no_fuse || d->stride != 1 || c % 4 != 0 || c > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < c ||
+      npix * ld_x * 4 >= 0x7FFFFFFFLL || (drop && (hw <= 0 || npix % hw != 0))) {
+    s = launch_bwd_data(g, dy, w, add, nullptr, da, st);          // unfused: the two passes of the plain entry points
+    if (s) return s;
+    return ssmi_bn_act_drop_bwd(da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn, dgamma,
+                                dbeta, dalpha, npix, c, ws, ws_bytes, stream);
+  }
+  float* part = reinterpret_cast<float*>(ws);
+  BnBwdArgs bb;
+  bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
+  bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
+  int rows = 0;
+  s = launch_bwd_data(g, dy, w, add, nullptr, da, st, bb, &rows);
+  if (s) return s;
+  float* coef = part + (size_t)rows * 3 * c;
+  return launch_bn_bwd_tail(part, rows, da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn,
+                            dgamma, dbeta, dalpha, npix, c, coef, st);
 }
 
 size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d) {

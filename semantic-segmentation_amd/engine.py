@@ -150,7 +150,8 @@ class Conv:
             out_hw = (ho, wo)
             d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l = self.kh, self.kw, self.stride, self.dil, pt, pl
             self.ws_bytes = max(L.conv2d_bwd_weight_workspace_bytes(C.byref(d)),
-                                L.conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)))
+                                L.conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)),
+                                L.conv2d_bwd_data_bn_bwd_workspace_bytes(C.byref(d)))
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
             H, W = h * self.stride, w * self.stride
@@ -197,6 +198,23 @@ class Conv:
             L.conv2d_transpose_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(dx), st)
         else:
             L.conv2d_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), st)
+
+    def bwd_data_bn(self, dy, da, bn: "BatchNorm", bn_x, ld_x, dx_bn, npix, ws, st, act=None, slope=0.0, drop=None, hw=1):
+        """Data gradient `da` (gradient of the output of `bn` + activation, which is this convolution's input) followed by
+        the backward of that BatchNormalization: dx_bn = gradient of bn's raw input bn_x (may alias da), parameter
+        gradients into the arena.  One fused call for stride-1 convolutions (column sums in the kernel epilogue)."""
+        if act is None:
+            act = ACT_PRELU if bn.alpha is not None else ACT_NONE
+        if self.transpose:
+            self.bwd_data(dy, da, st)
+            lib().bn_act_drop_bwd(_ptr(da), self.cin, _ptr(bn_x), ld_x, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma),
+                                  _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(drop), hw, _ptr(dx_bn), _ptr(bn.dgamma),
+                                  _ptr(bn.dbeta), _ptr(bn.dalpha), npix, self.cin, _ptr(ws), ws.numel() * 4, st)
+            return
+        lib().conv2d_bwd_data_bn_bwd(self._dref, _ptr(dy), _ptr(self.w), None, _ptr(da), _ptr(bn_x), ld_x, _ptr(bn.mean),
+                                     _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(drop),
+                                     hw, _ptr(dx_bn), _ptr(bn.dgamma), _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(ws),
+                                     ws.numel() * 4, st)
 
     def bwd_weight(self, x, dy, ws, st):
         L = lib()
@@ -557,22 +575,21 @@ class Bottleneck(Block):
                     _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
         # conv3
         cfg.wgrad(self.conv3, self.a2, self.dy3)
-        self.conv3.bwd_data(self.dy3, self.da2, st)
-        self.bn2.act_bwd(self.da2, self.y2, i, self.da2, self.np_out, ws, st)      # da2 -> dy2 (in place)
+        self.conv3.bwd_data_bn(self.dy3, self.da2, self.bn2, self.y2, i, self.da2, self.np_out, ws, st)   # da2 -> dy2 (in place)
         # conv2
         if self.conv2a is not None:
             cfg.wgrad(self.conv2, self.t, self.da2)
             self.conv2.bwd_data(self.da2, self.dt, st)
             cfg.wgrad(self.conv2a, self.a1, self.dt)
-            self.conv2a.bwd_data(self.dt, self.da1, st)
+            self.conv2a.bwd_data_bn(self.dt, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)
         elif self.nn_resize:
             cfg.wgrad(self.conv2, self.a1u, self.da2)
             self.conv2.bwd_data(self.da2, self.da1u, st)
             L.upsample_nn2x_bwd(_ptr(self.da1u), i, self.n, self.h1, self.w1, i, _ptr(self.da1), st)
+            self.bn1.act_bwd(self.da1, self.y1, i, self.da1, self.np1, ws, st)     # da1 -> dy1 (in place)
         else:
             cfg.wgrad(self.conv2, self.a1, self.da2)
-            self.conv2.bwd_data(self.da2, self.da1, st)
-        self.bn1.act_bwd(self.da1, self.y1, i, self.da1, self.np1, ws, st)         # da1 -> dy1 (in place)
+            self.conv2.bwd_data_bn(self.da2, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)   # da1 -> dy1
         # conv1 + skip branch
         cfg.wgrad(self.conv1, self.x, self.da1)
         if self.mode == 0:

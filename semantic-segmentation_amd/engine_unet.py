@@ -56,8 +56,9 @@ class ConvUnit:
                           cfg.st)
         return self.out
 
-    def bwd(self, dout_ptr, dout_ld, cfg: RunCfg):
-        """dout: gradient w.r.t. `out` (raw pointer + pixel stride, it may be a channel slice).  Returns dx."""
+    def bn_bwd(self, dout_ptr, dout_ld, cfg: RunCfg):
+        """dout: gradient w.r.t. `out` (raw pointer + pixel stride, it may be a channel slice) -> self.dy (gradient of
+        the raw convolution output) and the BN parameter gradients."""
         L = lib()
         bn = self.bn
         drop = self.drop_mask if cfg.use_dropout else None
@@ -65,7 +66,18 @@ class ConvUnit:
                           _ptr(bn.beta), self.act, None, LEAKY_ALPHA, _ptr(drop), self.h * self.w, _ptr(self.dy),
                           _ptr(bn.dgamma), _ptr(bn.dbeta), None, self.npix, self.cout, _ptr(cfg.ws), cfg.ws.numel() * 4,
                           cfg.st)
+
+    def conv_bwd(self, cfg: RunCfg, producer: "Optional[ConvUnit]" = None):
+        """Weight gradient and data gradient of the convolution from self.dy.  With `producer` (the unit whose output is
+        this unit's input) the data gradient and the producer's BN backward run as one fused call and land in
+        producer.dy; returns dx otherwise (None when the input needs no gradient)."""
         cfg.wgrad(self.conv, self.x, self.dy)
+        if producer is not None:
+            p = producer
+            drop = p.drop_mask if cfg.use_dropout else None
+            self.conv.bwd_data_bn(self.dy, self.dx, p.bn, p.y, p.cout, p.dy, p.npix, cfg.ws, cfg.st, act=p.act,
+                                  slope=LEAKY_ALPHA, drop=drop, hw=p.h * p.w)
+            return None
         if self.needs_dx:
             self.conv.bwd_data(self.dy, self.dx, cfg.st)
         return self.dx
@@ -92,13 +104,11 @@ class UnitBlock(Block):
         return x
 
     def _bwd_units(self, d: torch.Tensor, cfg):
-        ptr, ld = _ptr(d), self.units[-1].cout
-        for u in reversed(self.units):
-            dx = u.bwd(ptr, ld, cfg)
-            if dx is None:
-                return None
-            ptr, ld = _ptr(dx), u.cin
-        return dx
+        us = self.units
+        us[-1].bn_bwd(_ptr(d), us[-1].cout, cfg)
+        for k in range(len(us) - 1, 0, -1):
+            us[k].conv_bwd(cfg, producer=us[k - 1])      # also produces us[k-1].dy
+        return us[0].conv_bwd(cfg)
 
 
 class EncoderBlock(UnitBlock):

@@ -521,3 +521,68 @@ def test_conv2d_fwd_with_fused_bn_statistics(case):
     _check(invstd, 1.0 / np.sqrt(rv + 1e-3), "invstd", rtol=1e-4, atol_rel=1e-5)
     _check(mm, 0.1 * 0.25 + 0.9 * rm, "moving mean", rtol=1e-4, atol_rel=1e-5)
     _check(mv, 0.1 * 2.0 + 0.9 * rv, "moving variance", rtol=1e-4, atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("case", [
+    # kh kw cin cout dil  N  H  W  act drop
+    (1, 1, 16, 64, 1, 2, 9, 7, 1, False),      # conv3 of a bottleneck: 16x16 tiles, ragged pixels
+    (3, 3, 16, 16, 1, 2, 10, 12, 1, False),
+    (3, 3, 32, 32, 2, 1, 9, 9, 1, False),      # direct kernel, dilated
+    (1, 5, 32, 32, 1, 1, 6, 11, 1, False),
+    (1, 1, 32, 128, 1, 1, 8, 8, 0, False),
+    (3, 3, 64, 40, 1, 2, 8, 8, 2, True),       # U-Net style: LeakyReLU + dropout table, 64 input channels
+    (3, 3, 8, 24, 1, 3, 5, 6, 2, True),
+    (1, 1, 4, 16, 1, 1, 16, 16, 1, False),
+], ids=lambda c: "k{}x{}_{}to{}_d{}_act{}".format(c[0], c[1], c[2], c[3], c[4], c[8]))
+def test_conv2d_bwd_data_with_fused_bn_backward(case):
+    """ssmi_conv2d_bwd_data_bn_bwd == ssmi_conv2d_bwd_data followed by ssmi_bn_act_drop_bwd (checked against the oracle:
+    autograd through BN(train) -> activation -> dropout -> convolution)."""
+    kh, kw, cin, cout, dil, N, H, W, act, use_drop = case
+    eng = pkg("engine")
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(kh * 10 + cin + cout + act)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "c", kh, kw, cin, cout, dil=dil, padding="same", bias=False)
+    bn = eng.BatchNorm(store, "bn", cin)
+    if act == 1:
+        bn.add_prelu(store, "pr")
+    store.materialise(DEV)
+    cv.plan(N, H, W)
+    bn.plan(DEV)
+    w = rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)
+    xraw = rng.standard_normal((N, H, W, cin)) * 1.5 + 0.2
+    gam, bet = rng.uniform(0.5, 1.5, cin), rng.standard_normal(cin) * 0.3
+    alpha = rng.uniform(0.05, 0.3, cin)
+    dy = rng.standard_normal((N, H, W, cout))
+    drop = ((rng.uniform(size=(N, cin)) > 0.25) / 0.75) if use_drop else None
+    # oracle
+    xt = torch.tensor(xraw, requires_grad=True)
+    gt, bt = torch.tensor(gam, requires_grad=True), torch.tensor(bet, requires_grad=True)
+    at = torch.tensor(alpha, requires_grad=True)
+    yb, mean, var = K.batch_norm_train(xt, gt, bt)
+    a = K.prelu(yb, at) if act == 1 else (K.leaky_relu(yb, 0.1) if act == 2 else yb)
+    if use_drop:
+        a = K.spatial_dropout(a, torch.tensor(drop))
+    a.retain_grad()
+    out = K.conv2d(a, torch.tensor(w), None, 1, dil, "same")
+    out.backward(torch.tensor(dy))
+    # device
+    store.views["c/kernel"].copy_(_t(w))
+    bn.gamma.copy_(_t(gam)); bn.beta.copy_(_t(bet))
+    if act == 1:
+        bn.alpha.copy_(_t(alpha.reshape(1, 1, cin)))
+    bn.mean.copy_(_t(mean.detach().numpy()))
+    bn.invstd.copy_(_t(1.0 / np.sqrt(var.detach().numpy() + 1e-3)))
+    xd, dyd = _t(xraw), _t(dy)
+    dropd = _t(drop) if use_drop else None
+    da = torch.empty(N, H, W, cin, device=DEV)
+    dxbn = torch.empty_like(da)
+    ws = torch.empty(max(cv.ws_bytes, L.bn_workspace_bytes(N * H * W, cin)) // 4 + 16, device=DEV)
+    cv.bwd_data_bn(dyd, da, bn, xd, cin, dxbn, N * H * W, ws, torch.cuda.current_stream().cuda_stream,
+                   act=act, slope=0.1, drop=dropd, hw=H * W)
+    _check(da, a.grad, "da")
+    _check(dxbn, xt.grad, "dx_bn")
+    _check(bn.dgamma, gt.grad, "dgamma")
+    _check(bn.dbeta, bt.grad, "dbeta")
+    if act == 1:
+        _check(bn.dalpha.reshape(-1), at.grad, "dalpha")
