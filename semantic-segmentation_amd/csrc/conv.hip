@@ -1328,6 +1328,155 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
   return SSMI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of WIDE layers (cout a multiple of 64, K = taps*cin >= 256: the U-Net / SegNet convolutions) as a
+// tiled GEMM: a workgroup owns a (WK*64) x (WC*64) tile of dW and one share of the pixels; per chunk of 32 pixels it
+// stages the im2col slab A[32][WK*64] (for each k-row (tap, ci): x at the tap-shifted pixel) and the dy slab
+// B[32][WC*64] in LDS (16-byte buffer loads into registers one chunk ahead, then one LDS store), and each wave
+// multiplies its 64x64 sub-tile (2x2 MFMA tiles, K = pixels).  Each operand byte is staged once per tile instead of
+// once per 12 tiles.  The bias gradient (column sums of dy) is accumulated by the waves of the first k-tile.
+// Partial sums per pixel share: part[share][K_aug][cout], reduced by conv_bwd_weight_reduce.
+// ---------------------------------------------------------------------------------------------------
+template <int WK, int WC>
+__global__ __launch_bounds__(256) void conv_bwd_weight_tiled(Geo g, Sizes sz, int K, int K_aug, int chunks_per_share,
+                                                             const float* __restrict__ x, const float* __restrict__ dy,
+                                                             float* __restrict__ part) {
+  static_assert(WK * WC == 4, "four waves per workgroup");
+  constexpr int TK = WK * 64, TC = WC * 64, P = 32;
+  constexpr int KA4 = TK / 4, PA = 256 / KA4, NA = P / PA;     // A staging: thread -> (k group, pixel slots)
+  constexpr int KB4 = TC / 4, PB = 256 / KB4, NB = P / PB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;
+  float* Bs = smem + P * TK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int wk = wave % WK, wc = wave / WK;
+  const int k0 = blockIdx.x * TK, c0 = blockIdx.y * TC;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), ry = make_rsrc(dy, sz.y_bytes);
+  const unsigned M = (unsigned)(g.n * g.ho * g.wo);
+  const int nchunks = (int)((M + P - 1) / P);
+  const int ch0 = blockIdx.z * chunks_per_share;
+  const int ch1 = min(nchunks, ch0 + chunks_per_share);
+
+  // this thread's k group (4 consecutive k-rows inside one tap: cin % 4 == 0) and dy column group
+  const int ka = tid % KA4, pa0 = tid / KA4;
+  const int kk = k0 + ka * 4;
+  const bool kvalid = kk < K;
+  const int tap = kvalid ? kk / g.cin : 0;
+  const int ci = kvalid ? kk - tap * g.cin : 0;
+  const int ky = tap / g.kw, kx = tap - ky * g.kw;
+  const int offy = ky * g.dil - g.pad_t, offx = kx * g.dil - g.pad_l;
+  const int cb = tid % KB4, pb0 = tid / KB4;
+  const int co = c0 + cb * 4;
+  const bool covalid = co < g.cout;
+
+  f32x4 ra[NA], rb[NB];
+  auto prefetch = [&](int ch) {
+    const bool cv = ch < ch1;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned pix = (unsigned)ch * P + (unsigned)(pa0 + j * PA);
+      const bool pv = cv && kvalid && pix < M;
+      const unsigned pp = pv ? pix : 0u;
+      const unsigned t1 = pp / (unsigned)g.wo;
+      const int ox = (int)(pp - t1 * (unsigned)g.wo);
+      const unsigned n_ = t1 / (unsigned)g.ho;
+      const int oy = (int)(t1 - n_ * (unsigned)g.ho);
+      const int iy = oy * g.stride + offy, ix = ox * g.stride + offx;
+      const bool ok = pv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+      ra[j] = bload4(rx, ok ? (((n_ * (unsigned)g.h + (unsigned)iy) * (unsigned)g.w + (unsigned)ix) * (unsigned)g.x_ld + (unsigned)ci) * 4u : kOOB);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const unsigned pix = (unsigned)ch * P + (unsigned)(pb0 + j * PB);
+      rb[j] = bload4(ry, (cv && covalid && pix < M) ? (pix * (unsigned)g.y_ld + (unsigned)co) * 4u : kOOB);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a_][b_][i] = 0.f;
+  float bsum0 = 0.f, bsum1 = 0.f;
+  const bool do_bias = (K_aug > K) && blockIdx.x == 0 && wk == 0;
+
+  prefetch(ch0);
+  for (int ch = ch0; ch < ch1; ++ch) {
+    __syncthreads();            // everyone is done reading the previous chunk
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(As + (pa0 + j * PA) * TK + ka * 4) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<f32x4*>(Bs + (pb0 + j * PB) * TC + cb * 4) = rb[j];
+    __syncthreads();
+    prefetch(ch + 1);           // in flight while this chunk is multiplied
+    const float* ap = As + hh * TK + wk * 64 + r;
+    const float* bp = Bs + hh * TC + wc * 64 + r;
+#pragma unroll 4
+    for (int st = 0; st < P / 2; ++st) {
+      const float a0 = ap[st * 2 * TK], a1 = ap[st * 2 * TK + 32];
+      const float b0 = bp[st * 2 * TC], b1 = bp[st * 2 * TC + 32];
+      acc[0][0] = MFMA32(a0, b0, acc[0][0]);
+      acc[0][1] = MFMA32(a0, b1, acc[0][1]);
+      acc[1][0] = MFMA32(a1, b0, acc[1][0]);
+      acc[1][1] = MFMA32(a1, b1, acc[1][1]);
+      if (do_bias) { bsum0 += b0; bsum1 += b1; }
+    }
+  }
+
+  float* pbase = part + (int64_t)blockIdx.z * K_aug * g.cout;
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_) {
+      const int col = c0 + wc * 64 + b_ * 32 + r;
+      if (col >= g.cout) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + wk * 64 + a_ * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (k < K) pbase[(int64_t)k * g.cout + col] = acc[a_][b_][i];
+      }
+    }
+  if (do_bias) {
+    bsum0 += __shfl_xor(bsum0, 32, 64);
+    bsum1 += __shfl_xor(bsum1, 32, 64);
+    if (hh == 0) {
+      const int col = c0 + wc * 64 + r;
+      if (col < g.cout) pbase[(int64_t)K * g.cout + col] = bsum0;
+      if (col + 32 < g.cout) pbase[(int64_t)K * g.cout + col + 32] = bsum1;
+    }
+  }
+}
+
+struct TiledPlan {
+  bool use;
+  int wk, K, K_aug, shares, chunks_per_share, ktiles, ctiles;
+  size_t bytes;
+};
+
+static TiledPlan plan_tiled(const Geo& g, bool with_bias) {
+  TiledPlan t;
+  t.K = g.kh * g.kw * g.cin;
+  t.K_aug = t.K + (with_bias ? 1 : 0);
+  t.use = (g.cin % 4 == 0) && (g.cout % 64 == 0) && t.K >= 256 && (g.x_ld % 4 == 0) && (g.y_ld % 4 == 0);
+  t.wk = (g.cout % 128 == 0) ? 2 : 4;
+  if (!t.use) { t.bytes = 0; return t; }
+  const int TK = t.wk * 64, TC = (4 / t.wk) * 64;
+  t.ktiles = (t.K + TK - 1) / TK;
+  t.ctiles = g.cout / TC;
+  const int64_t M = (int64_t)g.n * g.ho * g.wo;
+  const int nchunks = (int)ceil_div64(M, 32);
+  int shares = 1024 / (t.ktiles * t.ctiles);          // about four workgroups per CU in total
+  if (shares > nchunks / 8) shares = nchunks / 8;       // at least 8 chunks per workgroup (amortises the pipeline fill)
+  if (shares < 1) shares = 1;
+  t.chunks_per_share = (nchunks + shares - 1) / shares;
+  t.shares = (nchunks + t.chunks_per_share - 1) / t.chunks_per_share;
+  t.bytes = (size_t)t.shares * t.K_aug * g.cout * sizeof(float);
+  return t;
+}
+
 struct WgPlan {
   WgArgs a;
   WgLds l;
@@ -1400,8 +1549,10 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
 }
 
 static size_t wg_ws_bytes(const Geo& g) {
+  const TiledPlan t = plan_tiled(g, true);
   const size_t b0 = plan_wg(g, false).bytes, b1 = plan_wg(g, true).bytes;
-  return b0 > b1 ? b0 : b1;
+  const size_t b = b0 > b1 ? b0 : b1;
+  return t.use && t.bytes > b ? t.bytes : b;      // the strip kernels remain the fallback for unaligned pointers
 }
 
 static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
@@ -1409,6 +1560,26 @@ static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* 
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  const TiledPlan t = plan_tiled(g, dbias != nullptr);
+  if (t.use && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+    SSMI_REQUIRE(ws != nullptr && ws_bytes >= t.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
+                 ws_bytes, t.bytes);
+    SSMI_REQUIRE(t.bytes < 0x7FFFFFFFULL, SSMI_E_UNSUPPORTED, "conv2d_bwd_weight: partial sums of 2 GiB or more");
+    float* part = reinterpret_cast<float*>(ws);
+    dim3 grid((unsigned)t.ktiles, (unsigned)t.ctiles, (unsigned)t.shares);
+    if (t.wk == 2)
+      hipLaunchKernelGGL((conv_bwd_weight_tiled<2, 2>), grid, dim3(256), (size_t)32 * 256 * 4, st, g, sz, t.K, t.K_aug,
+                         t.chunks_per_share, x, dy, part);
+    else
+      hipLaunchKernelGGL((conv_bwd_weight_tiled<4, 1>), grid, dim3(256), (size_t)32 * 320 * 4, st, g, sz, t.K, t.K_aug,
+                         t.chunks_per_share, x, dy, part);
+    SSMI_LAUNCH_CHECK();
+    const int E = t.K_aug * g.cout;
+    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 15) / 16), dim3(256), 0, st, part, t.shares, t.K, t.K_aug, g.cout,
+                       dw, dbias);
+    SSMI_LAUNCH_CHECK();
+    return SSMI_OK;
+  }
   WgPlan p = plan_wg(g, dbias != nullptr);
   SSMI_REQUIRE(ws != nullptr && ws_bytes >= p.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
                ws_bytes, p.bytes);

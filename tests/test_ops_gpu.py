@@ -48,6 +48,11 @@ CONV_CASES = [
     (1, 1, 64, 4, 1, 1, "valid", False, 1, 8, 8),
     (3, 3, 5, 7, 2, 1, "same", True, 1, 7, 9),         # odd everything
     (3, 3, 24, 24, 1, 1, "same", True, 1, 8, 8),       # enhanced head width
+    (3, 3, 64, 64, 1, 1, "same", True, 2, 9, 11),      # wide layers: tiled weight gradient (256 x 64 tiles), ragged pixels
+    (3, 3, 32, 128, 1, 1, "same", False, 1, 8, 8),     # 128 x 128 tiles, K = 288 (three k-tiles, the last one partial)
+    (1, 1, 256, 64, 1, 1, "valid", True, 1, 7, 9),
+    (3, 3, 48, 192, 1, 2, "same", True, 1, 10, 6),     # cout = 3 x 64, dilated taps
+    (3, 3, 136, 128, 1, 1, "same", True, 3, 5, 7),     # k-tile spanning two taps (cin not a multiple of the tile)
 ]
 
 
