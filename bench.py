@@ -85,7 +85,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: inference-phase forward + loss + confusion matrix (e.g. --size 1024 --batch 10), the matrices "
                          "of all ranks summed at the end")
-    ap.add_argument("--overlap-wgrad", action="store_true", help="weight gradients on a second stream (one fork per block)")
+    ap.add_argument("--no-overlap-wgrad", action="store_true", help="keep the weight gradients on the main stream")
     ap.add_argument("--eager", action="store_true", help="launch kernels directly instead of replaying HIP graphs")
     args = ap.parse_args()
 
@@ -115,8 +115,8 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     if args.eager:
         model.use_hip_graph = False
-    if args.overlap_wgrad:
-        model.graph.overlap_weight_gradients = True
+    if args.no_overlap_wgrad:
+        model.graph.overlap_weight_gradients = False
     with torch.cuda.stream(stream):
         model.set_batch([images, labels, weights, nu])
         step = model.train_step_async if args.mode == "train" else model.eval_step_async
@@ -195,6 +195,7 @@ def measure_roofline(model, stream, steps=3):
     import ctypes as C
     L = pkg("_lib").lib()
     model.use_hip_graph = False
+    saved_sync, model.grad_sync = model.grad_sync, None     # rank 0 measures alone: no collectives in these steps
     with torch.cuda.stream(stream):
         model.train_step_async()
         stream.synchronize()
@@ -205,6 +206,7 @@ def measure_roofline(model, stream, steps=3):
         cnt = C.c_int32()
         L.profile_end(C.byref(cnt))
     model.use_hip_graph = True
+    model.grad_sync = saved_sync
     records = []
     name = C.create_string_buffer(128)
     ms, by, fl = C.c_float(), C.c_double(), C.c_double()

@@ -733,9 +733,10 @@ class GraphBase:
         self.store.materialise(self.device)
         self.shape = None
         self.side_stream = None
-        # Forking the weight gradients onto a second stream was measured at 14.5 ms/step against 14.0 ms/step without
-        # (ENet 512x512, batch 16, graph replay): the HIP graph does not gain from the parallel branch, so it is off.
-        self.overlap_weight_gradients = False
+        # Weight gradients never feed the rest of the backward pass: they are collected per block and launched on a second
+        # stream, so that under graph capture they form a parallel branch that fills the machine while the latency-bound
+        # main chain runs (ENet 512x512, batch 16, same box: 11.79 -> 11.46 ms/step).  Must be set before the first plan().
+        self.overlap_weight_gradients = True
         self.drop_layers = [d for b in blocks for d in b.dropouts()]
 
     # -- planning -------------------------------------------------------------------------------------
