@@ -31,6 +31,8 @@ SHAPES = [
     ("3x3 4->4 @256", 3, 3, 4, 4, 1, 1, "same", True, False, 256),
     ("logits t2x2s2 16->24", 2, 2, 16, 24, 2, 1, "same", True, True, 256),
 ]
+if os.environ.get("SSMI_SHAPES"):      # comma-separated indices into SHAPES
+    SHAPES = [SHAPES[int(i)] for i in os.environ["SSMI_SHAPES"].split(",")]
 dev = torch.device("cuda")
 stream = torch.cuda.Stream()
 print("%-26s %10s %10s %10s   %8s %8s %8s   GB/s(fwd) TF(fwd) TF(wg)" % ("layer", "fwd us", "bwdD us", "bwdW us", "MB in", "MB out", "GFLOP"))

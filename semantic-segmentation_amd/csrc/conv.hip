@@ -2,6 +2,10 @@
 // from NHWC global memory.  One wave owns a 32-row x (NT*32)-column accumulator tile:
 //   forward / data-gradient : rows = 32 consecutive pixels, columns = output channels, K = taps x channels
 //   weight-gradient         : rows = 32 consecutive (tap,cin) kernel rows, columns = cout, K = pixels
+// Kernel families: conv_fwd_kernel / conv_bwd_data_kernel (operands straight from global memory, register double
+// buffered), conv_gemm_lds (kernel matrix in LDS, 16x16x4 tiles for narrow outputs), conv_bwd_weight_lds / _kernel
+// (strip kernels for narrow layers), conv_bwd_weight_tiled (tiled GEMM for wide layers).  Epilogues optionally emit
+// the column sums BatchNormalization needs (forward statistics / backward reductions).
 // MFMA operand map (32x32x2, wave64): lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
 // accumulator register i of lane l is C[row = (i&3) + 8*(i>>2) + 4*(l>>5)][col = l&31].
 #include "common.h"
@@ -60,11 +64,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
 
   bool colv[NT];
   unsigned wcol[NT];   // byte offset of the lane's column inside a kernel row, or kOOB
+  unsigned wcolr[NT], wcolm[NT];   // the same split into raw offset and out-of-range mask (bit 31)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int c = cbase + t * 32 + r;
     colv[t] = c < g.cout;
     wcol[t] = colv[t] ? (unsigned)c * 4u : kOOB;
+    wcolr[t] = colv[t] ? (unsigned)c * 4u : 0u;
+    wcolm[t] = colv[t] ? 0u : kOOB;
   }
   const unsigned wrow = (unsigned)g.cout * 4u;   // bytes per (tap, ci) kernel row
 
@@ -82,13 +89,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
     };
     settap();
     auto fetch = [&](f32x4& a, float (&b)[4][NT]) {
-      const int ci = c0 + 4 * hh;
-      a = bload4(rx, xo == kOOB ? kOOB : xo + (unsigned)ci * 4u);
+      // valid offsets are below 2^31, so OR-ing bit 31 in (kOOB) is the out-of-range mask: no compare/select per load
+      const unsigned cib = (unsigned)(c0 + 4 * hh);
+      a = bload4(rx, (xo + cib * 4u) | (xo & kOOB));
+      const unsigned wb = wtap + cib * wrow, wm = wtap & kOOB;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
-          b[j][t] = bload(rw, (wtap == kOOB || wcol[t] == kOOB) ? kOOB : wtap + (unsigned)(ci + j) * wrow + wcol[t]);
+        for (int t = 0; t < NT; ++t) b[j][t] = bload(rw, (wb + (unsigned)j * wrow + wcolr[t]) | wm | wcolm[t]);
       c0 += 8;
       if (c0 >= g.cin) {
         c0 = 0;
@@ -229,11 +237,14 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
   bool colv[NT];
   unsigned wci[NT];   // byte offset of kernel row (ci = lane's column) inside a tap, or kOOB
   const unsigned wrow = (unsigned)g.cout * 4u;
+  unsigned wcir[NT], wcim[NT];   // wci split into raw offset and out-of-range mask (bit 31)
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int c = cbase + t * 32 + r;   // input channel ci of the forward conv
     colv[t] = c < g.cin;
     wci[t] = colv[t] ? (unsigned)c * wrow : kOOB;
+    wcir[t] = colv[t] ? (unsigned)c * wrow : 0u;
+    wcim[t] = colv[t] ? 0u : kOOB;
   }
 
   if (VEC) {
@@ -265,9 +276,10 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
     }
     auto fetch = [&](f32x4& a, f32x4 (&b)[NT]) {
       const unsigned co4 = (unsigned)(c0 + 4 * hh) * 4u;
-      a = bload4(ry, yo == kOOB ? kOOB : yo + co4);
+      a = bload4(ry, (yo + co4) | (yo & kOOB));     // bit 31 of an invalid base is carried over: out of range
+      const unsigned wb = wtap + co4, wm = wtap & kOOB;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) b[t] = bload4(rw, (wtap == kOOB || wci[t] == kOOB) ? kOOB : wtap + wci[t] + co4);
+      for (int t = 0; t < NT; ++t) b[t] = bload4(rw, (wb + wcir[t]) | wm | wcim[t]);
       c0 += 8;
       if (c0 >= g.cout) {
         c0 = 0;
@@ -501,20 +513,28 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         }
       }
     } else {
+      // element e = (vi * cin + ci) * cout + co walks e = tid, tid + 256, ...; (vi, ci, co) advance incrementally (no
+      // division per element); eight loads per round are in flight, across tap boundaries
       const int total = nv * per_tap;
+      const int dvi = 256 / per_tap, drem = 256 - dvi * per_tap;
+      const int dci = drem / g.cout, dco = drem - dci * g.cout;
+      int vi = tid / per_tap;
+      const int q0 = tid - vi * per_tap;
+      int ci = q0 / g.cout, co = q0 - ci * g.cout;
       for (int e0 = tid; e0 < total; e0 += 256 * 8) {
         float v[8];
         int di[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int e = e0 + u * 256;
-          const bool ok = e < total;
-          const int es = ok ? e : 0;
-          const int vi = es / per_tap, q = es - vi * per_tap;
-          const int ci = q / g.cout, co = q - ci * g.cout;
-          const int srct = tab[4 + 3 * kMaxTaps + vi];
-          v[u] = bload(rwt, ok ? (unsigned)(srct * per_tap + q) * 4u : kOOB);
+          const bool ok = e0 + u * 256 < total;
+          const int srct = tab[4 + 3 * kMaxTaps + (ok ? vi : 0)];
+          v[u] = bload(rwt, ok ? (unsigned)(srct * per_tap + ci * g.cout + co) * 4u : kOOB);
           di[u] = ok ? vi * a.C_r * a.WS + (bwd ? co * a.WS + ci : ci * a.WS + co) : -1;
+          co += dco;
+          if (co >= g.cout) { co -= g.cout; ++ci; }
+          ci += dci;
+          if (ci >= g.cin) { ci -= g.cin; ++vi; }
+          vi += dvi;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u)

@@ -279,9 +279,10 @@ class RunCfg:
     """Per-call switches threaded through the blocks.
 
     Weight gradients never feed the rest of the backward pass, so they run on a second HIP stream (`side`) with their
-    own workspace: `wgrad()` forks after the kernel that produced dy, `join()` makes the main stream wait for the side
-    stream.  Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the
-    latency-bound main chain (small BN / merge kernels) is running."""
+    own workspace: `wgrad()` collects them, `flush()` (called after every block) launches the collected ones on the side
+    stream behind what the main stream has queued so far, `join()` makes the main stream wait for the side stream.
+    Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the latency-bound
+    main chain (small BN / merge kernels) is running.  Without a side stream wgrad() launches in place."""
     __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws", "main", "side", "ws2",
                  "_forked", "_pending")
 
