@@ -433,10 +433,15 @@ struct GemmArgs {
   int WS;                        // LDS row stride in words
   int q_blk, r_blk, q0_div;      // k-block advance: taps / channels per block (KB / C_r, KB % C_r)
   int ngroups_max;
+  // TILE variant: a workgroup owns 8 x 32 output pixels and stages their input halo patch [PH][PW][CP] in LDS
+  int tiles_x, tiles_y;          // tiles per image
+  int pmin_y, pmin_x;            // smallest tap offset (patch origin relative to the tile origin)
+  int PH, PW, CP;                // patch rows, columns, words per pixel (C_r + 4 pad)
+  int patch_off;                 // word offset of the patch inside the dynamic LDS block
 };
 static constexpr int kMaxTaps = 32;
 
-template <bool M16, int MT, int NT, bool VEC, int D>
+template <bool M16, int MT, int NT, bool VEC, int D, bool TILE>
 __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const float* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
                                                      const float* __restrict__ add, float* __restrict__ out,
@@ -460,27 +465,34 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   const int ntaps = g.kh * g.kw;
 
   // ---- tap table + kernel matrix into LDS ----
-  if (tid == 0) {
-    int n = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      const int ky = t / g.kw, kx = t % g.kw;
-      int dyo, dxo;
+  // Lane t of the first wave classifies tap t; a ballot compacts the valid taps in order (a serial loop over the taps
+  // in one thread costs ~150 dependent instructions per tap in front of the first barrier).
+  if (tid < 64) {
+    const int t = tid;
+    bool valid = false;
+    int dyo = 0, dxo = 0;
+    if (t < ntaps) {
+      const int ky = t / g.kw, kx = t - ky * g.kw;
       if (!bwd) {
         dyo = ky * g.dil - g.pad_t;
         dxo = kx * g.dil - g.pad_l;
+        valid = true;
       } else {
         const int ty = pa + g.pad_t - ky * g.dil, tx = pb + g.pad_l - kx * g.dil;
-        if ((((ty % s) + s) % s) != 0 || (((tx % s) + s) % s) != 0) continue;
+        valid = (((ty % s) + s) % s) == 0 && (((tx % s) + s) % s) == 0;
         dyo = (ty >= 0 ? ty / s : -((-ty) / s));   // exact: ty is a multiple of s
         dxo = (tx >= 0 ? tx / s : -((-tx) / s));
       }
+    }
+    const unsigned long long mask = __ballot(valid);
+    const int n = __popcll(mask & ((1ull << t) - 1ull));
+    if (valid) {
       tab[1 + 3 * n] = dyo;
       tab[2 + 3 * n] = dxo;
       tab[3 + 3 * n] = n * a.C_r * a.WS;     // only the valid taps are staged, packed
       tab[4 + 3 * kMaxTaps + n] = t;         // source tap of staged slot n
-      ++n;
     }
-    tab[0] = n;
+    if (t == 0) tab[0] = __popcll(mask);
   }
   __syncthreads();
   {
@@ -563,23 +575,91 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   for (int t = 0; t < NT; ++t) st1[t] = st2[t] = st3[t] = 0.f;
   const __amdgpu_buffer_rsrc_t rbx = make_rsrc(bb.x ? bb.x : out, bb.x ? (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4) : 0u);
 
-  for (int64_t grp = (int64_t)blockIdx.x * 4 + wave; grp < ngroups; grp += (int64_t)gridDim.x * 4) {
+  static_assert(!TILE || (MT * TS == 64 && NT == 1 && VEC), "tile variant: 64 pixels per wave, one column tile");
+  float* patch = smem + a.patch_off;
+  const int64_t nloop = TILE ? (int64_t)g.n * a.tiles_y * a.tiles_x : ngroups;
+  for (int64_t grp = TILE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave; grp < nloop;
+       grp += TILE ? (int64_t)gridDim.x : (int64_t)gridDim.x * 4) {
     const int64_t tile0 = grp * (MT * TS);
     bool pv[MT];
     int by[MT], bx[MT], img[MT];
-    // pixel coordinates in 32-bit arithmetic (M < 2^31: tensors are below 2 GiB); two divisions per pixel
+    int lbase[MT];                 // TILE: word offset of the lane's pixel inside the patch
+    int n_t = 0, ty0 = 0, tx0 = 0; // TILE: image and origin of this workgroup's tile (uniform)
+    if constexpr (TILE) {
+      const unsigned tl = (unsigned)grp;
+      const unsigned per_img = (unsigned)(a.tiles_y * a.tiles_x);
+      n_t = (int)(tl / per_img);
+      const unsigned rem = tl - (unsigned)n_t * per_img;
+      const unsigned tyi = rem / (unsigned)a.tiles_x;
+      ty0 = (int)tyi * 8;
+      tx0 = (int)(rem - tyi * (unsigned)a.tiles_x) * 32;
+      __syncthreads();             // every wave is done with the previous tile's patch
+      {
+        // stage the halo patch: element e = (py * PW + px) * C4 + c4 walks e = tid, tid + 256, ... with incremental
+        // coordinates; pixels outside the image read zeros through the bounds check; eight loads per round in flight
+        const int C4 = a.C_r >> 2;
+        const int elements = a.PH * a.PW * C4;
+        const int dpp = 256 / C4, dc4 = 256 - dpp * C4;
+        const int dpy = dpp / a.PW, dpx = dpp - dpy * a.PW;
+        const int pp0 = tid / C4;
+        int c4 = tid - pp0 * C4;
+        int py = pp0 / a.PW, px = pp0 - py * a.PW;
+        const int gy0 = ty0 + a.pmin_y, gx0 = tx0 + a.pmin_x;
+        for (int e0 = tid; e0 < elements; e0 += 256 * 8) {
+          f32x4 v[8];
+          int dw_[8];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-      const unsigned p = (unsigned)tile0 + (unsigned)(m * TS + c);
-      pv[m] = p < (unsigned)M;
-      const unsigned pp = pv[m] ? p : 0u;
-      const unsigned t1 = pp / (unsigned)qw;
-      const unsigned qx = pp - t1 * (unsigned)qw;
-      const unsigned n_ = t1 / (unsigned)qh;
-      by[m] = (int)(t1 - n_ * (unsigned)qh) * sm_;
-      bx[m] = (int)qx * sm_;
-      img[m] = (int)n_ * a.in_h * a.in_w;
+          for (int u = 0; u < 8; ++u) {
+            const bool ev = e0 + u * 256 < elements;
+            const int gy = gy0 + py, gx = gx0 + px;
+            const bool ok = ev && (unsigned)gy < (unsigned)a.in_h && (unsigned)gx < (unsigned)a.in_w;
+            v[u] = bload4(rin, ok ? ((unsigned)((n_t * a.in_h + gy) * a.in_w + gx) * (unsigned)a.in_ld + (unsigned)(c4 * 4)) * 4u : kOOB);
+            dw_[u] = ev ? (py * a.PW + px) * a.CP + c4 * 4 : -1;
+            c4 += dc4;
+            if (c4 >= C4) { c4 -= C4; ++px; }
+            px += dpx;
+            if (px >= a.PW) { px -= a.PW; ++py; }
+            py += dpy;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (dw_[u] >= 0) *reinterpret_cast<f32x4*>(patch + dw_[u]) = v[u];
+        }
+        if (tid < 4) patch[a.PH * a.PW * a.CP + tid] = 0.f;   // the zero operand of k-blocks past the last tap
+      }
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const int ly = wave * 2 + (M16 ? (m >> 1) : m), lx = (M16 ? (m & 1) * 16 : 0) + c;
+        lbase[m] = (ly * a.PW + lx) * a.CP;
+        pv[m] = true; by[m] = bx[m] = img[m] = 0;
+      }
+    } else {
+      // pixel coordinates in 32-bit arithmetic (M < 2^31: tensors are below 2 GiB); two divisions per pixel
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        const unsigned p = (unsigned)tile0 + (unsigned)(m * TS + c);
+        pv[m] = p < (unsigned)M;
+        const unsigned pp = pv[m] ? p : 0u;
+        const unsigned t1 = pp / (unsigned)qw;
+        const unsigned qx = pp - t1 * (unsigned)qw;
+        const unsigned n_ = t1 / (unsigned)qh;
+        by[m] = (int)(t1 - n_ * (unsigned)qh) * sm_;
+        bx[m] = (int)qx * sm_;
+        img[m] = (int)n_ * a.in_h * a.in_w;
+        lbase[m] = 0;
+      }
     }
+    // flat output pixel index of accumulator row `row` of pixel tile m, or 0xFFFFFFFF outside the tensor
+    auto row_pixel = [&](int m, int row) -> unsigned {
+      if constexpr (TILE) {
+        const int yy = ty0 + wave * 2 + (M16 ? (m >> 1) : m), xx = tx0 + (M16 ? (m & 1) * 16 : 0) + row;
+        return (yy < qh && xx < qw) ? (unsigned)((n_t * qh + yy) * qw + xx) : 0xFFFFFFFFu;
+      } else {
+        const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
+        return po < (unsigned)M ? po : 0xFFFFFFFFu;
+      }
+    };
     accv acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -604,13 +684,20 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
       const bool tv = tapi < nvt;
       const int ty = nty, tx = ntx;
       wbase = nwb + r0 * a.WS + cbase0 + c;
+      if constexpr (TILE) {
+        const int toff = tv ? ((ty - a.pmin_y) * a.PW + (tx - a.pmin_x)) * a.CP + r0 : -1;
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        const int iy = by[m] + ty, ix = bx[m] + tx;
-        const bool ok = tv && pv[m] && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
-        const unsigned off = ok ? ((unsigned)(img[m] + iy * a.in_w + ix) * (unsigned)a.in_ld + (unsigned)r0) * 4u : kOOB;
-        if (VEC) Ab[m] = bload4(rin, off);
-        else Ab[m][0] = bload(rin, off);
+        for (int m = 0; m < MT; ++m)
+          Ab[m] = *reinterpret_cast<const f32x4*>(patch + (toff >= 0 ? lbase[m] + toff : a.PH * a.PW * a.CP));
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          const int iy = by[m] + ty, ix = bx[m] + tx;
+          const bool ok = tv && pv[m] && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
+          const unsigned off = ok ? ((unsigned)(img[m] + iy * a.in_w + ix) * (unsigned)a.in_ld + (unsigned)r0) * 4u : kOOB;
+          if (VEC) Ab[m] = bload4(rin, off);
+          else Ab[m][0] = bload(rin, off);
+        }
       }
       tapi += a.q_blk;
       r0 += a.r_blk;
@@ -651,8 +738,8 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
-        const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
-        const unsigned pq = po < (unsigned)M ? po : 0u;
+        const unsigned po = row_pixel(m, row);
+        const unsigned pq = po != 0xFFFFFFFFu ? po : 0u;
         unsigned pix = pq;
         if (bwd && s != 1) {
           const unsigned t2 = pq / (unsigned)qw;
@@ -661,7 +748,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
           const unsigned oy_ = t2 - nn * (unsigned)qh;
           pix = (nn * (unsigned)g.h + (oy_ * (unsigned)s + (unsigned)pa)) * (unsigned)g.w + (ox_ * (unsigned)s + (unsigned)pb);
         }
-        rowoff[m][i] = po < (unsigned)M ? pix * (unsigned)a.out_ld * 4u : kOOB;
+        rowoff[m][i] = po != 0xFFFFFFFFu ? pix * (unsigned)a.out_ld * 4u : kOOB;
       }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -698,7 +785,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 #pragma unroll
           for (int i = 0; i < NR; ++i) {
             const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
-            const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
+            const unsigned po = row_pixel(m, row);
             xr[m][i] = bload(rbx, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)col) * 4u : kOOB);
           }
 #pragma unroll
@@ -709,7 +796,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
             float d = acc[m][t][i] + bvv + av[m][i];
             if (bb.drop) {
               const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
-              const unsigned po = (unsigned)tile0 + (unsigned)(m * TS + row);
+              const unsigned po = row_pixel(m, row);
               d *= bb.drop[(ok ? po / bb.hw : 0u) * (unsigned)a.C_o + (unsigned)cc];
             }
             const float xh = (xr[m][i] - mu) * is;
@@ -1229,17 +1316,21 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   a.in_w = mode == 0 ? g.w : g.wo;
   a.in_ld = mode == 0 ? g.x_ld : g.y_ld;
   a.out_ld = mode == 0 ? g.y_ld : g.x_ld;
+  a.tiles_x = a.tiles_y = a.pmin_y = a.pmin_x = a.PH = a.PW = a.CP = a.patch_off = 0;
   const int ntaps = g.kh * g.kw;
   if (ntaps > kMaxTaps) return false;
-  // Measured on MI355X (ENet layer shapes, batch 16): the LDS-weight kernel wins for outputs of <= 16 channels (16x16
-  // MFMA tiles waste no columns) unless the reduction is a single 4-channel tap; elsewhere the direct kernel's larger
-  // wave count hides latency better.
   static const int force = [] {
-    const char* e = getenv("SSMI_CONV_KERNEL");     // "lds" / "direct": override for A/B measurements
-    return e == nullptr ? 0 : (e[0] == 'l' ? 1 : (e[0] == 'd' ? 2 : 0));
+    const char* e = getenv("SSMI_CONV_KERNEL");     // "lds" / "direct" / "tile": overrides for A/B measurements
+    if (e == nullptr) return 0;
+    if (e[0] == 'l') return 1;
+    if (e[0] == 'd') return 2;
+    if (e[0] == 't') return 3;
+    return 0;
   }();
   if (force == 2) return false;
-  if (force == 0 && (a.C_o > 16 || (mode == 0 && ntaps * a.C_r <= 4))) return false;
+  const int s = g.stride;
+  const int qh = mode == 0 ? g.ho : (g.h + s - 1) / s, qw = mode == 0 ? g.wo : (g.w + s - 1) / s;
+  const bool vec = (a.C_r % 4 == 0) && (a.in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   const bool m16 = a.C_o <= 16;
   const int ts = m16 ? 16 : 32;
   const int nt = m16 ? 1 : (a.C_o <= 32 ? 1 : (a.C_o <= 64 ? 2 : 4));
@@ -1247,44 +1338,79 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   const int copad = ctiles * nt * ts;
   a.WS = m16 ? copad + 4 : copad;
   // a stride phase of the data gradient sees at most ceil(k/s)^2 taps (all of them when dilated)
-  const int staged_taps = (mode == 0 || g.dil > 1) ? ntaps : ((g.kh + g.stride - 1) / g.stride) * ((g.kw + g.stride - 1) / g.stride);
+  const int staged_taps = (mode == 0 || g.dil > 1) ? ntaps : ((g.kh + s - 1) / s) * ((g.kw + s - 1) / s);
   size_t lds = (size_t)(4 + 4 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
   if (lds > 64 * 1024) return false;
   if ((part || bb.x) && lds < (size_t)12 * nt * ts * 4) lds = (size_t)12 * nt * ts * 4;   // room for the column-sum combine
-  const bool vec = (a.C_r % 4 == 0) && (a.in_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+
+  // Tile variant (opt-in, SSMI_CONV_KERNEL=tile): multi-tap stride-1 convolutions into <= 32 channels read every input
+  // pixel once per tap; staging the 8 x 32 tile's halo patch in LDS makes that one pass over global memory and removes
+  // the per-tap address and bounds arithmetic from the inner loop.  Measured on MI355X (ENet shapes, batch 16) it does
+  // not pay: 3x3 16->16 at 128x128 31.6 vs 31.2 us, 3x3 32->32 at 64x64 24.7 vs 18.0 us, whole step 11.69 vs 11.34 ms -
+  // these launches are bound by instruction issue and fixed per-workgroup work, not by the operand path.
+  bool tile = false;
+  if (force == 3 && s == 1 && ntaps > 1 && vec && a.C_o <= 32 && a.C_r <= 32) {
+    const int ymin = mode == 0 ? -g.pad_t : g.pad_t - (g.kh - 1) * g.dil, ymax = mode == 0 ? (g.kh - 1) * g.dil - g.pad_t : g.pad_t;
+    const int xmin = mode == 0 ? -g.pad_l : g.pad_l - (g.kw - 1) * g.dil, xmax = mode == 0 ? (g.kw - 1) * g.dil - g.pad_l : g.pad_l;
+    a.pmin_y = ymin; a.pmin_x = xmin;
+    a.PH = 8 + ymax - ymin; a.PW = 32 + xmax - xmin; a.CP = a.C_r + 4;
+    a.patch_off = (int)((lds + 15) / 16) * 4;
+    const size_t total = (size_t)a.patch_off * 4 + ((size_t)a.PH * a.PW * a.CP + 4) * 4;
+    if (total <= 120 * 1024) {
+      tile = true;
+      lds = total;
+      a.tiles_y = (qh + 7) / 8;
+      a.tiles_x = (qw + 31) / 32;
+    }
+  }
+  // Measured on MI355X (ENet layer shapes, batch 16): without the tile variant the LDS-weight kernel wins for outputs of
+  // <= 16 channels (16x16 MFMA tiles waste no columns) unless the reduction is a single 4-channel tap; elsewhere the
+  // direct kernel's larger wave count hides latency better.
+  if (!tile && force != 1 && (a.C_o > 16 || (mode == 0 && ntaps * a.C_r <= 4))) return false;
+
   const int kb = (64 / ts) * (vec ? 4 : 1);
   a.q_blk = kb / a.C_r;
   a.r_blk = kb % a.C_r;
-  const int s = g.stride;
-  const int qh = mode == 0 ? g.ho : (g.h + s - 1) / s, qw = mode == 0 ? g.wo : (g.w + s - 1) / s;
   const int64_t M = (int64_t)g.n * qh * qw;
   const int mt = m16 ? 4 : (nt >= 4 ? 1 : 2);
   const int64_t ngroups = ceil_div64(M, (int64_t)mt * ts);
-  int64_t bx = ceil_div64(ngroups, 4);
+  int64_t bx = tile ? (int64_t)g.n * a.tiles_y * a.tiles_x : ceil_div64(ngroups, 4);
   // enough workgroups to fill the chip, few enough that each stages the kernel matrix for several pixel groups
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
-#define LG(M16_, MT_, NT_, V_, D_) \
-  hipLaunchKernelGGL((conv_gemm_lds<M16_, MT_, NT_, V_, D_>), grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out, part, bb)
   if (part_rows) *part_rows = (int)bx;
+  hipError_t attr_err = hipSuccess;
+#define LG(M16_, MT_, NT_, V_, D_, T_)                                                                                      \
+  do {                                                                                                                      \
+    auto kfn = conv_gemm_lds<M16_, MT_, NT_, V_, D_, T_>;                                                                   \
+    if (lds > 64 * 1024)                                                                                                    \
+      attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out, part, bb);                           \
+  } while (0)
   // prefetch depth: cover the whole reduction when it is short, else as deep as the register budget allows
   const int nblk = (staged_taps * a.C_r + kb - 1) / kb;
-  set_last_kernel("conv_gemm_lds<%s, %d, %d, %s, %d>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false",
-                  m16 ? (nblk <= 2 ? 2 : 4) : (nt == 1 ? (nblk <= 4 ? 4 : 8) : (nt == 2 ? 4 : (nblk <= 4 ? 4 : 8))));
-  if (m16) {
-    if (nblk <= 2) { if (vec) LG(true, 4, 1, true, 2); else LG(true, 4, 1, false, 2); }
-    else { if (vec) LG(true, 4, 1, true, 4); else LG(true, 4, 1, false, 4); }
-  } else if (nt == 1) {
-    if (nblk <= 4) { if (vec) LG(false, 2, 1, true, 4); else LG(false, 2, 1, false, 4); }
-    else { if (vec) LG(false, 2, 1, true, 8); else LG(false, 2, 1, false, 8); }
-  } else if (nt == 2) {
-    if (vec) LG(false, 2, 2, true, 4); else LG(false, 2, 2, false, 4);
+  if (tile) {
+    set_last_kernel("conv_gemm_lds<%s, %d, 1, true, 2, true>", m16 ? "true" : "false", mt);
+    if (m16) LG(true, 4, 1, true, 2, true); else LG(false, 2, 1, true, 2, true);
   } else {
-    if (nblk <= 4) { if (vec) LG(false, 1, 4, true, 4); else LG(false, 1, 4, false, 4); }
-    else { if (vec) LG(false, 1, 4, true, 8); else LG(false, 1, 4, false, 8); }
+    set_last_kernel("conv_gemm_lds<%s, %d, %d, %s, %d, false>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false",
+                    m16 ? (nblk <= 2 ? 2 : 4) : (nt == 1 ? (nblk <= 4 ? 4 : 8) : (nt == 2 ? 4 : (nblk <= 4 ? 4 : 8))));
+    if (m16) {
+      if (nblk <= 2) { if (vec) LG(true, 4, 1, true, 2, false); else LG(true, 4, 1, false, 2, false); }
+      else { if (vec) LG(true, 4, 1, true, 4, false); else LG(true, 4, 1, false, 4, false); }
+    } else if (nt == 1) {
+      if (nblk <= 4) { if (vec) LG(false, 2, 1, true, 4, false); else LG(false, 2, 1, false, 4, false); }
+      else { if (vec) LG(false, 2, 1, true, 8, false); else LG(false, 2, 1, false, 8, false); }
+    } else if (nt == 2) {
+      if (vec) LG(false, 2, 2, true, 4, false); else LG(false, 2, 2, false, 4, false);
+    } else {
+      if (nblk <= 4) { if (vec) LG(false, 1, 4, true, 4, false); else LG(false, 1, 4, false, 4, false); }
+      else { if (vec) LG(false, 1, 4, true, 8, false); else LG(false, 1, 4, false, 8, false); }
+    }
   }
 #undef LG
   hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = attr_err;
   if (e != hipSuccess) {
     set_error("conv_gemm_lds launch: %s", hipGetErrorString(e));
     *status = SSMI_E_HIP;

@@ -591,3 +591,19 @@ def test_conv2d_bwd_data_with_fused_bn_backward(case):
     _check(bn.dbeta, bt.grad, "dbeta")
     if act == 1:
         _check(bn.dalpha.reshape(-1), at.grad, "dalpha")
+
+
+@pytest.mark.parametrize("variant", ["lds", "direct", "tile"])
+def test_forced_conv_kernel_families(variant):
+    """SSMI_CONV_KERNEL forces one convolution kernel family (read once per process): re-run the convolution operator
+    tests in a child process for each, so the variants the selection rule does not pick stay covered."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("SSMI_CONV_KERNEL"):
+        pytest.skip("already inside a forced-variant run")
+    env = dict(os.environ, SSMI_CONV_KERNEL=variant)
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_conv2d_fwd_bwd or fused_bn"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
