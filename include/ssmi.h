@@ -298,6 +298,23 @@ ssmi_status ssmi_copy_ld(const float* src, int32_t src_ld, float* dst, int32_t d
 ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t n, int64_t hw, int32_t c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Input contract on the device (src/generators.py:711-770, 1787-1825): from the uint8 crops of a batch to the tensors
+ * the training step consumes.
+ *   images uint8 [n,h,w,3] -> X float32 = ((px / 255 - 0.5) * 2 - mean3) / std3   (mean3 / std3 nullable, already in
+ *                             the normalised [-1,1] range; same float32 operation order as the reference)
+ *   masks  uint8 [n,h,w] (red channel of the material mask; nullable: images only)
+ *          -> Y int32: rows < num_labeled: r_to_class[r] (int32[256], -1 = colour without a class);
+ *                      other rows: the raw value (src/generators.py:1806-1810)
+ *          -> W float32: rows < num_labeled: class_weights[Y]; other rows: 1
+ *   *bad (device int32, nullable) is incremented by the number of labeled pixels whose colour has no class (the
+ *   reference raises KeyError there); such pixels get class 0 and weight 0.
+ * ---------------------------------------------------------------------------------------------------- */
+ssmi_status ssmi_preprocess_batch(const uint8_t* images, const uint8_t* masks, const int32_t* r_to_class,
+                                  const float* class_weights, int32_t num_classes, int32_t num_labeled,
+                                  const float* mean3, const float* std3, int32_t n, int32_t h, int32_t w, float* X,
+                                  int32_t* Y, float* W, int32_t* bad, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
  * HIP graph capture of a whole training step (replaces the one tf.Session.run per step of
  * ExtendedModel.train_on_batch, src/keras_extensions/extended_model.py:1002).
  * ---------------------------------------------------------------------------------------------------- */

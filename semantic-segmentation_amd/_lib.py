@@ -87,6 +87,7 @@ _PROTOS = {
     "ssmi_upsample_nn2x_bwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "ssmi_copy_ld": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ssmi_scale_nc": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
+    "ssmi_preprocess_batch": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "ssmi_graph_begin_capture": (_i32, [_vp]),
     "ssmi_graph_end_capture": (_i32, [_vp, C.POINTER(_vp)]),
     "ssmi_graph_launch": (_i32, [_vp, _vp]),

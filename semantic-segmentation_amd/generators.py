@@ -1,0 +1,109 @@
+"""Device side of the reference's batch contract (src/generators.py).
+
+The reference's `SegmentationDataGenerator` crops / augments on CPU workers and then, still on the CPU, normalises the
+images (`_np_normalize_image_batch`, :711-770), index-encodes the masks (`_index_encode_batch_masks`, :1787-1812) and
+builds the per-pixel weight map (`_create_batch_weights`, :1814-1825).  `DeviceBatchEncoder` keeps those three method
+names and semantics but runs them as one HIP pre-pass over the uint8 crops (4 bytes in, 20 bytes out per pixel), so the
+host hands over 4 bytes per pixel instead of 20.  File reading, cropping and augmentation stay with the caller.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from ._lib import lib
+
+
+def np_from_255_to_normalized(val):
+    """src/utils/image_utils.py:1437-1441."""
+    return ((val / 255.0) - 0.5) * 2.0
+
+
+def _normalised_range(values, what) -> Optional[np.ndarray]:
+    """Per-channel mean / stddev given either in [-1, 1] or in [0, 255] (src/generators.py:741-766)."""
+    if values is None:
+        return None
+    v = np.array(values).astype(np.float32)
+    if (v >= -1.0 - 1e-7).all() and (v <= 1.0 + 1e-7).all():
+        return v
+    if (v >= 0.0).all() and (v <= 255.0).all():
+        return np_from_255_to_normalized(v).astype(np.float32)
+    raise ValueError('{} is in unknown range: {}'.format(what, v))
+
+
+class DeviceBatchEncoder(object):
+    def __init__(self, material_r_color_to_material_class: Dict[int, int], class_weights: Sequence[float],
+                 per_channel_mean=None, per_channel_stddev=None, use_per_channel_mean_normalization=True,
+                 use_per_channel_stddev_normalization=True, device="cuda"):
+        self.device = torch.device(device)
+        if use_per_channel_mean_normalization and per_channel_mean is None:
+            raise ValueError('Use per-channel mean normalization is true, but per-channel mean is None')
+        if use_per_channel_stddev_normalization and per_channel_stddev is None:
+            raise ValueError('Use per-channel stddev normalization is true, but per-channel stddev is None')
+        mean = _normalised_range(per_channel_mean, 'Per channel mean') if use_per_channel_mean_normalization else None
+        std = _normalised_range(per_channel_stddev, 'Per-channel stddev') if use_per_channel_stddev_normalization else None
+        lut = np.full(256, -1, dtype=np.int32)
+        for r, cls in material_r_color_to_material_class.items():
+            if not 0 <= int(r) <= 255:
+                raise ValueError('material red colour {} is not a byte'.format(r))
+            lut[int(r)] = int(cls)
+        self.num_classes = len(class_weights)
+        self._lut = torch.from_numpy(lut).to(self.device)
+        self._cw = torch.tensor(np.asarray(class_weights, dtype=np.float32), device=self.device)
+        self._mean = torch.from_numpy(mean).to(self.device) if mean is not None else None
+        self._std = torch.from_numpy(std).to(self.device) if std is not None else None
+        self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def _u8(self, a) -> torch.Tensor:
+        if torch.is_tensor(a):
+            if a.dtype != torch.uint8:
+                raise ValueError('expected uint8 data, got {}'.format(a.dtype))
+            return a.to(self.device).contiguous()
+        a = np.asarray(a)
+        if a.dtype != np.uint8:
+            if a.min() < 0 or a.max() > 255:
+                raise ValueError('Batch image values are not between [0, 255], got [{}, {}]'.format(a.min(), a.max()))
+            a = a.astype(np.uint8)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def encode(self, images, masks=None, num_labeled: Optional[int] = None, stream: Optional[int] = None):
+        """images uint8 [n,h,w,3]; masks uint8 [n,h,w] (red channel) or None.
+        Returns (X float32 [n,h,w,3], Y int32 [n,h,w] | None, W float32 [n,h,w] | None) as device tensors."""
+        img = self._u8(images)
+        if img.dim() != 4 or img.shape[3] != 3:
+            raise ValueError('images must be [n, h, w, 3], got {}'.format(tuple(img.shape)))
+        n, h, w = int(img.shape[0]), int(img.shape[1]), int(img.shape[2])
+        X = torch.empty(n, h, w, 3, dtype=torch.float32, device=self.device)
+        Y = W = msk = None
+        if masks is not None:
+            msk = self._u8(masks)
+            if tuple(msk.shape) != (n, h, w):
+                raise ValueError('masks must be [n, h, w] = {}, got {}'.format((n, h, w), tuple(msk.shape)))
+            Y = torch.empty(n, h, w, dtype=torch.int32, device=self.device)
+            W = torch.empty(n, h, w, dtype=torch.float32, device=self.device)
+        nl = n if num_labeled is None else int(num_labeled)
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        p = lambda t: None if t is None else t.data_ptr()
+        lib().preprocess_batch(p(img), p(msk), p(self._lut), p(self._cw), self.num_classes, nl, p(self._mean), p(self._std),
+                               n, h, w, p(X), p(Y), p(W), p(self._bad), st)
+        return X, Y, W
+
+    def check(self):
+        """Raises KeyError (like the reference's dictionary lookup) if a labeled pixel had a colour without a class."""
+        bad = int(self._bad.item())
+        if bad:
+            self._bad.zero_()
+            raise KeyError('{} labeled pixels carry a material colour that maps to no class'.format(bad))
+
+    def get_data_batch(self, images, masks, num_labeled: Optional[int] = None):
+        """The SEMI_SUPERVISED batch format of src/generators.py:1742-1766:
+        ([X, Y, W, num_unlabeled], [dummy_output, logits_output])."""
+        X, Y, W = self.encode(images, masks, num_labeled)
+        n = int(X.shape[0])
+        nl = n if num_labeled is None else int(num_labeled)
+        num_unlabeled = np.ones(n, dtype=np.int32) * (n - nl)
+        logits_output = Y.clone().unsqueeze(-1)
+        logits_output[nl:] = 0
+        return [X, Y, W, num_unlabeled], [np.zeros(n, dtype=np.int32), logits_output]

@@ -178,3 +178,21 @@ def test_enet_forward_shapes_and_inference_mode():
     assert logits.shape == (1, 32, 48, 5) and not ctx.bn_stats
     logits2, ctx2 = E.enet_forward(name, w, x, training=True)
     assert len(ctx2.bn_stats) > 60 and not torch.allclose(logits, logits2)
+
+
+def test_input_contract_known_answers():
+    """src/generators.py:711-770, 1787-1825 restated: byte 0 -> -1, 255 -> +1; labeled rows map the red colour to the
+    class id and take the class weight, unlabeled rows keep the raw value and weight 1."""
+    from oracle import input_oracle as O
+    img = np.array([[[[0, 255, 51]]]], dtype=np.uint8)
+    x = O.normalize_image_batch(img)
+    assert x.dtype == np.float32 and np.allclose(x[0, 0, 0], [-1.0, 1.0, -0.6], atol=1e-6)
+    x2 = O.normalize_image_batch(img, [0.0, 0.5, 0.0], [0.5, 0.5, 1.0])
+    assert np.allclose(x2[0, 0, 0], [-2.0, 1.0, -0.6], atol=1e-6)
+    x3 = O.normalize_image_batch(img, [127.5, 127.5, 127.5], None)          # mean given in the [0, 255] range = 0 normalised
+    assert np.allclose(x3, x, atol=1e-6)
+    masks = np.array([[[10, 20]], [[7, 20]]], dtype=np.uint8)
+    y = O.index_encode_batch_masks(masks, {10: 1, 20: 2}, num_labeled=1)
+    assert np.array_equal(y, [[[1, 2]], [[7, 20]]])
+    w = O.create_batch_weights(y, np.array([0.0, 0.25, 4.0], dtype=np.float32), num_labeled=1)
+    assert np.array_equal(w, [[[0.25, 4.0]], [[1.0, 1.0]]])
