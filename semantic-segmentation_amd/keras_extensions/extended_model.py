@@ -107,12 +107,43 @@ class ExtendedModel(object):
 
     def load_weights(self, filepath, by_name=False):
         with np.load(filepath, allow_pickle=False) as z:
-            d = {k.replace("::", "/"): z[k] for k in z.files}
+            d = {k.replace("::", "/"): z[k] for k in z.files if not k.startswith("optimizer_weights::")}
         if by_name:
             cur = self.get_weights_dict()
             cur.update({k: v for k, v in d.items() if k in cur})
             d = cur
         self.set_weights_dict(d)
+
+    def save(self, filepath, overwrite=True, include_optimizer=True):
+        """Weights plus, like Keras Model.save, the optimizer state (slot arenas and the iteration counter) in one .npz
+        container; `load_weights` reads the weights back, `ModelBase.load_optimizer_weights` the optimizer part."""
+        if os.path.exists(filepath) and not overwrite:
+            raise IOError("{} exists".format(filepath))
+        d = {k.replace("/", "::"): v for k, v in self.get_weights_dict().items()}
+        if include_optimizer and self.optimizer is not None:
+            for k, t in self.optimizer.slot_tensors().items():
+                d["optimizer_weights::" + k] = t.detach().cpu().numpy()
+            d["optimizer_weights::iterations"] = np.array(self.optimizer.iterations, dtype=np.int64)
+        np.savez(filepath, **d)
+
+    def load_optimizer_weights(self, filepath) -> bool:
+        """False when the file holds no (or incompatible) optimizer state, True after restoring it."""
+        if self.optimizer is None:
+            raise ValueError('The model must be compiled with an optimizer before loading optimizer weights')
+        with np.load(filepath, allow_pickle=False) as z:
+            names = [k for k in z.files if k.startswith("optimizer_weights::")]
+            if not names:
+                return False
+            slots = self.optimizer.slot_tensors()
+            for k, t in slots.items():
+                key = "optimizer_weights::" + k
+                if key not in z.files or tuple(z[key].shape) != tuple(t.shape):
+                    return False
+            for k, t in slots.items():
+                t.copy_(torch.from_numpy(np.ascontiguousarray(z["optimizer_weights::" + k], dtype=np.float32)))
+            if "optimizer_weights::iterations" in z.files:
+                self.optimizer.set_iterations(int(z["optimizer_weights::iterations"]))
+        return True
 
     def count_params(self):
         return sum(s.size for s in self.graph.store.specs.values())
@@ -130,7 +161,9 @@ class ExtendedModel(object):
             if float(loss_weights.get("loss", 1.0)) != 1.0 or float(loss_weights.get("logits", 0.0)) != 0.0:
                 raise NotImplementedError("only loss_weights {'loss': 1, 'logits': 0} are supported")
         self.optimizer = optimizer
-        optimizer.bind(self.graph.store)
+        # layers frozen before compile() (ModelBase.transfer_weights) take no updates, as in Keras
+        frozen = [k for l in self.layers if not l.trainable for k in l.weight_keys]
+        optimizer.bind(self.graph.store, frozen)
         self.loss = loss
         self.loss_weights = loss_weights
         self.metrics = metrics

@@ -17,19 +17,28 @@ class Optimizer:
         self.lr_scalers: Dict[int, float] = dict(lr_scalers or {})
         self._bound = False
 
-    def bind(self, store):
-        """Attach to a parameter store (engine.ParamStore)."""
+    def bind(self, store, frozen_keys=()):
+        """Attach to a parameter store (engine.ParamStore).  `frozen_keys`: weights of layers with trainable = False.
+        Keras builds `params` from the trainable weights only, so the indices of `lr_scalers`
+        (extended_optimizers.py:41,124: `lr_scalers[i]` scales params[i]) count the non-frozen weights in creation
+        order; frozen weights get a rate of exactly zero."""
         self.store = store
         dev = store.theta.device
         # 16-byte block: int64 iterations + 8 bytes the library uses for the step's effective learning rate
         self.step_block = torch.zeros(2, dtype=torch.int64, device=dev)
         self.lr_scale = None
-        if self.lr_scalers:
+        frozen = set(frozen_keys)
+        if self.lr_scalers or frozen:
             tab = torch.ones_like(store.theta)
-            for i, key in enumerate(store.trainable_keys()):
+            i = 0
+            for key in store.trainable_keys():
+                s = store.specs[key]
+                if key in frozen:
+                    tab[s.offset:s.offset + s.size] = 0.0
+                    continue
                 if i in self.lr_scalers:
-                    s = store.specs[key]
                     tab[s.offset:s.offset + s.size] = float(self.lr_scalers[i])
+                i += 1
             self.lr_scale = tab
         self._bound = True
 
@@ -51,8 +60,8 @@ class Adam(Optimizer):
         self.initial_decay = float(decay)
         self.amsgrad = amsgrad
 
-    def bind(self, store):
-        super().bind(store)
+    def bind(self, store, frozen_keys=()):
+        super().bind(store, frozen_keys)
         self.m = torch.zeros_like(store.theta)
         self.v = torch.zeros_like(store.theta)
         self.vhat = torch.zeros_like(store.theta) if self.amsgrad else None
@@ -82,8 +91,8 @@ class SGD(Optimizer):
         self.initial_decay = float(decay)
         self.nesterov = bool(nesterov)
 
-    def bind(self, store):
-        super().bind(store)
+    def bind(self, store, frozen_keys=()):
+        super().bind(store, frozen_keys)
         self.moments = torch.zeros_like(store.theta)
 
     def apply(self, grad_scale: float = 1.0, stream: Optional[int] = None):

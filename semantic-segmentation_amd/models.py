@@ -31,6 +31,24 @@ def get_lambda_loss_function(model_lambda_loss_type):
     raise ValueError('Unknown model lambda loss type: {}'.format(model_lambda_loss_type))
 
 
+class WeightTransferInformation(object):
+    """src/models.py:29-47."""
+
+    def __init__(self, num_transferred_layers, last_transferred_layer_name, num_frozen_layers, last_frozen_layer_name,
+                 lr_scalers):
+        self.num_transferred_layers = num_transferred_layers
+        self.last_transferred_layer_name = last_transferred_layer_name
+        self.num_frozen_layers = num_frozen_layers
+        self.last_frozen_layer_name = last_frozen_layer_name
+        self.lr_scalers = lr_scalers
+
+
+def _norm_index(idx, n):
+    if idx is None:
+        return None
+    return idx + n if idx < 0 else idx
+
+
 class ModelBase(object):
     """src/models.py:157-205."""
 
@@ -55,6 +73,106 @@ class ModelBase(object):
 
     def _build_model(self):
         raise NotImplementedError('This method should be implemented in the class derived from ModelBase')
+
+    def transfer_weights(self, from_model, from_layer_index, to_layer_index, freeze_from_layer_index=None,
+                         freeze_to_layer_index=None, scale_lr_from_layer_index=None, scale_lr_to_layer_index=None,
+                         scale_lr_factor=None):
+        """src/models.py:211-301, kept to the letter: the index range slices the get_weights() LIST of both models
+        ("assumes indexing is the same for both models"), freezing marks LAYERS [freeze_from, freeze_to) untrainable
+        (call compile() afterwards), and the returned lr_scalers are keyed by the indices given."""
+        n = len(from_model.layers)
+        from_layer_index, to_layer_index = _norm_index(from_layer_index, n), _norm_index(to_layer_index, n)
+        freeze_from_layer_index, freeze_to_layer_index = _norm_index(freeze_from_layer_index, n), _norm_index(freeze_to_layer_index, n)
+        scale_lr_from_layer_index, scale_lr_to_layer_index = _norm_index(scale_lr_from_layer_index, n), _norm_index(scale_lr_to_layer_index, n)
+        freezing = freeze_from_layer_index is not None and freeze_to_layer_index is not None
+        scaling = scale_lr_from_layer_index is not None and scale_lr_to_layer_index is not None
+        assert from_layer_index < to_layer_index
+        assert not (freezing and freeze_from_layer_index > freeze_to_layer_index)
+        assert not (scaling and scale_lr_from_layer_index > scale_lr_to_layer_index)
+        assert not (scaling and scale_lr_factor is None)
+        to_w = self._model.get_weights()
+        from_w = from_model.get_weights()
+        to_w[from_layer_index:to_layer_index] = from_w[from_layer_index:to_layer_index]
+        self._model.set_weights(to_w)
+        num_frozen = 0
+        if freezing:
+            for i in range(freeze_from_layer_index, freeze_to_layer_index):
+                self._model.layers[i].trainable = False
+                num_frozen += 1
+        lr_scalers = {}
+        if scaling:
+            for i in range(scale_lr_from_layer_index, scale_lr_to_layer_index):
+                lr_scalers[i] = scale_lr_factor
+        return WeightTransferInformation(to_layer_index - from_layer_index, from_model.layers[to_layer_index - 1].name,
+                                         num_frozen, from_model.layers[freeze_to_layer_index - 1].name if freezing else None,
+                                         lr_scalers)
+
+    def transfer_weights_from_file(self, filepath, from_layer_index, to_layer_index, freeze_from_layer_index=None,
+                                   freeze_to_layer_index=None, scale_lr_from_layer_index=None,
+                                   scale_lr_to_layer_index=None, scale_lr_factor=None):
+        """Topological (order-based) transfer from a weight container (src/models.py:303-516): the layers WITH weights
+        of the file and of this model are paired by position, layers [from, to) are copied (shapes must agree),
+        freezing / learning-rate scaling as in transfer_weights but counted over the layers with weights; the
+        lr_scalers index the model's trainable weights of the scaled layers.  The container is the .npz written by
+        ExtendedModel.save_weights / save (h5py is not available on this platform)."""
+        import numpy as np
+        from collections import OrderedDict
+        with np.load(filepath, allow_pickle=False) as z:
+            file_layers: "OrderedDict[str, list]" = OrderedDict()
+            for k in z.files:
+                if k.startswith("optimizer_weights::"):
+                    continue
+                lname, _ = k.rsplit("::", 1)
+                file_layers.setdefault(lname, []).append(np.asarray(z[k]))
+        model_layers = [l for l in self._model.layers if l.weight_keys]
+        n = len(file_layers)
+        from_layer_index, to_layer_index = _norm_index(from_layer_index, n), _norm_index(to_layer_index, n)
+        freeze_from_layer_index, freeze_to_layer_index = _norm_index(freeze_from_layer_index, n), _norm_index(freeze_to_layer_index, n)
+        scale_lr_from_layer_index, scale_lr_to_layer_index = _norm_index(scale_lr_from_layer_index, n), _norm_index(scale_lr_to_layer_index, n)
+        freezing = freeze_from_layer_index is not None and freeze_to_layer_index is not None
+        scaling = scale_lr_from_layer_index is not None and scale_lr_to_layer_index is not None
+        assert from_layer_index < to_layer_index
+        assert not (scaling and scale_lr_factor is None)
+        if to_layer_index > min(n, len(model_layers)):
+            raise ValueError('Cannot transfer layers up to index {}: the file holds {} layers with weights, the model {}'
+                             .format(to_layer_index, n, len(model_layers)))
+        names = list(file_layers.keys())
+        cur = self._model.get_weights_dict()
+        for i in range(from_layer_index, to_layer_index):
+            layer, vals = model_layers[i], file_layers[names[i]]
+            if len(vals) != len(layer.weight_keys):
+                raise ValueError('Layer #{} (named "{}") expects {} weight(s), but the saved weights have {} element(s)'
+                                 .format(i, layer.name, len(layer.weight_keys), len(vals)))
+            for key, v in zip(layer.weight_keys, vals):
+                if tuple(v.shape) != tuple(cur[key].shape):
+                    raise ValueError('Layer #{} (named "{}"): weight shape {} not compatible with provided shape {}'
+                                     .format(i, layer.name, cur[key].shape, v.shape))
+                cur[key] = v
+        self._model.set_weights_dict(cur)
+        num_frozen = 0
+        if freezing:
+            for i in range(freeze_from_layer_index, freeze_to_layer_index):
+                model_layers[i].trainable = False
+                num_frozen += 1
+        lr_scalers = {}
+        if scaling:
+            store = self._model.graph.store
+            trainable = [k for l in model_layers if l.trainable for k in l.weight_keys if store.specs[k].trainable]
+            pos = {k: i for i, k in enumerate(trainable)}
+            for i in range(scale_lr_from_layer_index, scale_lr_to_layer_index):
+                for k in model_layers[i].weight_keys:
+                    if k in pos:
+                        lr_scalers[pos[k]] = scale_lr_factor
+        return WeightTransferInformation(to_layer_index - from_layer_index, model_layers[to_layer_index - 1].name, num_frozen,
+                                         model_layers[freeze_to_layer_index - 1].name if freezing else None, lr_scalers)
+
+    def load_optimizer_weights(self, weights_file_path):
+        """src/models.py:518-564."""
+        if self.model is None:
+            raise ValueError('The internal model must be built before loading optimizer weights')
+        if self.model.optimizer is None:
+            raise ValueError('The model must be compiled with an optimizer before loading optimizer weights')
+        return self.model.load_optimizer_weights(weights_file_path)
 
 
 class ENetNaiveUpsampling(ModelBase):

@@ -175,3 +175,53 @@ def test_metric_factories_carry_the_reference_attributes():
     for f, nm in ((metrics.segmentation_accuracy(0, [0]), "acc"), (metrics.segmentation_mean_iou(24, 0, [0]), "miou"),
                   (metrics.segmentation_mean_per_class_accuracy(24, 0, [0]), "mpca")):
         assert f.__name__ == nm and f.streaming and not getattr(f, "cfm", False) and callable(f.reset_op)
+
+
+def test_transfer_weights_freezing_and_lr_scalers(tmp_path):
+    """ModelBase.transfer_weights / transfer_weights_from_file (src/models.py:211-516) and the optimizer's handling of
+    frozen layers: lr_scalers index the trainable weights that remain, frozen weights get rate 0."""
+    models = pkg("models")
+    xo = pkg("keras_extensions.extended_optimizers")
+    name = "enet-max-unpooling"
+    a = models.get_model(name, (None, None, 3), 24, device="cpu")
+    b = models.get_model(name, (None, None, 3), 24, device="cpu")
+    wa = E.init_weights(name, 24, seed=1, perturb=True, dtype=np.float32)
+    wb = E.init_weights(name, 24, seed=2, perturb=True, dtype=np.float32)
+    a.model.set_weights(list(wa.values()))
+    b.model.set_weights(list(wb.values()))
+    info = b.transfer_weights(a.model, 0, 10, freeze_from_layer_index=0, freeze_to_layer_index=3,
+                              scale_lr_from_layer_index=3, scale_lr_to_layer_index=5, scale_lr_factor=0.1)
+    got = b.model.get_weights()
+    for i, (x, y, z) in enumerate(zip(got, wa.values(), wb.values())):
+        assert np.array_equal(x, y if i < 10 else z)
+    assert info.num_transferred_layers == 10 and info.num_frozen_layers == 3 and info.lr_scalers == {3: 0.1, 4: 0.1}
+    assert [l.trainable for l in b.model.layers[:4]] == [False, False, False, True]
+    assert info.last_frozen_layer_name == a.model.layers[2].name
+    # optimizer table: frozen weights -> 0; scaler index counts the remaining trainable weights
+    store = b.model.graph.store
+    frozen = [k for l in b.model.layers if not l.trainable for k in l.weight_keys]
+    opt = xo.Adam(lr=1e-3, lr_scalers={0: 0.5})
+    opt.bind(store, frozen)
+    tab = opt.lr_scale.numpy()
+    remaining = [k for k in store.trainable_keys() if k not in frozen]
+    for k in store.trainable_keys():
+        s = store.specs[k]
+        seg = tab[s.offset:s.offset + s.size]
+        want = 0.0 if k in frozen else (0.5 if k == remaining[0] else 1.0)
+        assert (seg == want).all(), k
+    # order-based transfer from a file
+    path = str(tmp_path / "w.npz")
+    a.model.save_weights(path)
+    c = models.get_model(name, (None, None, 3), 24, device="cpu")
+    c.model.set_weights(list(wb.values()))
+    info = c.transfer_weights_from_file(path, 0, 4, freeze_from_layer_index=0, freeze_to_layer_index=2,
+                                        scale_lr_from_layer_index=2, scale_lr_to_layer_index=4, scale_lr_factor=0.25)
+    layers = [l for l in c.model.layers if l.weight_keys]
+    cw = c.model.get_weights_dict()
+    for i, l in enumerate(layers[:6]):
+        for k in l.weight_keys:
+            assert np.array_equal(cw[k], wa[k] if i < 4 else wb[k])
+    assert info.num_transferred_layers == 4 and info.num_frozen_layers == 2 and info.last_transferred_layer_name == layers[3].name
+    assert len(info.lr_scalers) > 0 and set(info.lr_scalers.values()) == {0.25}
+    with pytest.raises(ValueError):
+        c.transfer_weights_from_file(path, 0, 10 ** 6)

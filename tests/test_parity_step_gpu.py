@@ -178,3 +178,67 @@ def test_segnet_train_step_parity():
 
 def test_unet_train_step_parity():
     _run_case("unet", 2, 48, 32, seed=17, steps=1)
+
+
+def test_frozen_layers_and_optimizer_state_roundtrip(tmp_path):
+    """Layers marked untrainable before compile() take no updates; Model.save + load_optimizer_weights restore the Adam
+    slots and the iteration counter so that a resumed step equals the uninterrupted one."""
+    models, losses, opt = pkg("models"), pkg("losses"), pkg("keras_extensions.extended_optimizers")
+    name, nc = "enet-naive-upsampling", 24
+    w0 = E.init_weights(name, nc, seed=4, perturb=True, dtype=np.float32)
+    images, labels, pw = E.synthetic_batch(2, 32, 32, nc, seed=5, block=8)
+    x = [images, labels, pw, np.zeros((2, 1), dtype=np.int32)]
+    y = [np.zeros(2, dtype=np.int32), labels[..., None]]
+
+    def make(frozen_layers=()):
+        mb = models.get_model(name, (None, None, 3), nc, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
+        m = mb.model
+        m.set_weights([w0[k] for k in m.weight_names()])
+        for i in frozen_layers:
+            m.layers[i].trainable = False
+        m.compile(optimizer=opt.Adam(lr=1e-3), loss={'loss': losses.dummy_loss, 'logits': lambda t, p: 0 * p},
+                  loss_weights={'loss': 1.0, 'logits': 0.0})
+        m.use_hip_graph = False
+        return mb, m
+
+    mb, m = make(frozen_layers=range(0, 6))
+    with torch.cuda.stream(torch.cuda.Stream()):
+        m.train_on_batch(x, y)
+    torch.cuda.synchronize()
+    after = m.get_weights_dict()
+    store = m.graph.store
+    frozen_keys = {k for l in m.layers[:6] for k in l.weight_keys}
+    moved = 0
+    for k in store.trainable_keys():
+        if k in frozen_keys:
+            assert np.array_equal(after[k], w0[k]), "frozen weight {} changed".format(k)
+        else:
+            moved += int(not np.array_equal(after[k], w0[k]))
+    assert moved > 300
+
+    # resume: A runs two steps; B runs one, is saved, a fresh model restores weights + optimizer state and runs the second
+    _, a = make()
+    _, b = make()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for mdl in (a, b):
+            mdl.seed = 99
+        a.train_on_batch(x, y)
+        a.train_on_batch(x, y)
+        b.train_on_batch(x, y)
+        torch.cuda.synchronize()
+        path = str(tmp_path / "ckpt.npz")
+        b.save(path)
+        mbc, c = make()
+        c.seed = 99
+        c.load_weights(path)
+        assert mbc.load_optimizer_weights(path) is True
+        assert c.optimizer.iterations == 1
+        c.train_on_batch(x, y)
+    torch.cuda.synchronize()
+    wa, wc = a.get_weights_dict(), c.get_weights_dict()
+    for k in wa:
+        assert np.array_equal(wa[k], wc[k]), "resumed step differs in {}".format(k)
+    assert mbc.load_optimizer_weights(str(tmp_path / "ckpt.npz")) is True
+    c.save_weights(str(tmp_path / "weights_only.npz"))
+    assert mbc.load_optimizer_weights(str(tmp_path / "weights_only.npz")) is False
