@@ -244,6 +244,9 @@ ssmi_status ssmi_idx_f32_to_i32(const float* src, int32_t* dst, int64_t count, v
  *   loss   = (1/npix) * sum_p w[p] * (logsumexp(z[p,:]) - z[p, label[p]])
  *   dlogits[p,k] = grad_scale * w[p]/npix * (softmax(z[p,:])[k] - [k == label[p]])        (dlogits nullable)
  *   cm[label[p], argmax_k z[p,k]] += 1 for p < npix_metrics with label[p] not in ignore_mask   (cm int64, nullable, accumulated)
+ *   npix_metrics may exceed npix (semi-supervised batches, src/generators.py:1764-1766: the metrics see every row, the
+ *   classification cost only the labeled ones): pixels in [npix, npix_metrics) update cm / pred_out only, their dlogits
+ *   rows are left untouched, and logits / labels must cover npix_metrics pixels.
  * loss_out is a device float, overwritten.  ignore_mask bit k set <=> class k ignored (num_classes <= 64).
  * Labels outside [0, num_classes) are an error in TensorFlow; here they contribute nothing and set *bad_labels
  * (device int32, nullable) to the count seen.  Deterministic loss reduction through ws. */
@@ -258,6 +261,26 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
  * out[0]=accuracy, out[1]=tf mean_per_class_accuracy, out[2]=tf mean_iou (classes with non-zero denominator),
  * out[3]=tf mean_iou over all classes, out[4]=script mpca, out[5]=script miou. */
 ssmi_status ssmi_metrics_from_cm(const int64_t* cm_host, int32_t num_classes, uint64_t ignore_mask, double* out6);
+
+/* Mean-teacher consistency cost and its gradient (src/losses.py:195-215 called from
+ * segmentation_mean_teacher_lambda_loss, src/losses.py:377-436):
+ *   cost = coef * mean_pixels( mean_classes( (softmax(teacher_logits) - softmax(logits))^2 ) )
+ * over all `npix` pixels (labeled and unlabeled rows).  `coef_dev` is a 1-element DEVICE float so that a captured
+ * graph can be replayed while the coefficient follows its schedule.  The teacher logits take no gradient.
+ * dlogits (nullable): rows of the first `npix_accumulate` pixels are added to (they already hold the classification
+ * gradient written by ssmi_softmax_xent_fwd_bwd over the labeled rows), the remaining rows are overwritten.
+ * loss_io (nullable): receives cost, or loss_io + cost when accumulate_loss != 0.  cost_out (nullable) receives cost.
+ * Deterministic: per-block partial sums in `ws`, reduced in double by a single block. */
+size_t ssmi_mt_consistency_workspace_bytes(int64_t npix);
+ssmi_status ssmi_mt_consistency_fwd_bwd(const float* logits, const float* teacher_logits, int64_t npix, int32_t num_classes,
+                                        const float* coef_dev, float grad_scale, int64_t npix_accumulate, float* dlogits,
+                                        float* loss_io, int32_t accumulate_loss, float* cost_out, void* ws, size_t ws_bytes,
+                                        void* stream);
+
+/* Teacher weights as an exponential moving average of the student's (src/trainers.py:1692-1706):
+ *   teacher[i] = fl32(fl32(a) * teacher[i]) + fl32(fl32(1 - a) * student[i])   (no fused multiply-add, like numpy)
+ * applied to a whole arena; `1 - a` is formed in double before rounding, as the reference's Python float does. */
+ssmi_status ssmi_ema_update(float* teacher, const float* student, double a, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Optimizers over a flat parameter arena (src/keras_extensions/extended_optimizers.py:35-67, 117-162).

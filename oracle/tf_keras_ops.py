@@ -225,6 +225,29 @@ def segmentation_cce_lambda_loss(logits, labels, weights, num_unlabeled: int):
     return sparse_weighted_pixelwise_xent(logits, labels, weights[0:num_labeled])
 
 
+def mean_teacher_consistency_cost(y_pred, mt_pred, consistency_coefficient):
+    """src/losses.py:195-215: coefficient * mean over pixels of the class-mean squared difference of the softmax
+    outputs.  The teacher logits are an input (no gradient flows into them)."""
+    s = torch.softmax(y_pred, dim=-1)
+    t = torch.softmax(mt_pred.detach(), dim=-1)
+    mse = torch.mean((t - s) ** 2, dim=-1)
+    return consistency_coefficient * torch.mean(mse)
+
+
+def segmentation_mean_teacher_lambda_loss(logits, labels, weights, num_unlabeled: int, mt_pred, consistency_coefficient):
+    """src/losses.py:377-436: classification cost over the first B - num_unlabeled rows (mean over THEIR pixels,
+    src/losses.py:416-422) plus the consistency cost over every row (src/losses.py:428)."""
+    B = labels.shape[0]
+    num_labeled = B - int(num_unlabeled)
+    cls = sparse_weighted_pixelwise_xent(logits[0:num_labeled], labels[0:num_labeled], weights[0:num_labeled])
+    return cls + mean_teacher_consistency_cost(logits, mt_pred, consistency_coefficient)
+
+
+def ema_update_np(teacher, student, a):
+    """src/trainers.py:1692-1706 on lists of float32 numpy arrays; `a` is a Python float, so numpy keeps float32."""
+    return [a * t + ((1.0 - a) * s) for t, s in zip(teacher, student)]
+
+
 def class_weight_map(labels, class_weights):
     """src/losses.py:270-298 (while_loop over classes) == class_weights[labels];
     src/generators.py:1814-1825 builds the same map on the host."""

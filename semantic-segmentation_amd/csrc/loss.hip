@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
   }
   float local = 0.f;
   int bad = 0;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+  const int64_t nloop = npix_metrics > npix ? npix_metrics : npix;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nloop; p += (int64_t)gridDim.x * 256) {
+    const bool in_loss = p < npix;   // rows past npix feed the confusion matrix only
     const float* zp = logits + p * C;
     float z[C];
     if (C % 4 == 0) {
@@ -68,14 +70,14 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     for (int j = 0; j < C; ++j) { e[j] = __expf(z[j] - mx); se += e[j]; }
     const int lab = labels[p];
     const bool lv = (unsigned)lab < (unsigned)C;
-    const float wgt = lv ? weights[p] : 0.f;
+    const float wgt = (lv && in_loss) ? weights[p] : 0.f;
     if (!lv) ++bad;
     float zl = 0.f;
 #pragma unroll
     for (int j = 0; j < C; ++j) zl = (j == lab) ? z[j] : zl;
     const float lse = mx + __logf(se);
     local += wgt * (lse - zl);
-    if (dlogits) {
+    if (dlogits && in_loss) {
       const float k = grad_scale * wgt * inv_npix;
       const float inv = 1.f / se;
       float* dp = dlogits + p * C;
@@ -113,7 +115,9 @@ __global__ __launch_bounds__(256) void xent_kernel_generic(const float* __restri
   }
   float local = 0.f;
   int bad = 0;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+  const int64_t nloop = npix_metrics > npix ? npix_metrics : npix;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nloop; p += (int64_t)gridDim.x * 256) {
+    const bool in_loss = p < npix;
     const float* zp = logits + p * C;
     float mx = zp[0];
     int am = 0;
@@ -125,11 +129,11 @@ __global__ __launch_bounds__(256) void xent_kernel_generic(const float* __restri
     for (int j = 0; j < C; ++j) se += __expf(zp[j] - mx);
     const int lab = labels[p];
     const bool lv = (unsigned)lab < (unsigned)C;
-    const float wgt = lv ? weights[p] : 0.f;
+    const float wgt = (lv && in_loss) ? weights[p] : 0.f;
     if (!lv) ++bad;
     const float zl = lv ? zp[lab] : 0.f;
     local += wgt * (mx + __logf(se) - zl);
-    if (dlogits) {
+    if (dlogits && in_loss) {
       const float k = grad_scale * wgt * inv_npix;
       const float inv = 1.f / se;
       float* dp = dlogits + p * C;
@@ -155,6 +159,136 @@ __global__ void xent_final(const double* __restrict__ part, int nblocks, double 
   if (threadIdx.x == 0) *loss_out = (float)(sm[0] * inv_npix);
 }
 
+
+// Mean-teacher consistency cost (src/losses.py:195-215): coef * mean over pixels of mean_c (softmax(teacher) -
+// softmax(student))^2, with its gradient w.r.t. the student logits.  CT > 0 keeps both softmax rows in registers;
+// CT == 0 handles any class count by re-reading the rows (served by L1/L2).  Pixels below `npix_acc` already hold the
+// classification gradient and are accumulated into, the remaining pixels are overwritten.
+template <int CT>
+__global__ __launch_bounds__(256) void mt_consistency_kernel(const float* __restrict__ logits, const float* __restrict__ teacher,
+                                                             int64_t npix, int Cdyn, const float* __restrict__ coef_dev,
+                                                             float kscale, int64_t npix_acc, float* __restrict__ dlogits,
+                                                             double* __restrict__ part) {
+  const int C = CT > 0 ? CT : Cdyn;
+  const float coef = *coef_dev;
+  const float k = 2.f * coef * kscale;   // kscale = grad_scale / (C * npix)
+  float local = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    const float* zp = logits + p * C;
+    const float* tp = teacher + p * C;
+    if (CT > 0) {
+      float s[CT > 0 ? CT : 1], t[CT > 0 ? CT : 1];
+      if (CT % 4 == 0) {
+#pragma unroll
+        for (int j = 0; j < CT / 4; ++j) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(zp + 4 * j);
+          const f32x4 b = *reinterpret_cast<const f32x4*>(tp + 4 * j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { s[4 * j + q] = a[q]; t[4 * j + q] = b[q]; }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) { s[j] = zp[j]; t[j] = tp[j]; }
+      }
+      float ms = s[0], mt = t[0];
+#pragma unroll
+      for (int j = 1; j < CT; ++j) { ms = fmaxf(ms, s[j]); mt = fmaxf(mt, t[j]); }
+      float ss = 0.f, st = 0.f;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) { s[j] = __expf(s[j] - ms); ss += s[j]; t[j] = __expf(t[j] - mt); st += t[j]; }
+      const float is = 1.f / ss, it = 1.f / st;
+      float sq = 0.f, dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        s[j] *= is;
+        t[j] = s[j] - t[j] * it;          // d_j = s_j - t_j
+        sq += t[j] * t[j];
+        dot += t[j] * s[j];
+      }
+      local += sq;
+      if (dlogits) {
+        float* dp = dlogits + p * C;
+        const bool acc = p < npix_acc;
+        if (CT % 4 == 0) {
+#pragma unroll
+          for (int j = 0; j < CT / 4; ++j) {
+            f32x4 g;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) g[q] = k * s[4 * j + q] * (t[4 * j + q] - dot);
+            if (acc) {
+              const f32x4 o = *reinterpret_cast<const f32x4*>(dp + 4 * j);
+              g += o;
+            }
+            *reinterpret_cast<f32x4*>(dp + 4 * j) = g;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < CT; ++j) {
+            const float g = k * s[j] * (t[j] - dot);
+            dp[j] = acc ? dp[j] + g : g;
+          }
+        }
+      }
+    } else {
+      float ms = zp[0], mt = tp[0];
+      for (int j = 1; j < C; ++j) { ms = fmaxf(ms, zp[j]); mt = fmaxf(mt, tp[j]); }
+      float ss = 0.f, st = 0.f;
+      for (int j = 0; j < C; ++j) { ss += __expf(zp[j] - ms); st += __expf(tp[j] - mt); }
+      const float is = 1.f / ss, it = 1.f / st;
+      float sq = 0.f, dot = 0.f;
+      for (int j = 0; j < C; ++j) {
+        const float sj = __expf(zp[j] - ms) * is;
+        const float d = sj - __expf(tp[j] - mt) * it;
+        sq += d * d;
+        dot += d * sj;
+      }
+      local += sq;
+      if (dlogits) {
+        float* dp = dlogits + p * C;
+        const bool acc = p < npix_acc;
+        for (int j = 0; j < C; ++j) {
+          const float sj = __expf(zp[j] - ms) * is;
+          const float d = sj - __expf(tp[j] - mt) * it;
+          const float g = k * sj * (d - dot);
+          dp[j] = acc ? dp[j] + g : g;
+        }
+      }
+    }
+  }
+  __shared__ float red[4];
+  const float ws = wave_sum(local);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+}
+
+__global__ void mt_consistency_final(const double* __restrict__ part, int nblocks, double inv_count,
+                                     const float* __restrict__ coef_dev, int accumulate, float* __restrict__ loss_io,
+                                     float* __restrict__ cost_out) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[b];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float cost = (float)((double)*coef_dev * (sm[0] * inv_count));
+    if (cost_out) *cost_out = cost;
+    if (loss_io) *loss_io = accumulate ? *loss_io + cost : cost;
+  }
+}
+
+// teacher = a * teacher + (1 - a) * student, evaluated in this order (src/trainers.py:1704)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, const float* __restrict__ student, float a,
+                                                  float one_minus_a, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    teacher[i] = __fadd_rn(__fmul_rn(a, teacher[i]), __fmul_rn(one_minus_a, student[i]));
+}
+
 }  // namespace ssmi
 
 using namespace ssmi;
@@ -173,9 +307,9 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
   SSMI_REQUIRE(logits && labels && weights && loss_out && npix > 0, SSMI_E_INVALID_ARG, "softmax_xent: bad argument");
   SSMI_REQUIRE(num_classes >= 2 && num_classes <= 64, SSMI_E_UNSUPPORTED, "softmax_xent: num_classes %d outside [2,64]", num_classes);
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_softmax_xent_workspace_bytes(npix), SSMI_E_WORKSPACE, "softmax_xent: workspace too small");
-  SSMI_REQUIRE(npix_metrics >= 0 && npix_metrics <= npix, SSMI_E_INVALID_ARG, "softmax_xent: npix_metrics out of range");
+  SSMI_REQUIRE(npix_metrics >= 0, SSMI_E_INVALID_ARG, "softmax_xent: npix_metrics out of range");
   hipStream_t st = as_stream(stream);
-  int64_t nb64 = ceil_div64(npix, 256);
+  int64_t nb64 = ceil_div64(npix_metrics > npix ? npix_metrics : npix, 256);
   if (nb64 > kLossBlocks) nb64 = kLossBlocks;
   const int nb = (int)nb64;
   double* part = reinterpret_cast<double*>(ws);
@@ -191,6 +325,53 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
   }
   SSMI_LAUNCH_CHECK();
   hipLaunchKernelGGL(xent_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, loss_out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+size_t ssmi_mt_consistency_workspace_bytes(int64_t npix) {
+  (void)npix;
+  return (size_t)kLossBlocks * sizeof(double);
+}
+
+ssmi_status ssmi_mt_consistency_fwd_bwd(const float* logits, const float* teacher_logits, int64_t npix, int32_t num_classes,
+                                        const float* coef_dev, float grad_scale, int64_t npix_accumulate, float* dlogits,
+                                        float* loss_io, int32_t accumulate_loss, float* cost_out, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  SSMI_REQUIRE(logits && teacher_logits && coef_dev && npix > 0, SSMI_E_INVALID_ARG, "mt_consistency: bad argument");
+  SSMI_REQUIRE(num_classes >= 2 && num_classes <= 64, SSMI_E_UNSUPPORTED, "mt_consistency: num_classes %d outside [2,64]", num_classes);
+  SSMI_REQUIRE(npix_accumulate >= 0 && npix_accumulate <= npix, SSMI_E_INVALID_ARG, "mt_consistency: npix_accumulate out of range");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_mt_consistency_workspace_bytes(npix), SSMI_E_WORKSPACE, "mt_consistency: workspace too small");
+  hipStream_t st = as_stream(stream);
+  int64_t nb64 = ceil_div64(npix, 256);
+  if (nb64 > kLossBlocks) nb64 = kLossBlocks;
+  const int nb = (int)nb64;
+  double* part = reinterpret_cast<double*>(ws);
+  const double inv_count = 1.0 / ((double)npix * (double)num_classes);
+  const float kscale = (float)((double)grad_scale * inv_count);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(teacher_logits) |
+                         reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
+  if (num_classes == 24 && aligned) {
+    hipLaunchKernelGGL((mt_consistency_kernel<24>), dim3(nb), dim3(256), 0, st, logits, teacher_logits, npix, num_classes,
+                       coef_dev, kscale, npix_accumulate, dlogits, part);
+  } else {
+    hipLaunchKernelGGL((mt_consistency_kernel<0>), dim3(nb), dim3(256), 0, st, logits, teacher_logits, npix, num_classes,
+                       coef_dev, kscale, npix_accumulate, dlogits, part);
+  }
+  SSMI_LAUNCH_CHECK();
+  hipLaunchKernelGGL(mt_consistency_final, dim3(1), dim3(256), 0, st, part, nb, inv_count, coef_dev, accumulate_loss, loss_io,
+                     cost_out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_ema_update(float* teacher, const float* student, double a, int64_t count, void* stream) {
+  SSMI_REQUIRE(teacher && student && count >= 0, SSMI_E_INVALID_ARG, "ema_update: bad argument");
+  if (count == 0) return SSMI_OK;
+  int64_t nb = ceil_div64(count, 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(ema_kernel, dim3((int)nb), dim3(256), 0, as_stream(stream), teacher, student, (float)a,
+                     (float)(1.0 - a), count);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }

@@ -38,13 +38,21 @@ class LayerInfo:
 
 class ExtendedModel(object):
 
-    def __init__(self, name: str, graph: ENetGraph, input_shape, num_classes: int, lambda_loss: bool):
+    def __init__(self, name: str, graph: ENetGraph, input_shape, num_classes: int, lambda_loss: bool,
+                 mean_teacher: bool = False):
         self.name = name
         self.graph = graph
         self.input_shape = tuple(input_shape)
         self.num_classes = num_classes
         self.lambda_loss = lambda_loss
+        # student of the mean-teacher method (src/models.py:188-190, src/losses.py:377-436): two more inputs, the
+        # teacher's logits and the consistency-cost coefficient, and a loss over labeled + unlabeled rows
+        self.mean_teacher = bool(mean_teacher and lambda_loss)
         self.input_names = ["images"] + (["labels", "class_weights", "num_unlabeled"] if lambda_loss else [])
+        if self.mean_teacher:
+            self.input_names += ["mt_predictions", "consistency_cost"]
+        self._num_labeled = None
+        self.mt_buf = self.coef_buf = self._cost_buf = None
         self.output_names = (["loss", "logits"] if lambda_loss else ["logits"])
         self.optimizer = None
         self.metrics = None
@@ -229,6 +237,11 @@ class ExtendedModel(object):
         self.images_buf = torch.zeros(n, h, w, 3, dtype=torch.float32, device=dev)
         self.labels_buf = torch.zeros(n, h, w, dtype=torch.int32, device=dev)
         self.weights_buf = torch.zeros(n, h, w, dtype=torch.float32, device=dev)
+        if self.mean_teacher:
+            self.mt_buf = torch.zeros(n, h, w, self.num_classes, dtype=torch.float32, device=dev)
+            self.coef_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._cost_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._num_labeled = n
         self.graph.plan(n, h, w)
         self._bufs_shape = (n, h, w)
         self._graphs.clear()
@@ -253,7 +266,20 @@ class ExtendedModel(object):
             self._to_dev(self.weights_buf, x[2])
             nu = x[3]
             nu = int(nu.reshape(-1)[0].item() if torch.is_tensor(nu) else np.asarray(nu).reshape(-1)[0])
-            if nu != 0:
+            if self.mean_teacher:
+                if len(x) != 6:
+                    raise ValueError('Expected 6 inputs {}, got: {}'.format(self.input_names, len(x)))
+                if not 0 <= nu < n:
+                    raise ValueError("num_unlabeled must lie in [0, batch): the classification cost needs a labeled row")
+                self._num_labeled = n - nu
+                if nu:
+                    # the metrics see zero labels on the unlabeled rows (src/generators.py:1764-1766)
+                    self.labels_buf[n - nu:].zero_()
+                self._to_dev(self.mt_buf, x[4])
+                cf = x[5]
+                cf = float(cf.reshape(-1)[0].item() if torch.is_tensor(cf) else np.asarray(cf).reshape(-1)[0])
+                self.coef_buf.fill_(cf)      # src/losses.py:413: element 0 of the per-row coefficient vector
+            elif nu != 0:
                 # src/losses.py:327-329,369 slices only the weights; logits/labels keep the full batch, so the
                 # reference's own graph is shape-inconsistent for num_unlabeled > 0 in the supervised loss
                 raise ValueError("the supervised lambda loss requires num_unlabeled == 0")
@@ -268,7 +294,20 @@ class ExtendedModel(object):
         npix = n * h * w
         C_ = self.num_classes
 
+        def loss_call_mt(st, want_grad):
+            # classification cost over the labeled rows, metrics over every row, then the consistency cost over
+            # every row added to the loss and to the gradient (src/losses.py:416-431)
+            npl = self._num_labeled * h * w
+            dl = _ptr(g.dlogits) if want_grad else None
+            L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npl, C_, 1.0, dl,
+                                   _ptr(self._loss_buf), _ptr(self._cm), npix, self._ignore_bits, None, _ptr(self._bad),
+                                   _ptr(g.ws), g.ws.numel() * 4, st)
+            L.mt_consistency_fwd_bwd(_ptr(g.logits), _ptr(self.mt_buf), npix, C_, _ptr(self.coef_buf), 1.0, npl, dl,
+                                     _ptr(self._loss_buf), 1, _ptr(self._cost_buf), _ptr(g.ws), g.ws.numel() * 4, st)
+
         def loss_call(st, want_grad):
+            if self.mean_teacher:
+                return loss_call_mt(st, want_grad)
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npix, C_, 1.0,
                                    _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), _ptr(self._cm), npix,
                                    self._ignore_bits, None, _ptr(self._bad), _ptr(g.ws), g.ws.numel() * 4, st)
@@ -325,7 +364,7 @@ class ExtendedModel(object):
         return [(cut, st.theta.numel()), (0, cut)]
 
     def _run(self, training: bool):
-        key = (training, self._bufs_shape, self.grad_sync is not None)
+        key = (training, self._bufs_shape, self.grad_sync is not None, self._num_labeled)
         stream = torch.cuda.current_stream()
         st = stream.cuda_stream
         segs = self._segments(training)
@@ -420,6 +459,37 @@ class ExtendedModel(object):
             self.graph.refresh_dropout(self.seed + 1, blk, stream=st)
         self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
         return self.graph.logits.detach().cpu().numpy()
+
+    def predict_on_batch_device(self, x, use_training_phase_layers=False) -> torch.Tensor:
+        """predict_on_batch without the host round trip: returns the graph's logits buffer (device, [n, h, w, classes]),
+        valid until this model's next forward pass.  The mean-teacher trainer hands it straight to the student."""
+        images = x[0] if isinstance(x, (list, tuple)) else x
+        n, h, w = int(images.shape[0]), int(images.shape[1]), int(images.shape[2])
+        self._ensure_buffers(n, h, w)
+        self._to_dev(self.images_buf, images)
+        st = torch.cuda.current_stream().cuda_stream
+        if use_training_phase_layers and self.graph.drop_groups:
+            blk = self.optimizer.step_block if self.optimizer is not None else None
+            self.graph.refresh_dropout(self.seed + 1, blk, stream=st)
+        self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
+        return self.graph.logits
+
+    def ema_update_from(self, student: "ExtendedModel", a: float):
+        """Teacher update of the mean-teacher method (src/trainers.py:1692-1706) over EVERY weight get_weights()
+        lists - trainable ones and the BN moving statistics - as two launches over the flat arenas."""
+        ts, ss = self.graph.store, student.graph.store
+        if list(ts.specs.keys()) != list(ss.specs.keys()) or ts.theta.numel() != ss.theta.numel():
+            raise ValueError('The weight arrays are not of the same length for the student and teacher: {} vs {}'.format(
+                len(ts.specs), len(ss.specs)))
+        L = lib()
+        st = torch.cuda.current_stream().cuda_stream
+        L.ema_update(_ptr(ts.theta), _ptr(ss.theta), float(a), ts.n_train, st)
+        if ts.n_state:
+            L.ema_update(_ptr(ts.state), _ptr(ss.state), float(a), ts.n_state, st)
+
+    def consistency_cost(self) -> float:
+        """The consistency term of the last step's loss (0 for models without the mean-teacher loss)."""
+        return float(self._cost_buf.item()) if self._cost_buf is not None else 0.0
 
     def predict(self, x, batch_size=None, verbose=0):
         images = x[0] if isinstance(x, (list, tuple)) else x

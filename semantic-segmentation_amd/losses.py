@@ -85,6 +85,46 @@ def segmentation_categorical_cross_entropy_lambda_loss(args):
     return _xent(y_pred, y_true, weights)
 
 
+def _consistency(y_pred, mt_pred, coefficient: float, dlogits, npix_accumulate: int, loss: torch.Tensor):
+    """Adds coefficient * mean((softmax(mt_pred) - softmax(y_pred))^2) (src/losses.py:195-215) to `loss` and its
+    gradient to `dlogits`."""
+    if tuple(mt_pred.shape) != tuple(y_pred.shape):
+        raise ValueError("mt_pred {} and y_pred {} must have the same shape".format(tuple(mt_pred.shape), tuple(y_pred.shape)))
+    L = lib()
+    y_pred = y_pred.contiguous().float()
+    mt_pred = mt_pred.contiguous().float()
+    C = y_pred.shape[-1]
+    npix = y_pred.numel() // C
+    ws = torch.empty(L.mt_consistency_workspace_bytes(npix) // 4 + 4, dtype=torch.float32, device=y_pred.device)
+    coef = torch.full((1,), float(coefficient), dtype=torch.float32, device=y_pred.device)
+    lbuf = loss.reshape(1)
+    st = torch.cuda.current_stream().cuda_stream
+    L.mt_consistency_fwd_bwd(y_pred.data_ptr(), mt_pred.data_ptr(), npix, C, coef.data_ptr(), 1.0, npix_accumulate,
+                             None if dlogits is None else dlogits.data_ptr(), lbuf.data_ptr(), 1, None, ws.data_ptr(),
+                             ws.numel() * 4, st)
+    return loss
+
+
+def segmentation_mean_teacher_lambda_loss(args):
+    """src/losses.py:377-436.  args = [logits BxHxWxC, labels BxHxW int32, weights BxHxW, num_unlabeled Bx1 int32,
+    mt_pred BxHxWxC (teacher logits), cons_coefficient Bx1].  Classification cost over the first B - num_unlabeled rows,
+    consistency cost over every row."""
+    y_pred, y_true, weights_labeled, num_unlabeled, num_labeled = _preprocess_segmentation_lambda_loss_args(args, 6)
+    mt_pred, coef = args[4], args[5]
+    if mt_pred.dim() != y_pred.dim() or coef.dim() != 2:
+        raise ValueError("rank mismatch: mt_pred must have the rank of y_pred, cons_coefficient rank 2")
+    if num_labeled <= 0:
+        raise ValueError("the classification cost needs at least one labeled row")
+    y_pred = y_pred.contiguous().float()
+    loss = _xent(y_pred[0:num_labeled], y_true[0:num_labeled], weights_labeled)
+    dl = torch.zeros_like(y_pred)
+    dl[0:num_labeled].copy_(_last["dlogits"])
+    npl = num_labeled * y_pred.shape[1] * y_pred.shape[2]
+    _consistency(y_pred, mt_pred, float(coef.reshape(-1)[0].item()), dl, npl, loss)
+    _last["dlogits"] = dl
+    return loss
+
+
 def segmentation_sparse_weighted_categorical_cross_entropy(class_weights):
     """src/losses.py:334-338 (+268-307): y_true BxHxWx1, per-pixel weights = class_weights[y_true]."""
     if class_weights is None:

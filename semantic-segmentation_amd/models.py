@@ -26,8 +26,10 @@ def get_lambda_loss_function(model_lambda_loss_type):
         return None
     if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY:
         return losses.segmentation_categorical_cross_entropy_lambda_loss
+    if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER:
+        return losses.segmentation_mean_teacher_lambda_loss
     if isinstance(model_lambda_loss_type, ModelLambdaLossType):
-        raise NotImplementedError('lambda loss type {} is outside the supervised hot path'.format(model_lambda_loss_type))
+        raise NotImplementedError('lambda loss type {} is not implemented (superpixel / classification losses)'.format(model_lambda_loss_type))
     raise ValueError('Unknown model lambda loss type: {}'.format(model_lambda_loss_type))
 
 
@@ -62,10 +64,11 @@ class ModelBase(object):
             raise ValueError('input_shape must be (H|None, W|None, 3), got {}'.format(self.input_shape))
         self.device = device
         graph = self._build_model()
-        lambda_loss = model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY
+        mean_teacher = model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER
+        lambda_loss = mean_teacher or model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY
         if lambda_loss:
-            self.name = self.name + '-CCE'
-        self._model = ExtendedModel(self.name, graph, self.input_shape, num_classes, lambda_loss)
+            self.name = self.name + ('-MT' if mean_teacher else '-CCE')      # src/models.py:185-190
+        self._model = ExtendedModel(self.name, graph, self.input_shape, num_classes, lambda_loss, mean_teacher=mean_teacher)
 
     @property
     def model(self):

@@ -118,8 +118,10 @@ class SegmentationTrainer(object):
                  num_classes: int = 24, device=None):
         from . import models, losses, metrics
         from .keras_extensions import extended_optimizers as xo
-        if trainer_type != "segmentation_supervised":
-            raise NotImplementedError("trainer type {} is outside the supervised hot path".format(trainer_type))
+        if trainer_type not in ("segmentation_supervised", "segmentation_supervised_mean_teacher",
+                                "segmentation_semi_supervised_mean_teacher"):
+            raise NotImplementedError("trainer type {} is not implemented (superpixel / classification trainers)".format(trainer_type))
+        self.trainer_type = trainer_type
         if config is None:
             with open(config_file_path) as f:
                 config = json.load(f)
@@ -133,14 +135,19 @@ class SegmentationTrainer(object):
         self.ignore_classes = list(config.get("ignore_classes", [0]))
         self.num_epochs = int(config.get("num_epochs", 1))
         self.num_labeled_per_batch = int(config.get("num_labeled_per_batch", 16))
+        self.num_unlabeled_per_batch = int(config.get("num_unlabeled_per_batch", 0)) if trainer_type.startswith("segmentation_semi") else 0
+        self.mean_teacher_method_config = config.get("mean_teacher_params") or config.get("mean_teacher_method_config")
+        self.teacher_model = None
+        self._ema_fn = self._cons_fn = None
         cw = config.get("override_class_weights")
         if cw is None or not config.get("use_class_weights", True):
             cw = np.ones(num_classes, dtype=np.float32)
             for c in self.ignore_classes:
                 cw[c] = 0.0   # src/trainers.py:2047-2053
         self.class_weights = np.asarray(cw, dtype=np.float32)
-        mb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes,
-                              losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, device=self.device)
+        ltype = (losses.ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER if self.using_mean_teacher_method
+                 else losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
+        mb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes, ltype, device=self.device)
         self.model_wrapper = mb
         self.model = mb.model
         self.model.seed = self.random_seed + self.rank   # independent dropout draws per replica
@@ -166,13 +173,117 @@ class SegmentationTrainer(object):
             st = self.model.graph.store
             self.reducer.broadcast_([st.theta, st.state], src=0)
             self.model.grad_sync = self.reducer
+        if self.using_mean_teacher_method:
+            # src/trainers.py:1460-1520: the teacher has the student's topology without the lambda loss, starts from the
+            # student's weights and is never trained; compile gives it the supervised loss + metrics for validation.
+            # Every replica derives the same teacher: the students are identical after each all-reduced step.
+            tb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes,
+                                  losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, device=self.device)
+            self.teacher_model_wrapper = tb
+            self.teacher_model = tb.model
+            self.teacher_model.seed = self.random_seed + 7919 + self.rank
+            ts, ss = self.teacher_model.graph.store, self.model.graph.store
+            ts.theta.copy_(ss.theta)
+            ts.state.copy_(ss.state)
+            self.teacher_model.compile(optimizer=xo.SGD(lr=0.0), loss={'loss': losses.dummy_loss, 'logits': lambda _, y_pred: 0.0 * y_pred},
+                                       loss_weights={'loss': 1.0, 'logits': 0.0},
+                                       metrics={'logits': [metrics.segmentation_accuracy(0, ic), metrics.segmentation_mean_iou(num_classes, 0, ic),
+                                                           metrics.segmentation_mean_per_class_accuracy(num_classes, 0, ic),
+                                                           metrics.segmentation_confusion_matrix(num_classes, 0, ic)]})
+
+    @property
+    def using_mean_teacher_method(self):
+        return self.trainer_type.endswith("mean_teacher")
+
+    @staticmethod
+    def _schedule(spec):
+        """The reference's configs give the schedules as Python lambda source ("lambda x: 0.99 if x < 40000 else
+        0.999", src/trainers.py:1568-1583 evaluates them); callables and plain numbers are accepted too.  The source is
+        evaluated with numpy and a few arithmetic builtins only."""
+        if callable(spec):
+            return spec
+        if isinstance(spec, (int, float)):
+            return lambda step, v=float(spec): v
+        env = {"__builtins__": {}, "np": np, "min": min, "max": max, "float": float, "int": int, "abs": abs, "pow": pow}
+        fn = eval(spec, env)     # noqa: S307 - configuration supplied by the user running the training
+        if not callable(fn):
+            raise ValueError("schedule '{}' does not evaluate to a function".format(spec))
+        return fn
+
+    @property
+    def ema_smoothing_coefficient_function(self):
+        if self.using_mean_teacher_method and self._ema_fn is None:
+            self._ema_fn = self._schedule((self.mean_teacher_method_config or {}).get('ema_smoothing_coefficient_function', 0.99))
+        return self._ema_fn
+
+    @property
+    def consistency_cost_coefficient_function(self):
+        if self.using_mean_teacher_method and self._cons_fn is None:
+            self._cons_fn = self._schedule((self.mean_teacher_method_config or {}).get('consistency_cost_coefficient_function', 1.0))
+        return self._cons_fn
 
     # hooks of the reference's engine (src/trainers.py:1314-1334)
     def modify_batch_data(self, step_index, x, y, validation=False):
-        return x, y
+        """src/trainers.py:1620-1664, 1822-1867: for a mean-teacher student the teacher's images (last input of a training
+        batch, the student's own images when validating) are replaced by the teacher's logits, predicted with the
+        training-phase layers active, followed by the per-row consistency coefficient; validation batches get zeros."""
+        if not self.using_mean_teacher_method:
+            return x, y
+        x = list(x)
+        img_batch = x[0]
+        n = int(img_batch.shape[0])
+        if not validation:
+            teacher_img_batch, x = x[-1], x[:-1]
+        else:
+            teacher_img_batch = img_batch
+        if len(x) != 4:
+            raise ValueError("expected [images, labels, class_weights, num_unlabeled(, teacher_images)], got {} inputs".format(len(x) + (0 if validation else 1)))
+        if self.teacher_model is None:
+            raise ValueError('Teacher model is not set, cannot run predictions')
+        if validation:
+            shape = tuple(int(v) for v in img_batch.shape[0:-1]) + (self.num_classes,)
+            mt = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            coef = np.zeros([n, 1], dtype=np.float32)
+        else:
+            mt = self.teacher_model.predict_on_batch_device(teacher_img_batch, use_training_phase_layers=True)
+            coef = np.ones([n, 1], dtype=np.float32) * float(self.consistency_cost_coefficient_function(step_index))
+        return x + [mt, coef], y
 
     def on_batch_end(self, step_index):
-        pass
+        """src/trainers.py:1666-1707: exponential moving average of the student's weights into the teacher."""
+        if not self.using_mean_teacher_method:
+            return
+        if self.teacher_model is None:
+            raise ValueError('Teacher model is not set, cannot run EMA update')
+        a = float(self.ema_smoothing_coefficient_function(step_index))
+        self.teacher_model.ema_update_from(self.model, a)
+
+    def evaluate_teacher(self, generator, steps) -> Dict[str, object]:
+        """src/trainers.py:1734-1743: the teacher on the validation data (supervised loss + metrics), sharded and
+        reduced like `evaluate`."""
+        from . import metrics
+        m = self.teacher_model
+        m.reset_metrics()
+        get = generator.__next__ if hasattr(generator, "__next__") else None
+        loss_sum, count = 0.0, 0
+        for b in range(steps):
+            batch = get() if get else generator.get_batch(0, b)
+            x = list(batch[0])[:4]
+            outs = m.test_on_batch(x, batch[1])
+            n = int(x[0].shape[0])
+            loss_sum += float(outs[0]) * n
+            count += n
+        cm, loss, images = all_reduce_evaluation(m._cm, loss_sum, count, self.reducer.group if self.reducer else None)
+        out = {"loss": loss, "images": images, "confusion_matrix": cm}
+        out.update(metrics.metrics_from_confusion_matrix(cm, self.ignore_classes))
+        return out
+
+    def save_teacher_model_weights(self, file_path):
+        """src/trainers.py:1770-1803 (the path template handling stays with the caller)."""
+        if self.teacher_model is None:
+            raise ValueError('Teacher model is not set, cannot save teacher model weights')
+        os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
+        self.teacher_model.save(file_path, overwrite=True, include_optimizer=True)
 
     def on_epoch_end(self, epoch_index, step_index, logs):
         pass

@@ -9,7 +9,8 @@ target that does not depend on re-running the oracle); they are not outputs of t
 Files (all float64 unless noted; inputs are regenerated from the recorded seeds where they are large):
   ops.npz        per-operator cases: SAME stride-2 convolution, dilated convolution, transposed convolution,
                  BN training statistics, max-pool with argmax (with ties), unpooling, weighted cross entropy,
-                 confusion matrix, metrics, three Adam steps, three SGD(momentum, nesterov) steps
+                 confusion matrix, metrics, three Adam steps, three SGD(momentum, nesterov) steps, the mean-teacher
+                 lambda loss with one unlabeled row, the teacher's EMA update
   step_<model>.npz  one supervised training step of every model at a tiny shape: loss, logits, dlogits,
                  confusion matrix, per-tensor gradient checksums (sum, sum of squares) and a few full gradients
 """
@@ -120,6 +121,22 @@ def make_ops():
         K.sgd_step(ps, [t(g) for g in gs[it]], mo, it, lr=0.01, momentum=0.9, decay=1e-3, nesterov=True,
                    lr_scalers={1: 0.5})
     out["sgd_p3_a"], out["sgd_p3_b"] = ps[0].numpy(), ps[1].numpy()
+    # mean-teacher lambda loss: 3 rows, the last one unlabeled; EMA of the teacher weights
+    logits = rng.standard_normal((3, 4, 4, 24)) * 2
+    teacher = rng.standard_normal((3, 4, 4, 24)) * 2
+    labels = rng.randint(0, 24, size=(3, 4, 4))
+    wts = cw[labels]
+    lg = t(logits).requires_grad_(True)
+    loss = K.segmentation_mean_teacher_lambda_loss(lg, torch.tensor(labels), t(wts), 1, t(teacher), 3.5)
+    (dl,) = torch.autograd.grad(loss, [lg])
+    out["mt_logits"], out["mt_teacher"], out["mt_labels"], out["mt_weights"] = logits, teacher, labels.astype(np.int64), wts
+    out["mt_loss"], out["mt_dlogits"] = np.float64(loss.item()), dl.numpy()
+    out["mt_cost"] = np.float64(K.mean_teacher_consistency_cost(t(logits), t(teacher), 3.5).item())
+    tw = [rng.standard_normal(11).astype(np.float32), rng.standard_normal((2, 3)).astype(np.float32)]
+    sw = [rng.standard_normal(11).astype(np.float32), rng.standard_normal((2, 3)).astype(np.float32)]
+    ew = K.ema_update_np(tw, sw, 0.99)
+    out["ema_t_a"], out["ema_t_b"], out["ema_s_a"], out["ema_s_b"] = tw[0], tw[1], sw[0], sw[1]
+    out["ema_out_a"], out["ema_out_b"] = ew[0], ew[1]
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
     print("ops.npz", len(out), "arrays")
 
@@ -158,5 +175,6 @@ def make_step(model):
 
 if __name__ == "__main__":
     make_ops()
-    for m in STEP_CASES:
-        make_step(m)
+    if "--ops-only" not in sys.argv:
+        for m in STEP_CASES:
+            make_step(m)

@@ -48,6 +48,17 @@ def test_ops_fixture_matches_oracle():
     lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
     ce = lse - np.take_along_axis(lg, lab[..., None], -1)[..., 0]
     assert abs((w * ce).mean() - float(g["xent_loss"])) < 1e-12
+    # mean-teacher loss by hand: CE averaged over the pixels of the 2 labeled rows + 3.5 * mean squared softmax difference
+    lg, tl, lab, w = g["mt_logits"], g["mt_teacher"], g["mt_labels"], g["mt_weights"]
+    sm = lambda z: np.exp(z - z.max(-1, keepdims=True)) / np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)
+    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
+    ce = (lse - np.take_along_axis(lg, lab[..., None], -1)[..., 0]) * w
+    cost = 3.5 * ((sm(lg) - sm(tl)) ** 2).mean()
+    assert abs(cost - float(g["mt_cost"])) < 1e-12
+    assert abs(ce[:2].mean() + cost - float(g["mt_loss"])) < 1e-12
+    for s_ in "ab":
+        ew = np.float32(0.99) * g["ema_t_" + s_] + np.float32(1.0 - 0.99) * g["ema_s_" + s_]
+        assert ew.dtype == np.float32 and np.array_equal(ew, g["ema_out_" + s_])
 
 
 @pytest.mark.parametrize("model", ["enet-naive-upsampling", "enet-max-unpooling", "enet-naive-upsampling-enhanced", "segnet"])

@@ -196,3 +196,31 @@ def test_input_contract_known_answers():
     assert np.array_equal(y, [[[1, 2]], [[7, 20]]])
     w = O.create_batch_weights(y, np.array([0.0, 0.25, 4.0], dtype=np.float32), num_labeled=1)
     assert np.array_equal(w, [[[0.25, 4.0]], [[1.0, 1.0]]])
+
+
+def test_mean_teacher_consistency_and_loss_known_answers():
+    """src/losses.py:195-215, 377-436 on values worked by hand: student softmax (1/2, 1/2), teacher (3/4, 1/4)."""
+    y = torch.zeros(2, 1, 1, 2, dtype=torch.float64)
+    t_ = torch.tensor([np.log(3.0), 0.0], dtype=torch.float64).expand(2, 1, 1, 2)
+    c = K.mean_teacher_consistency_cost(y, t_, 2.0)
+    assert abs(float(c) - 2.0 * 0.0625) < 1e-15
+    # one labeled row (label 1, weight 3: CE = 3 ln 2, averaged over that single pixel), one unlabeled row
+    lab = torch.tensor([[[1]], [[0]]])
+    w = torch.tensor([[[3.0]], [[7.0]]], dtype=torch.float64)
+    loss = K.segmentation_mean_teacher_lambda_loss(y, lab, w, 1, t_, 2.0)
+    assert abs(float(loss) - (3.0 * np.log(2.0) + 0.125)) < 1e-14
+    # gradient of the consistency cost w.r.t. the student's logits: 2*coef/(C*N) * s_j * (d_j - sum_c d_c s_c)
+    yy = y.clone().requires_grad_(True)
+    (g,) = torch.autograd.grad(K.mean_teacher_consistency_cost(yy, t_, 2.0), [yy])
+    d = np.array([-0.25, 0.25])
+    exp = 2 * 2.0 / (2 * 2) * 0.5 * (d - (d * 0.5).sum())
+    np.testing.assert_allclose(g[0, 0, 0].numpy(), exp, rtol=1e-14, atol=1e-16)
+    # no gradient reaches the teacher's logits
+    tt = t_.clone().requires_grad_(True)
+    assert not K.mean_teacher_consistency_cost(y, tt, 2.0).requires_grad
+
+
+def test_ema_update_known_answer():
+    """src/trainers.py:1704 keeps float32: a*t + (1-a)*s with a Python float."""
+    out = K.ema_update_np([np.array([1.0, -2.0], np.float32)], [np.array([2.0, 4.0], np.float32)], 0.75)
+    assert out[0].dtype == np.float32 and np.array_equal(out[0], np.array([1.25, -0.5], np.float32))
