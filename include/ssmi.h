@@ -338,6 +338,30 @@ ssmi_status ssmi_preprocess_batch(const uint8_t* images, const uint8_t* masks, c
                                   int32_t* Y, float* W, int32_t* bad, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
+ * Full-image inference around the network (src/predict.py:86-125 PredictionImage, :465-527 main).
+ *   ssmi_predict_prepare   : uint8 image [h,w,3] -> X float32 [hp,wp,3]: the normalised image (same arithmetic as
+ *                            ssmi_preprocess_batch) at rows v_pad_before.., columns h_pad_before..; every other pixel =
+ *                            cval3 (device float[3], nullable = 0).  The reference pads after normalising, with the data
+ *                            set's per-channel mean as fill (src/predict.py:115-124, src/utils/image_utils.py:1400-1434).
+ *   ssmi_predict_accumulate: crops [v_pad_before : +h, h_pad_before : +w] out of a prediction [hp,wp,classes]
+ *                            (src/predict.py:484-490), multiplies class 0 by bg_weight (:524) and writes (accumulate = 0)
+ *                            or adds (accumulate = 1) it to acc [h,w,classes]; the sum runs in the order numpy's mean over
+ *                            the stacked predictions uses (:527).
+ *   ssmi_predict_topk      : mean_out (nullable) = acc / count; topk (nullable, int32 [k, npix]) = the k best classes per
+ *                            pixel by descending mean (src/utils/prediction_utils.py:95-99); equal values rank the lower
+ *                            class first.
+ * ---------------------------------------------------------------------------------------------------- */
+ssmi_status ssmi_predict_prepare(const uint8_t* image, const float* mean3, const float* std3, int32_t h, int32_t w,
+                                 int32_t v_pad_before, int32_t h_pad_before, int32_t hp, int32_t wp, const float* cval3,
+                                 float* X, void* stream);
+ssmi_status ssmi_predict_accumulate(const float* pred, int32_t hp, int32_t wp, int32_t num_classes, int32_t v_pad_before,
+                                    int32_t h_pad_before, int32_t h, int32_t w, float bg_weight, int32_t accumulate, float* acc,
+                                    void* stream);
+ssmi_status ssmi_predict_topk(const float* acc, int64_t npix, int32_t num_classes, int32_t count, int32_t k, float* mean_out,
+                              int32_t* topk, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------------
  * HIP graph capture of a whole training step (replaces the one tf.Session.run per step of
  * ExtendedModel.train_on_batch, src/keras_extensions/extended_model.py:1002).
  * ---------------------------------------------------------------------------------------------------- */

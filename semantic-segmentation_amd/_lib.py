@@ -91,6 +91,9 @@ _PROTOS = {
     "ssmi_copy_ld": (_i32, [_vp, _i32, _vp, _i32, _i64, _i32, _i32, _vp]),
     "ssmi_scale_nc": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _vp]),
     "ssmi_preprocess_batch": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "ssmi_predict_prepare": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssmi_predict_accumulate": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "ssmi_predict_topk": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssmi_graph_begin_capture": (_i32, [_vp]),
     "ssmi_graph_end_capture": (_i32, [_vp, C.POINTER(_vp)]),
     "ssmi_graph_launch": (_i32, [_vp, _vp]),
