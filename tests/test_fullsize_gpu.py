@@ -1,0 +1,132 @@
+"""Properties that hold at the benchmark's full sizes (ENet, 24 classes, 512x512 batch 16 training; 1024x1024 inference),
+where the CPU oracle would take minutes per step.  All of them are exact (bit for bit / integer equality):
+
+  * replay determinism: the step launched eagerly and the same step replayed from captured HIP graphs (weight gradients
+    overlapped on the side stream) give identical losses, gradients and updated weights;
+  * linearity in the pixel weights: doubling every weight doubles the loss and every gradient exactly (a power-of-two
+    scale commutes with every rounding in the backward pass) and leaves the BN statistics and the matrix untouched;
+  * the confusion matrix accounts for every pixel whose label is not ignored, rows of ignored labels stay empty;
+  * pooling indices (src/layers/pooling.py:34-50) lie inside their 2x2 window, address the maximum, and unpooling
+    puts the pooled value back at exactly that position;
+  * inference is independent of the batch composition: an image predicted inside a batch of 4 and alone gives identical logits.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import enet_oracle as E
+
+pytestmark = pytest.mark.gpu
+NC = 24
+
+
+def _build(name, seed=3):
+    models, losses, metrics, opt = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
+    mb = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
+    m = mb.model
+    m.graph.store.init_values(seed)
+    m.compile(optimizer=opt.Adam(lr=5e-4), loss={'loss': losses.dummy_loss, 'logits': lambda t, p: 0 * p},
+              loss_weights={'loss': 1.0, 'logits': 0.0},
+              metrics={'logits': [metrics.segmentation_accuracy(0, [0]), metrics.segmentation_mean_iou(NC, 0, [0]),
+                                  metrics.segmentation_mean_per_class_accuracy(NC, 0, [0]),
+                                  metrics.segmentation_confusion_matrix(NC, 0, [0])]})
+    return m
+
+
+def _snapshot(m):
+    st = m.graph.store
+    return st.theta.clone(), st.state.clone(), st.grad.clone()
+
+
+def _restore(m, snap, opt_snap):
+    st = m.graph.store
+    st.theta.copy_(snap[0])
+    st.state.copy_(snap[1])
+    for k, t in m.optimizer.slot_tensors().items():
+        t.copy_(opt_snap[k])
+    m.optimizer.set_iterations(0)
+    m.reset_metrics()
+
+
+@pytest.mark.parametrize("name,B", [("enet-naive-upsampling", 16), ("enet-max-unpooling", 16), ("segnet", 4), ("unet", 4)])
+def test_full_size_training_step_properties(name, B):
+    H, W = 512, 512
+    m = _build(name)
+    cw = np.ones(NC, dtype=np.float32)
+    cw[0] = 0
+    cw[1:] = 0.5 + np.arange(1, NC) / 23.0
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=77, block=32, class_weights=cw)
+    x = [torch.from_numpy(images).cuda(), torch.from_numpy(labels).cuda(), torch.from_numpy(pw).cuda(), np.zeros((B, 1), np.int32)]
+    snap = _snapshot(m)
+    opt_snap = {k: t.clone() for k, t in m.optimizer.slot_tensors().items()}
+    stream = torch.cuda.Stream()
+    runs = {}
+    for mode in ("eager", "graph", "graph2", "double"):
+        _restore(m, snap, opt_snap)
+        m.use_hip_graph = mode != "eager"
+        xx = list(x)
+        if mode == "double":
+            xx[2] = x[2] * 2.0
+        with torch.cuda.stream(stream):
+            outs = m.train_on_batch(xx, None)
+        torch.cuda.synchronize()
+        st = m.graph.store
+        runs[mode] = dict(loss=outs[0], cm=outs[6].copy(), grad=st.grad.clone(), theta=st.theta.clone(), state=st.state.clone(),
+                          dlogits=m.graph.dlogits.clone())
+    a = runs["eager"]
+    assert np.isfinite(a["loss"]) and a["loss"] > 0
+    for other in ("graph", "graph2"):
+        b = runs[other]
+        assert a["loss"] == b["loss"], "loss differs between eager launch and graph replay"
+        assert torch.equal(a["grad"], b["grad"]) and torch.equal(a["theta"], b["theta"]) and torch.equal(a["state"], b["state"])
+        assert np.array_equal(a["cm"], b["cm"])
+    d = runs["double"]
+    assert d["loss"] == np.float32(a["loss"]) * np.float32(2.0)
+    assert torch.equal(d["dlogits"], a["dlogits"] * 2.0)
+    assert torch.equal(d["grad"], a["grad"] * 2.0), "gradients are not linear in the pixel weights"
+    assert torch.equal(d["state"], a["state"]) and np.array_equal(d["cm"], a["cm"])
+    # confusion matrix bookkeeping
+    cm = a["cm"]
+    assert cm.dtype == np.int64 and int(cm.sum()) == int((labels != 0).sum()) and int(cm[0].sum()) == 0
+    assert np.array_equal(cm.sum(axis=1), np.bincount(labels.reshape(-1), minlength=NC) * (np.arange(NC) != 0))
+    if name == "enet-max-unpooling":
+        g = m.graph
+        blk = g.by_name["en_bn_1.0"]
+        idx = blk.idx.long()                     # [B, H/4, W/4, C] flat (y*W + x)*C + c into the block's input
+        n, h2, w2, c = idx.shape
+        hin, win = 2 * h2, 2 * w2
+        ch = idx % c
+        xx_ = (idx // c) % win
+        yy_ = idx // (c * win)
+        ar_c = torch.arange(c, device="cuda").view(1, 1, 1, c)
+        ar_y = torch.arange(h2, device="cuda").view(1, h2, 1, 1)
+        ar_x = torch.arange(w2, device="cuda").view(1, 1, w2, 1)
+        assert bool((ch == ar_c).all()) and bool(((yy_ >> 1) == ar_y).all()) and bool(((xx_ >> 1) == ar_x).all())
+        assert int(idx.max()) < hin * win * c and int(idx.min()) >= 0
+
+
+def test_full_size_inference_is_batch_independent():
+    m = _build("enet-naive-upsampling", seed=9)
+    B, H, W = 4, 1024, 1024
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=5, block=64)
+    xb = torch.from_numpy(images).cuda()
+    full = m.predict_on_batch_device(xb).clone()
+    torch.cuda.synchronize()
+    assert tuple(full.shape) == (B, H, W, NC) and bool(torch.isfinite(full).all())
+    for i in (0, 3):
+        one = m.predict_on_batch_device(xb[i:i + 1]).clone()
+        assert torch.equal(one[0], full[i]), "image {} differs between batch sizes".format(i)
+    # evaluation: the matrix over the batch equals the matrix recomputed from the logits, and the loss is the mean over pixels
+    m.reset_metrics()
+    outs = m.test_on_batch([xb, labels, pw, np.zeros((B, 1), np.int32)], None)
+    pred = full.argmax(dim=-1).cpu().numpy()
+    keep = labels != 0
+    cm = np.zeros((NC, NC), np.int64)
+    np.add.at(cm, (labels[keep], pred[keep]), 1)
+    # ties in the argmax are resolved towards the lower class on both sides
+    assert np.array_equal(outs[6], cm)
+    lse = torch.logsumexp(full.double(), dim=-1).cpu().numpy()
+    picked = torch.gather(full.double(), 3, torch.from_numpy(labels).long().cuda().unsqueeze(-1)).squeeze(-1).cpu().numpy()
+    ref = float((pw.astype(np.float64) * (lse - picked)).mean())
+    assert abs(outs[0] - ref) <= 1e-5 * abs(ref)
