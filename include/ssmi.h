@@ -277,6 +277,23 @@ ssmi_status ssmi_mt_consistency_fwd_bwd(const float* logits, const float* teache
                                         float* loss_io, int32_t accumulate_loss, float* cost_out, void* ws, size_t ws_bytes,
                                         void* stream);
 
+/* Superpixel cost of the unlabeled rows and its gradient (src/losses.py:108-192, called from
+ * segmentation_superpixel_lambda_loss :439-492 and segmentation_mean_teacher_superpixel_lambda_loss :495-572):
+ *   S = softmax(logits);  Gx, Gy = depthwise 3x3 cross-correlation of every class map with the Sobel mask
+ *   [[1,2,1],[0,0,0],[-1,-2,-1]] and its transpose (SAME zero padding inside each image);
+ *   Gx, Gy = max(., epsilon)  (the reference clips from BELOW only: negative responses become epsilon and pass no gradient);
+ *   cost = coef * mean_pixels( sqrt(sum_classes(Gx^2 + Gy^2)) * min(max(mask, 0), 1) ).
+ * logits / mask / dlogits point at the FIRST UNLABELED row (n rows of h*w pixels); coef_dev is a 1-element device float.
+ * dlogits (nullable) is overwritten (accumulate_grad = 0) or added to (1: the mean-teacher term already wrote these rows).
+ * loss_io / accumulate_loss / cost_out as in ssmi_mt_consistency_fwd_bwd.  The workspace holds three [n*h*w, classes]
+ * float planes (softmax and the two stencil gradients) plus the per-block partial sums; the reference's
+ * settings.EPSILON is 1e-6. */
+size_t ssmi_superpixel_workspace_bytes(int64_t npix, int32_t num_classes);
+ssmi_status ssmi_superpixel_cost_fwd_bwd(const float* logits, const int32_t* mask, int32_t n, int32_t h, int32_t w,
+                                         int32_t num_classes, const float* coef_dev, float grad_scale, float epsilon,
+                                         float* dlogits, int32_t accumulate_grad, float* loss_io, int32_t accumulate_loss,
+                                         float* cost_out, void* ws, size_t ws_bytes, void* stream);
+
 /* Teacher weights as an exponential moving average of the student's (src/trainers.py:1692-1706):
  *   teacher[i] = fl32(fl32(a) * teacher[i]) + fl32(fl32(1 - a) * student[i])   (no fused multiply-add, like numpy)
  * applied to a whole arena; `1 - a` is formed in double before rounding, as the reference's Python float does. */

@@ -357,12 +357,13 @@ def trainable_keys(model_name: str, num_classes: int) -> List[str]:
 def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images: np.ndarray, labels: np.ndarray,
                pixel_weights: np.ndarray, drop_masks=None, dtype=torch.float64, collect=False,
                adam: Optional[dict] = None, adam_state: Optional[dict] = None, ignore_classes=(0,),
-               mean_teacher: Optional[dict] = None):
+               mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None):
     """One supervised training step exactly as the reference assembles it
     (src/trainers.py:2436-2440: total = 1*loss + 0*mean(0*logits)):
     forward (training phase) -> weighted CE -> gradients -> BN moving-average updates -> optional Adam.
     With mean_teacher = dict(num_unlabeled, mt_logits, coefficient) the loss is the mean-teacher lambda loss
-    (src/losses.py:377-436) and the metrics see zero labels on the unlabeled rows (src/generators.py:1764-1766).
+    (src/losses.py:377-436); with superpixel = dict(num_unlabeled, coefficient) the superpixel lambda loss (:439-492); with
+    both the combined one (:495-572).  The metrics see zero labels on the unlabeled rows (src/generators.py:1764-1766).
     Returns dict(loss, logits, grads{key}, new_weights{key}, cm, acts)."""
     num_classes = weights["logits/bias"].shape[0]
     params = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
@@ -374,12 +375,19 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
     logits, ctx = enet_forward(model_name, params, x, True, masks, collect)
     lab = torch.tensor(labels.astype(np.int64))
     w = torch.tensor(pixel_weights, dtype=dtype)
-    if mean_teacher is None:
+    if mean_teacher is None and superpixel is None:
         loss = K.segmentation_cce_lambda_loss(logits, lab, w, 0)
     else:
-        nu = int(mean_teacher["num_unlabeled"])
-        loss = K.segmentation_mean_teacher_lambda_loss(logits, lab, w, nu, torch.tensor(mean_teacher["mt_logits"], dtype=dtype),
-                                                       float(mean_teacher["coefficient"]))
+        nu = int((mean_teacher or superpixel)["num_unlabeled"])
+        if mean_teacher is not None:
+            mt = torch.tensor(mean_teacher["mt_logits"], dtype=dtype)
+        if mean_teacher is not None and superpixel is not None:
+            loss = K.segmentation_mean_teacher_superpixel_lambda_loss(logits, lab, w, nu, mt, float(mean_teacher["coefficient"]),
+                                                                      float(superpixel["coefficient"]))
+        elif mean_teacher is not None:
+            loss = K.segmentation_mean_teacher_lambda_loss(logits, lab, w, nu, mt, float(mean_teacher["coefficient"]))
+        else:
+            loss = K.segmentation_superpixel_lambda_loss(logits, lab, w, nu, float(superpixel["coefficient"]))
         if nu:
             labels = labels.copy()
             labels[labels.shape[0] - nu:] = 0

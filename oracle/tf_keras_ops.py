@@ -243,6 +243,53 @@ def segmentation_mean_teacher_lambda_loss(logits, labels, weights, num_unlabeled
     return cls + mean_teacher_consistency_cost(logits, mt_pred, consistency_coefficient)
 
 
+SUPERPIXEL_EPSILON = 10e-7     # src/settings.py:6
+
+
+def unlabeled_superpixel_cost(y_true_unlabeled, y_pred_unlabeled, coefficient, epsilon=SUPERPIXEL_EPSILON):
+    """src/losses.py:108-192: Sobel responses of the softmax maps (depthwise cross-correlation, SAME zero padding),
+    clipped from below at epsilon (tf.clip_by_value passes the gradient inside [min, max] only), vector length over the
+    classes of the per-class magnitudes, masked by clip(y_true, 0, 1), mean over batch and space, times the coefficient."""
+    dt = y_pred_unlabeled.dtype
+    m = torch.clamp(y_true_unlabeled, 0, 1).to(dt)
+    s = torch.softmax(y_pred_unlabeled, dim=-1)
+    C = s.shape[-1]
+    sx = torch.tensor([[1.0, 2.0, 1.0], [0.0, 0.0, 0.0], [-1.0, -2.0, -1.0]], dtype=dt)
+    sy = sx.t()
+    x = _nchw(s)
+    gx = _nhwc(F.conv2d(x, sx.reshape(1, 1, 3, 3).repeat(C, 1, 1, 1), padding=1, groups=C))
+    gy = _nhwc(F.conv2d(x, sy.reshape(1, 1, 3, 3).repeat(C, 1, 1, 1), padding=1, groups=C))
+    big = torch.finfo(torch.float32).max
+    gx = torch.clamp(gx, min=epsilon, max=big)
+    gy = torch.clamp(gy, min=epsilon, max=big)
+    g_mag = torch.sqrt(gx ** 2 + gy ** 2)
+    g_dot = torch.linalg.vector_norm(g_mag, dim=-1)
+    return coefficient * torch.mean(g_dot * m)
+
+
+def segmentation_superpixel_lambda_loss(logits, labels, weights, num_unlabeled: int, sp_coefficient):
+    """src/losses.py:439-492: classification cost over the labeled rows + superpixel cost over the unlabeled rows
+    (0 when the batch has none)."""
+    B = labels.shape[0]
+    nl = B - int(num_unlabeled)
+    loss = sparse_weighted_pixelwise_xent(logits[0:nl], labels[0:nl], weights[0:nl])
+    if num_unlabeled > 0:
+        loss = loss + unlabeled_superpixel_cost(labels[nl:], logits[nl:], sp_coefficient)
+    return loss
+
+
+def segmentation_mean_teacher_superpixel_lambda_loss(logits, labels, weights, num_unlabeled: int, mt_pred, mt_coefficient,
+                                                     sp_coefficient):
+    """src/losses.py:495-572."""
+    B = labels.shape[0]
+    nl = B - int(num_unlabeled)
+    loss = sparse_weighted_pixelwise_xent(logits[0:nl], labels[0:nl], weights[0:nl])
+    loss = loss + mean_teacher_consistency_cost(logits, mt_pred, mt_coefficient)
+    if num_unlabeled > 0:
+        loss = loss + unlabeled_superpixel_cost(labels[nl:], logits[nl:], sp_coefficient)
+    return loss
+
+
 def ema_update_np(teacher, student, a):
     """src/trainers.py:1692-1706 on lists of float32 numpy arrays; `a` is a Python float, so numpy keeps float32."""
     return [a * t + ((1.0 - a) * s) for t, s in zip(teacher, student)]

@@ -80,6 +80,9 @@ _PROTOS = {
                                          _vp]),
     "ssmi_mt_consistency_workspace_bytes": (_sz, [_i64]),
     "ssmi_mt_consistency_fwd_bwd": (_i32, [_vp, _vp, _i64, _i32, _vp, _f32, _i64, _vp, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "ssmi_superpixel_workspace_bytes": (_sz, [_i64, _i32]),
+    "ssmi_superpixel_cost_fwd_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _f32, _vp, _i32, _vp, _i32, _vp, _vp,
+                                            _sz, _vp]),
     "ssmi_ema_update": (_i32, [_vp, _vp, C.c_double, _i64, _vp]),
     "ssmi_metrics_from_cm": (_i32, [_vp, _i32, _u64, C.POINTER(C.c_double)]),
     "ssmi_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
@@ -103,7 +106,7 @@ _PROTOS = {
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 _NOT_STATUS = {"ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
-               "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes"}
+               "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 
 
 class _Lib:

@@ -282,6 +282,113 @@ __global__ void mt_consistency_final(const double* __restrict__ part, int nblock
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Superpixel cost of the unlabeled rows (src/losses.py:108-192): Sobel gradients of the per-class softmax maps
+// (3x3 depthwise, SAME zero padding, per image), clipped from below at epsilon, combined to one magnitude per pixel
+// (sqrt over classes of Gx^2 + Gy^2), masked by the superpixel-interior mask and averaged over all pixels.
+// Three passes over an [npix, C] workspace triple: softmax S -> (dGx, dGy) + cost -> dlogits.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_softmax_kernel(const float* __restrict__ logits, unsigned npix, int C,
+                                                         float* __restrict__ S) {
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+    const float* z = logits + (size_t)p * C;
+    float* o = S + (size_t)p * C;
+    float mx = z[0];
+    for (int j = 1; j < C; ++j) mx = fmaxf(mx, z[j]);
+    float se = 0.f;
+    for (int j = 0; j < C; ++j) se += __expf(z[j] - mx);
+    const float inv = 1.f / se;
+    for (int j = 0; j < C; ++j) o[j] = __expf(z[j] - mx) * inv;
+  }
+}
+
+// Cross-correlation with S_x = [[1,2,1],[0,0,0],[-1,-2,-1]] (gx) and its transpose (gy) at pixel (y, x), class c.
+// `up`/`dn`/`lf`/`rt` say whether the neighbouring row / column exists inside the image.
+__device__ __forceinline__ void sobel_pair(const float* __restrict__ T, int wc, int C, int c, bool up, bool dn, bool lf, bool rt,
+                                           float& gx, float& gy) {
+  // T points at (y, x, 0); wc = w * C
+  const float a00 = (up && lf) ? T[-wc - C + c] : 0.f, a01 = up ? T[-wc + c] : 0.f, a02 = (up && rt) ? T[-wc + C + c] : 0.f;
+  const float a10 = lf ? T[-C + c] : 0.f, a12 = rt ? T[C + c] : 0.f;
+  const float a20 = (dn && lf) ? T[wc - C + c] : 0.f, a21 = dn ? T[wc + c] : 0.f, a22 = (dn && rt) ? T[wc + C + c] : 0.f;
+  gx = (a00 + 2.f * a01 + a02) - (a20 + 2.f * a21 + a22);
+  gy = (a00 + 2.f * a10 + a20) - (a02 + 2.f * a12 + a22);
+}
+
+__global__ __launch_bounds__(256) void sp_grad_kernel(const float* __restrict__ S, const int32_t* __restrict__ mask, int h, int w,
+                                                      unsigned npix, int C, const float* __restrict__ coef_dev, float kscale,
+                                                      float eps, float* __restrict__ dGx, float* __restrict__ dGy,
+                                                      double* __restrict__ part) {
+  const float k = *coef_dev * kscale;      // coef * grad_scale / npix
+  const int wc = w * C;
+  float local = 0.f;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+    const unsigned rem = p % ((unsigned)h * (unsigned)w);
+    const int y = (int)(rem / (unsigned)w), x = (int)(rem % (unsigned)w);
+    const bool up = y > 0, dn = y < h - 1, lf = x > 0, rt = x < w - 1;
+    const float* T = S + (size_t)p * C;
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) {
+      float gx, gy;
+      sobel_pair(T, wc, C, c, up, dn, lf, rt, gx, gy);
+      gx = fmaxf(gx, eps);
+      gy = fmaxf(gy, eps);
+      sum += gx * gx + gy * gy;
+    }
+    const float gdot = sqrtf(sum);
+    const int mv = mask[p];
+    const float m = mv > 0 ? 1.f : 0.f;      // clip_by_value(y_true, 0, 1) of an integer mask
+    local += gdot * m;
+    if (dGx) {
+      const float f = k * m / gdot;
+      for (int c = 0; c < C; ++c) {
+        float gx, gy;
+        sobel_pair(T, wc, C, c, up, dn, lf, rt, gx, gy);
+        // the clip passes the gradient where the raw value is inside [epsilon, max]
+        dGx[(size_t)p * C + c] = gx >= eps ? f * gx : 0.f;
+        dGy[(size_t)p * C + c] = gy >= eps ? f * gy : 0.f;
+      }
+    }
+  }
+  __shared__ float red[4];
+  const float ws = wave_sum(local);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (double)red[0] + (double)red[1] + (double)red[2] + (double)red[3];
+}
+
+// ds = transposed Sobel stencils applied to (dGx, dGy), then the softmax backward into the logits gradient.
+__device__ __forceinline__ float sp_ds(const float* __restrict__ X, const float* __restrict__ Y, int wc, int C, int c, bool up,
+                                       bool dn, bool lf, bool rt) {
+  // the transpose of a cross-correlation with K is a cross-correlation with K rotated by 180 degrees: -S_x and -S_y
+  float gx, gy, t;
+  sobel_pair(X, wc, C, c, up, dn, lf, rt, gx, t);
+  sobel_pair(Y, wc, C, c, up, dn, lf, rt, t, gy);
+  return -(gx + gy);
+}
+
+__global__ __launch_bounds__(256) void sp_apply_kernel(const float* __restrict__ S, const float* __restrict__ dGx,
+                                                       const float* __restrict__ dGy, int h, int w, unsigned npix, int C,
+                                                       int accumulate, float* __restrict__ dlogits) {
+  const int wc = w * C;
+  for (unsigned p = blockIdx.x * 256u + threadIdx.x; p < npix; p += gridDim.x * 256u) {
+    const unsigned rem = p % ((unsigned)h * (unsigned)w);
+    const int y = (int)(rem / (unsigned)w), x = (int)(rem % (unsigned)w);
+    const bool up = y > 0, dn = y < h - 1, lf = x > 0, rt = x < w - 1;
+    const float* T = S + (size_t)p * C;
+    const float* X = dGx + (size_t)p * C;
+    const float* Y = dGy + (size_t)p * C;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) dot += sp_ds(X, Y, wc, C, c, up, dn, lf, rt) * T[c];
+    float* o = dlogits + (size_t)p * C;
+    for (int c = 0; c < C; ++c) {
+      const float g = T[c] * (sp_ds(X, Y, wc, C, c, up, dn, lf, rt) - dot);
+      o[c] = accumulate ? o[c] + g : g;
+    }
+  }
+}
+
 // teacher = a * teacher + (1 - a) * student, evaluated in this order (src/trainers.py:1704)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, const float* __restrict__ student, float a,
                                                   float one_minus_a, int64_t count) {
@@ -361,6 +468,45 @@ ssmi_status ssmi_mt_consistency_fwd_bwd(const float* logits, const float* teache
   SSMI_LAUNCH_CHECK();
   hipLaunchKernelGGL(mt_consistency_final, dim3(1), dim3(256), 0, st, part, nb, inv_count, coef_dev, accumulate_loss, loss_io,
                      cost_out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+size_t ssmi_superpixel_workspace_bytes(int64_t npix, int32_t num_classes) {
+  return (size_t)3 * (size_t)npix * (size_t)num_classes * sizeof(float) + (size_t)kLossBlocks * sizeof(double) + 64;
+}
+
+ssmi_status ssmi_superpixel_cost_fwd_bwd(const float* logits, const int32_t* mask, int32_t n, int32_t h, int32_t w,
+                                         int32_t num_classes, const float* coef_dev, float grad_scale, float epsilon,
+                                         float* dlogits, int32_t accumulate_grad, float* loss_io, int32_t accumulate_loss,
+                                         float* cost_out, void* ws, size_t ws_bytes, void* stream) {
+  SSMI_REQUIRE(logits && mask && coef_dev && n > 0 && h > 0 && w > 0, SSMI_E_INVALID_ARG, "superpixel_cost: bad argument");
+  SSMI_REQUIRE(num_classes >= 2 && num_classes <= 64, SSMI_E_UNSUPPORTED, "superpixel_cost: num_classes %d outside [2,64]", num_classes);
+  const int64_t npix = (int64_t)n * h * w;
+  SSMI_REQUIRE(npix * num_classes < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "superpixel_cost: more than 2^31 elements");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_superpixel_workspace_bytes(npix, num_classes), SSMI_E_WORKSPACE, "superpixel_cost: workspace too small");
+  hipStream_t st = as_stream(stream);
+  const size_t plane = (size_t)npix * num_classes;
+  float* S = reinterpret_cast<float*>(ws);
+  float* dGx = S + plane;
+  float* dGy = dGx + plane;
+  double* part = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(dGy + plane) + 63) & ~(uintptr_t)63);
+  int64_t nb64 = ceil_div64(npix, 256);
+  if (nb64 > kLossBlocks) nb64 = kLossBlocks;
+  const int nb = (int)nb64;
+  hipLaunchKernelGGL(sp_softmax_kernel, dim3(nb), dim3(256), 0, st, logits, (unsigned)npix, num_classes, S);
+  SSMI_LAUNCH_CHECK();
+  const float kscale = (float)((double)grad_scale / (double)npix);
+  hipLaunchKernelGGL(sp_grad_kernel, dim3(nb), dim3(256), 0, st, S, mask, h, w, (unsigned)npix, num_classes, coef_dev, kscale,
+                     epsilon, dlogits ? dGx : nullptr, dGy, part);
+  SSMI_LAUNCH_CHECK();
+  if (dlogits) {
+    hipLaunchKernelGGL(sp_apply_kernel, dim3(nb), dim3(256), 0, st, S, dGx, dGy, h, w, (unsigned)npix, num_classes,
+                       accumulate_grad, dlogits);
+    SSMI_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(mt_consistency_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, coef_dev, accumulate_loss,
+                     loss_io, cost_out);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }

@@ -39,7 +39,7 @@ class LayerInfo:
 class ExtendedModel(object):
 
     def __init__(self, name: str, graph: ENetGraph, input_shape, num_classes: int, lambda_loss: bool,
-                 mean_teacher: bool = False):
+                 mean_teacher: bool = False, superpixel: bool = False):
         self.name = name
         self.graph = graph
         self.input_shape = tuple(input_shape)
@@ -49,10 +49,15 @@ class ExtendedModel(object):
         # teacher's logits and the consistency-cost coefficient, and a loss over labeled + unlabeled rows
         self.mean_teacher = bool(mean_teacher and lambda_loss)
         self.input_names = ["images"] + (["labels", "class_weights", "num_unlabeled"] if lambda_loss else [])
+        # superpixel cost over the unlabeled rows (src/models.py:191-196, src/losses.py:439-572): one more input, its coefficient
+        self.superpixel = bool(superpixel and lambda_loss)
         if self.mean_teacher:
             self.input_names += ["mt_predictions", "consistency_cost"]
+        if self.superpixel:
+            self.input_names += ["unlabeled_cost_coeff"]
         self._num_labeled = None
         self.mt_buf = self.coef_buf = self._cost_buf = None
+        self.sp_mask_buf = self.sp_coef_buf = self._sp_cost_buf = self._sp_ws = None
         self.output_names = (["loss", "logits"] if lambda_loss else ["logits"])
         self.optimizer = None
         self.metrics = None
@@ -241,6 +246,11 @@ class ExtendedModel(object):
             self.mt_buf = torch.zeros(n, h, w, self.num_classes, dtype=torch.float32, device=dev)
             self.coef_buf = torch.zeros(1, dtype=torch.float32, device=dev)
             self._cost_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+        if self.superpixel:
+            self.sp_mask_buf = torch.zeros(n, h, w, dtype=torch.int32, device=dev)
+            self.sp_coef_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._sp_cost_buf = torch.zeros(1, dtype=torch.float32, device=dev)
+            self._sp_ws = None
         self._num_labeled = n
         self.graph.plan(n, h, w)
         self._bufs_shape = (n, h, w)
@@ -254,6 +264,10 @@ class ExtendedModel(object):
             a = np.ascontiguousarray(src).reshape(tuple(dst.shape))
             dst.copy_(torch.from_numpy(a).to(dst.dtype), non_blocking=True)
 
+    @staticmethod
+    def _scalar(v) -> float:
+        return float(v.reshape(-1)[0].item() if torch.is_tensor(v) else np.asarray(v).reshape(-1)[0])
+
     def set_batch(self, x):
         """Stage one batch [images, labels, class_weights, num_unlabeled] (numpy or torch) into the static device
         buffers the captured graphs read."""
@@ -266,19 +280,27 @@ class ExtendedModel(object):
             self._to_dev(self.weights_buf, x[2])
             nu = x[3]
             nu = int(nu.reshape(-1)[0].item() if torch.is_tensor(nu) else np.asarray(nu).reshape(-1)[0])
-            if self.mean_teacher:
-                if len(x) != 6:
-                    raise ValueError('Expected 6 inputs {}, got: {}'.format(self.input_names, len(x)))
+            if self.mean_teacher or self.superpixel:
+                if len(x) != len(self.input_names):
+                    raise ValueError('Expected {} inputs {}, got: {}'.format(len(self.input_names), self.input_names, len(x)))
                 if not 0 <= nu < n:
                     raise ValueError("num_unlabeled must lie in [0, batch): the classification cost needs a labeled row")
                 self._num_labeled = n - nu
+                if self.superpixel:
+                    # the unlabeled rows of `labels` carry the superpixel masks (0 = border); keep them for the cost
+                    self.sp_mask_buf.copy_(self.labels_buf)
+                    self._to_dev(self.sp_coef_buf, np.asarray(self._scalar(x[-1]), dtype=np.float32).reshape(1))
+                    if nu:
+                        need = lib().superpixel_workspace_bytes(nu * h * w, self.num_classes)
+                        if self._sp_ws is None or self._sp_ws.numel() * 4 < need:
+                            self._sp_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.graph.device)
+                            self._graphs.clear()
                 if nu:
                     # the metrics see zero labels on the unlabeled rows (src/generators.py:1764-1766)
                     self.labels_buf[n - nu:].zero_()
-                self._to_dev(self.mt_buf, x[4])
-                cf = x[5]
-                cf = float(cf.reshape(-1)[0].item() if torch.is_tensor(cf) else np.asarray(cf).reshape(-1)[0])
-                self.coef_buf.fill_(cf)      # src/losses.py:413: element 0 of the per-row coefficient vector
+                if self.mean_teacher:
+                    self._to_dev(self.mt_buf, x[4])
+                    self.coef_buf.fill_(self._scalar(x[5]))      # src/losses.py:413: element 0 of the per-row vector
             elif nu != 0:
                 # src/losses.py:327-329,369 slices only the weights; logits/labels keep the full batch, so the
                 # reference's own graph is shape-inconsistent for num_unlabeled > 0 in the supervised loss
@@ -294,20 +316,32 @@ class ExtendedModel(object):
         npix = n * h * w
         C_ = self.num_classes
 
-        def loss_call_mt(st, want_grad):
-            # classification cost over the labeled rows, metrics over every row, then the consistency cost over
-            # every row added to the loss and to the gradient (src/losses.py:416-431)
-            npl = self._num_labeled * h * w
+        def loss_call_semi(st, want_grad):
+            # classification cost over the labeled rows, metrics over every row (src/losses.py:416-422), then the
+            # mean-teacher consistency cost over every row (:428) and / or the superpixel cost over the unlabeled rows
+            # (:484), each added to the loss and to the logits gradient
+            nl = self._num_labeled
+            npl = nl * h * w
             dl = _ptr(g.dlogits) if want_grad else None
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npl, C_, 1.0, dl,
                                    _ptr(self._loss_buf), _ptr(self._cm), npix, self._ignore_bits, None, _ptr(self._bad),
                                    _ptr(g.ws), g.ws.numel() * 4, st)
-            L.mt_consistency_fwd_bwd(_ptr(g.logits), _ptr(self.mt_buf), npix, C_, _ptr(self.coef_buf), 1.0, npl, dl,
-                                     _ptr(self._loss_buf), 1, _ptr(self._cost_buf), _ptr(g.ws), g.ws.numel() * 4, st)
+            if self.mean_teacher:
+                L.mt_consistency_fwd_bwd(_ptr(g.logits), _ptr(self.mt_buf), npix, C_, _ptr(self.coef_buf), 1.0, npl, dl,
+                                         _ptr(self._loss_buf), 1, _ptr(self._cost_buf), _ptr(g.ws), g.ws.numel() * 4, st)
+            if self.superpixel:
+                if nl < n:
+                    off = npl * C_ * 4
+                    L.superpixel_cost_fwd_bwd(_ptr(g.logits) + off, _ptr(self.sp_mask_buf) + npl * 4, n - nl, h, w, C_,
+                                              _ptr(self.sp_coef_buf), 1.0, 10e-7, (dl + off) if want_grad else None,
+                                              1 if self.mean_teacher else 0, _ptr(self._loss_buf), 1, _ptr(self._sp_cost_buf),
+                                              _ptr(self._sp_ws), self._sp_ws.numel() * 4, st)
+                else:
+                    L.fill_f32(_ptr(self._sp_cost_buf), 0.0, 1, st)
 
         def loss_call(st, want_grad):
-            if self.mean_teacher:
-                return loss_call_mt(st, want_grad)
+            if self.mean_teacher or self.superpixel:
+                return loss_call_semi(st, want_grad)
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npix, C_, 1.0,
                                    _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), _ptr(self._cm), npix,
                                    self._ignore_bits, None, _ptr(self._bad), _ptr(g.ws), g.ws.numel() * 4, st)
@@ -490,6 +524,10 @@ class ExtendedModel(object):
     def consistency_cost(self) -> float:
         """The consistency term of the last step's loss (0 for models without the mean-teacher loss)."""
         return float(self._cost_buf.item()) if self._cost_buf is not None else 0.0
+
+    def superpixel_cost(self) -> float:
+        """The superpixel term of the last step's loss (0 for models without it or batches without unlabeled rows)."""
+        return float(self._sp_cost_buf.item()) if self._sp_cost_buf is not None else 0.0
 
     def predict(self, x, batch_size=None, verbose=0):
         images = x[0] if isinstance(x, (list, tuple)) else x

@@ -109,20 +109,66 @@ def segmentation_mean_teacher_lambda_loss(args):
     """src/losses.py:377-436.  args = [logits BxHxWxC, labels BxHxW int32, weights BxHxW, num_unlabeled Bx1 int32,
     mt_pred BxHxWxC (teacher logits), cons_coefficient Bx1].  Classification cost over the first B - num_unlabeled rows,
     consistency cost over every row."""
-    y_pred, y_true, weights_labeled, num_unlabeled, num_labeled = _preprocess_segmentation_lambda_loss_args(args, 6)
-    mt_pred, coef = args[4], args[5]
-    if mt_pred.dim() != y_pred.dim() or coef.dim() != 2:
-        raise ValueError("rank mismatch: mt_pred must have the rank of y_pred, cons_coefficient rank 2")
+    return _semi_supervised(args, 6, True, False)
+
+
+SUPERPIXEL_EPSILON = 10e-7      # src/settings.py:6
+
+
+def _superpixel(y_pred_unlabeled, y_true_unlabeled, coefficient: float, dlogits_unlabeled, accumulate: bool, loss: torch.Tensor):
+    """Adds the superpixel cost of the unlabeled rows (src/losses.py:108-192) to `loss` and its gradient to the
+    unlabeled rows of the logits gradient (a contiguous view)."""
+    L = lib()
+    nu, h, w, C = y_pred_unlabeled.shape
+    mask = y_true_unlabeled.contiguous().to(torch.int32)
+    ws = torch.empty(L.superpixel_workspace_bytes(nu * h * w, C) // 4 + 4, dtype=torch.float32, device=y_pred_unlabeled.device)
+    coef = torch.full((1,), float(coefficient), dtype=torch.float32, device=y_pred_unlabeled.device)
+    st = torch.cuda.current_stream().cuda_stream
+    L.superpixel_cost_fwd_bwd(y_pred_unlabeled.data_ptr(), mask.data_ptr(), nu, h, w, C, coef.data_ptr(), 1.0, SUPERPIXEL_EPSILON,
+                              None if dlogits_unlabeled is None else dlogits_unlabeled.data_ptr(), int(accumulate),
+                              loss.reshape(1).data_ptr(), 1, None, ws.data_ptr(), ws.numel() * 4, st)
+    return loss
+
+
+def _semi_supervised(args, n_args, with_mt, with_sp):
+    y_pred, y_true, weights_labeled, num_unlabeled, num_labeled = _preprocess_segmentation_lambda_loss_args(args, n_args)
     if num_labeled <= 0:
         raise ValueError("the classification cost needs at least one labeled row")
+    for extra in args[4:]:
+        if extra.dim() not in (2, y_pred.dim()):
+            raise ValueError("rank mismatch in the semi-supervised loss inputs")
     y_pred = y_pred.contiguous().float()
     loss = _xent(y_pred[0:num_labeled], y_true[0:num_labeled], weights_labeled)
     dl = torch.zeros_like(y_pred)
     dl[0:num_labeled].copy_(_last["dlogits"])
     npl = num_labeled * y_pred.shape[1] * y_pred.shape[2]
-    _consistency(y_pred, mt_pred, float(coef.reshape(-1)[0].item()), dl, npl, loss)
+    if with_mt:
+        mt_pred, coef = args[4], args[5]
+        if mt_pred.dim() != y_pred.dim() or coef.dim() != 2:
+            raise ValueError("rank mismatch: mt_pred must have the rank of y_pred, cons_coefficient rank 2")
+        _consistency(y_pred, mt_pred, float(coef.reshape(-1)[0].item()), dl, npl, loss)
+    if with_sp and num_unlabeled > 0:
+        sp_coef = args[-1]
+        if sp_coef.dim() != 2:
+            raise ValueError("rank mismatch: superpixel_consistency_cost_coefficient must have rank 2")
+        _superpixel(y_pred[num_labeled:], y_true[num_labeled:], float(sp_coef.reshape(-1)[0].item()), dl[num_labeled:],
+                    with_mt, loss)
     _last["dlogits"] = dl
     return loss
+
+
+def segmentation_superpixel_lambda_loss(args):
+    """src/losses.py:439-492.  args = [logits, labels (superpixel masks on the unlabeled rows), weights, num_unlabeled,
+    superpixel_consistency_cost_coefficient Bx1]."""
+    if len(args) != 5:
+        raise ValueError('Expected 5 values (y_pred, y_true, weights, num_unlabeled, unlabeled_cost_coefficient), got: {} ({})'.format(len(args), args))
+    return _semi_supervised(args, 5, False, True)
+
+
+def segmentation_mean_teacher_superpixel_lambda_loss(args):
+    """src/losses.py:495-572.  args = [logits, labels, weights, num_unlabeled, mt_pred, consistency_coefficient Bx1,
+    superpixel_consistency_cost_coefficient Bx1]."""
+    return _semi_supervised(args, 7, True, True)
 
 
 def segmentation_sparse_weighted_categorical_cross_entropy(class_weights):

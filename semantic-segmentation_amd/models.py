@@ -28,8 +28,12 @@ def get_lambda_loss_function(model_lambda_loss_type):
         return losses.segmentation_categorical_cross_entropy_lambda_loss
     if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER:
         return losses.segmentation_mean_teacher_lambda_loss
+    if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL:
+        return losses.segmentation_superpixel_lambda_loss
+    if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL:
+        return losses.segmentation_mean_teacher_superpixel_lambda_loss
     if isinstance(model_lambda_loss_type, ModelLambdaLossType):
-        raise NotImplementedError('lambda loss type {} is not implemented (superpixel / classification losses)'.format(model_lambda_loss_type))
+        raise NotImplementedError('lambda loss type {} is not implemented (classification losses)'.format(model_lambda_loss_type))
     raise ValueError('Unknown model lambda loss type: {}'.format(model_lambda_loss_type))
 
 
@@ -64,11 +68,16 @@ class ModelBase(object):
             raise ValueError('input_shape must be (H|None, W|None, 3), got {}'.format(self.input_shape))
         self.device = device
         graph = self._build_model()
-        mean_teacher = model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER
-        lambda_loss = mean_teacher or model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY
-        if lambda_loss:
-            self.name = self.name + ('-MT' if mean_teacher else '-CCE')      # src/models.py:185-190
-        self._model = ExtendedModel(self.name, graph, self.input_shape, num_classes, lambda_loss, mean_teacher=mean_teacher)
+        T = ModelLambdaLossType
+        mean_teacher = model_lambda_loss_type in (T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER,
+                                                  T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL)
+        superpixel = model_lambda_loss_type in (T.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL,
+                                                T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL)
+        lambda_loss = mean_teacher or superpixel or model_lambda_loss_type == T.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY
+        if lambda_loss:      # src/models.py:185-196
+            self.name = self.name + (('-MT' if mean_teacher else '') + ('-SP' if superpixel else '') or '-CCE')
+        self._model = ExtendedModel(self.name, graph, self.input_shape, num_classes, lambda_loss, mean_teacher=mean_teacher,
+                                    superpixel=superpixel)
 
     @property
     def model(self):

@@ -119,8 +119,9 @@ class SegmentationTrainer(object):
         from . import models, losses, metrics
         from .keras_extensions import extended_optimizers as xo
         if trainer_type not in ("segmentation_supervised", "segmentation_supervised_mean_teacher",
-                                "segmentation_semi_supervised_mean_teacher"):
-            raise NotImplementedError("trainer type {} is not implemented (superpixel / classification trainers)".format(trainer_type))
+                                "segmentation_semi_supervised_mean_teacher", "segmentation_semi_supervised_superpixel",
+                                "segmentation_semi_supervised_mean_teacher_superpixel"):
+            raise NotImplementedError("trainer type {} is not implemented (classification trainers)".format(trainer_type))
         self.trainer_type = trainer_type
         if config is None:
             with open(config_file_path) as f:
@@ -138,15 +139,19 @@ class SegmentationTrainer(object):
         self.num_unlabeled_per_batch = int(config.get("num_unlabeled_per_batch", 0)) if trainer_type.startswith("segmentation_semi") else 0
         self.mean_teacher_method_config = config.get("mean_teacher_params") or config.get("mean_teacher_method_config")
         self.teacher_model = None
-        self._ema_fn = self._cons_fn = None
+        self._ema_fn = self._cons_fn = self._sp_fn = None
+        self.superpixel_method_config = config.get("superpixel_params")
         cw = config.get("override_class_weights")
         if cw is None or not config.get("use_class_weights", True):
             cw = np.ones(num_classes, dtype=np.float32)
             for c in self.ignore_classes:
                 cw[c] = 0.0   # src/trainers.py:2047-2053
         self.class_weights = np.asarray(cw, dtype=np.float32)
-        ltype = (losses.ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER if self.using_mean_teacher_method
-                 else losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
+        T = losses.ModelLambdaLossType
+        ltype = {(False, False): T.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, (True, False): T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER,
+                 (False, True): T.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL,
+                 (True, True): T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL}[(self.using_mean_teacher_method,
+                                                                                          self.using_superpixel_method)]
         mb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes, ltype, device=self.device)
         self.model_wrapper = mb
         self.model = mb.model
@@ -193,7 +198,19 @@ class SegmentationTrainer(object):
 
     @property
     def using_mean_teacher_method(self):
-        return self.trainer_type.endswith("mean_teacher")
+        return "mean_teacher" in self.trainer_type
+
+    @property
+    def using_superpixel_method(self):
+        """src/trainers.py:2204-2207."""
+        return self.trainer_type.endswith("superpixel")
+
+    @property
+    def superpixel_unlabeled_cost_coefficient_function(self):
+        """src/trainers.py:1940-1947."""
+        if self.using_superpixel_method and self._sp_fn is None:
+            self._sp_fn = self._schedule((self.superpixel_method_config or {}).get('unlabeled_cost_coefficient_function', 1.0))
+        return self._sp_fn
 
     @staticmethod
     def _schedule(spec):
@@ -227,27 +244,34 @@ class SegmentationTrainer(object):
         """src/trainers.py:1620-1664, 1822-1867: for a mean-teacher student the teacher's images (last input of a training
         batch, the student's own images when validating) are replaced by the teacher's logits, predicted with the
         training-phase layers active, followed by the per-row consistency coefficient; validation batches get zeros."""
-        if not self.using_mean_teacher_method:
+        if not (self.using_mean_teacher_method or self.using_superpixel_method):
             return x, y
         x = list(x)
         img_batch = x[0]
         n = int(img_batch.shape[0])
-        if not validation:
-            teacher_img_batch, x = x[-1], x[:-1]
-        else:
-            teacher_img_batch = img_batch
+        if self.using_mean_teacher_method:
+            if not validation:
+                teacher_img_batch, x = x[-1], x[:-1]
+            else:
+                teacher_img_batch = img_batch
         if len(x) != 4:
-            raise ValueError("expected [images, labels, class_weights, num_unlabeled(, teacher_images)], got {} inputs".format(len(x) + (0 if validation else 1)))
-        if self.teacher_model is None:
-            raise ValueError('Teacher model is not set, cannot run predictions')
-        if validation:
-            shape = tuple(int(v) for v in img_batch.shape[0:-1]) + (self.num_classes,)
-            mt = torch.zeros(shape, dtype=torch.float32, device=self.device)
-            coef = np.zeros([n, 1], dtype=np.float32)
-        else:
-            mt = self.teacher_model.predict_on_batch_device(teacher_img_batch, use_training_phase_layers=True)
-            coef = np.ones([n, 1], dtype=np.float32) * float(self.consistency_cost_coefficient_function(step_index))
-        return x + [mt, coef], y
+            raise ValueError("expected [images, labels, class_weights, num_unlabeled(, teacher_images)], got {} inputs".format(len(x)))
+        if self.using_mean_teacher_method:
+            if self.teacher_model is None:
+                raise ValueError('Teacher model is not set, cannot run predictions')
+            if validation:
+                shape = tuple(int(v) for v in img_batch.shape[0:-1]) + (self.num_classes,)
+                mt = torch.zeros(shape, dtype=torch.float32, device=self.device)
+                coef = np.zeros([n, 1], dtype=np.float32)
+            else:
+                mt = self.teacher_model.predict_on_batch_device(teacher_img_batch, use_training_phase_layers=True)
+                coef = np.ones([n, 1], dtype=np.float32) * float(self.consistency_cost_coefficient_function(step_index))
+            x = x + [mt, coef]
+        if self.using_superpixel_method:
+            # src/trainers.py:2455-2472: zeros when validating, the scheduled coefficient otherwise
+            sp = 0.0 if validation else float(self.superpixel_unlabeled_cost_coefficient_function(step_index))
+            x = x + [np.ones([n, 1], dtype=np.float32) * sp]
+        return x, y
 
     def on_batch_end(self, step_index):
         """src/trainers.py:1666-1707: exponential moving average of the student's weights into the teacher."""

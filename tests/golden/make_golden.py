@@ -10,7 +10,7 @@ Files (all float64 unless noted; inputs are regenerated from the recorded seeds 
   ops.npz        per-operator cases: SAME stride-2 convolution, dilated convolution, transposed convolution,
                  BN training statistics, max-pool with argmax (with ties), unpooling, weighted cross entropy,
                  confusion matrix, metrics, three Adam steps, three SGD(momentum, nesterov) steps, the mean-teacher
-                 lambda loss with one unlabeled row, the teacher's EMA update
+                 lambda loss with one unlabeled row, the teacher's EMA update, the superpixel lambda loss with two unlabeled rows
   step_<model>.npz  one supervised training step of every model at a tiny shape: loss, logits, dlogits,
                  confusion matrix, per-tensor gradient checksums (sum, sum of squares) and a few full gradients
 """
@@ -137,6 +137,17 @@ def make_ops():
     ew = K.ema_update_np(tw, sw, 0.99)
     out["ema_t_a"], out["ema_t_b"], out["ema_s_a"], out["ema_s_b"] = tw[0], tw[1], sw[0], sw[1]
     out["ema_out_a"], out["ema_out_b"] = ew[0], ew[1]
+    # superpixel lambda loss: 4 rows of 6x5 pixels, the last two unlabeled with superpixel-border masks (0 = border)
+    logits = rng.standard_normal((4, 6, 5, 24)) * 2
+    labels = rng.randint(0, 24, size=(4, 6, 5))
+    labels[2:] = rng.randint(0, 4, size=(2, 6, 5))          # superpixel ids; 0 marks a border
+    wts = cw[labels]
+    lg = t(logits).requires_grad_(True)
+    loss = K.segmentation_superpixel_lambda_loss(lg, torch.tensor(labels), t(wts), 2, 1.75)
+    (dl,) = torch.autograd.grad(loss, [lg])
+    out["sp_logits"], out["sp_labels"], out["sp_weights"] = logits, labels.astype(np.int64), wts
+    out["sp_loss"], out["sp_dlogits"] = np.float64(loss.item()), dl.numpy()
+    out["sp_cost"] = np.float64(K.unlabeled_superpixel_cost(torch.tensor(labels[2:]), t(logits[2:]), 1.75).item())
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **out)
     print("ops.npz", len(out), "arrays")
 

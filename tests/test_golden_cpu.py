@@ -56,6 +56,18 @@ def test_ops_fixture_matches_oracle():
     cost = 3.5 * ((sm(lg) - sm(tl)) ** 2).mean()
     assert abs(cost - float(g["mt_cost"])) < 1e-12
     assert abs(ce[:2].mean() + cost - float(g["mt_loss"])) < 1e-12
+    # superpixel loss by hand (numpy): Sobel responses of the softmax maps with zero padding, clipped from below
+    lg, lab, w = g["sp_logits"], g["sp_labels"], g["sp_weights"]
+    lse = np.log(np.exp(lg - lg.max(-1, keepdims=True)).sum(-1)) + lg.max(-1)
+    ce = (lse - np.take_along_axis(lg, lab[..., None], -1)[..., 0]) * w
+    sp = np.pad(sm(lg[2:]), [(0, 0), (1, 1), (1, 1), (0, 0)])
+    H, W = lg.shape[1:3]
+    v = lambda dy, dx: sp[:, 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]
+    gx = (v(-1, -1) + 2 * v(-1, 0) + v(-1, 1)) - (v(1, -1) + 2 * v(1, 0) + v(1, 1))
+    gy = (v(-1, -1) + 2 * v(0, -1) + v(1, -1)) - (v(-1, 1) + 2 * v(0, 1) + v(1, 1))
+    gd = np.sqrt((np.maximum(gx, 1e-6) ** 2 + np.maximum(gy, 1e-6) ** 2).sum(-1))
+    cost = 1.75 * (gd * np.clip(lab[2:], 0, 1)).mean()
+    assert abs(cost - float(g["sp_cost"])) < 1e-12 and abs(ce[:2].mean() + cost - float(g["sp_loss"])) < 1e-12
     for s_ in "ab":
         ew = np.float32(0.99) * g["ema_t_" + s_] + np.float32(1.0 - 0.99) * g["ema_s_" + s_]
         assert ew.dtype == np.float32 and np.array_equal(ew, g["ema_out_" + s_])

@@ -224,3 +224,27 @@ def test_ema_update_known_answer():
     """src/trainers.py:1704 keeps float32: a*t + (1-a)*s with a Python float."""
     out = K.ema_update_np([np.array([1.0, -2.0], np.float32)], [np.array([2.0, 4.0], np.float32)], 0.75)
     assert out[0].dtype == np.float32 and np.array_equal(out[0], np.array([1.25, -0.5], np.float32))
+
+
+def test_superpixel_cost_known_answers():
+    """src/losses.py:108-192 on a 3x3 image with a uniform softmax (1/2, 1/2): interior responses vanish and are clipped to
+    epsilon, the zero padding makes the border respond; bottom-right corner: Gx = Gy = 1.5 for both classes, so
+    sqrt(2 * (1.5^2 + 1.5^2)) = 3; bottom-left corner: Gx = 1.5, Gy = -1.5 -> epsilon."""
+    y = torch.zeros(1, 3, 3, 2, dtype=torch.float64)
+    only = lambda yy, xx: torch.tensor(np.eye(9)[yy * 3 + xx].reshape(1, 3, 3).astype(np.int64))
+    eps = K.SUPERPIXEL_EPSILON
+    assert eps == 1e-6
+    assert abs(float(K.unlabeled_superpixel_cost(only(2, 2), y, 9.0)) - 3.0) < 1e-12
+    assert abs(float(K.unlabeled_superpixel_cost(only(2, 0), y, 9.0)) - np.sqrt(2 * (2.25 + eps ** 2))) < 1e-12
+    assert abs(float(K.unlabeled_superpixel_cost(only(1, 1), y, 9.0)) - np.sqrt(4 * eps ** 2)) < 1e-15
+    assert abs(float(K.unlabeled_superpixel_cost(only(0, 0), y, 9.0)) - np.sqrt(4 * eps ** 2)) < 1e-15
+    # superpixel ids above 1 count as interior (clip to [0, 1]); the coefficient scales linearly
+    assert abs(float(K.unlabeled_superpixel_cost(only(2, 2) * 7, y, 18.0)) - 6.0) < 1e-12
+    # clipped responses pass no gradient: with only the top-left pixel unmasked every logit gradient is zero
+    yy = y.clone().requires_grad_(True)
+    (g,) = torch.autograd.grad(K.unlabeled_superpixel_cost(only(0, 0), yy, 9.0), [yy])
+    assert float(g.abs().max()) == 0.0
+    # a batch without unlabeled rows has no superpixel term (src/losses.py:484)
+    lab = torch.zeros(1, 3, 3, dtype=torch.int64)
+    w = torch.ones(1, 3, 3, dtype=torch.float64)
+    assert abs(float(K.segmentation_superpixel_lambda_loss(y, lab, w, 0, 5.0)) - np.log(2.0)) < 1e-14

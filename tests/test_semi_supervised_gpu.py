@@ -1,4 +1,4 @@
-"""Mean-teacher support on the GPU: consistency cost + gradient, the lambda loss with unlabeled rows, the teacher's EMA
+"""Semi-supervised losses on the GPU (mean teacher, superpixel, both): consistency cost + gradient, the lambda loss with unlabeled rows, the teacher's EMA
 update and a whole student step, against the CPU oracle and the golden vectors.
 
 Tolerances: rtol 1e-3 (fp32 kernels against fp64 oracle values) for loss and gradients; the EMA update is bit-exact
@@ -205,3 +205,125 @@ def test_trainer_teacher_follows_the_student():
     assert student.consistency_cost() == 0.0 and np.isfinite(outs[0])
     ev = tr.evaluate_teacher(iter([([images, labels, pw, np.zeros((B, 1), np.int32)], None)]), 1)
     assert ev["images"] == B and np.isfinite(ev["loss"])
+
+
+def test_superpixel_lambda_loss_golden_vector():
+    losses = pkg("losses")
+    g = np.load(os.path.join(GOLD, "ops.npz"))
+    args = [_t(g["sp_logits"]), _t(g["sp_labels"], torch.int32), _t(g["sp_weights"]),
+            torch.full((4, 1), 2, dtype=torch.int32, device=DEV), torch.full((4, 1), 1.75, device=DEV)]
+    loss = losses.segmentation_superpixel_lambda_loss(args)
+    _close(loss, g["sp_loss"], "superpixel loss")
+    _close(losses.last_gradient(), g["sp_dlogits"], "superpixel dlogits")
+    with pytest.raises(ValueError):
+        losses.segmentation_superpixel_lambda_loss(args[:4])
+
+
+@pytest.mark.parametrize("C,shape,nu,with_mt", [(24, (3, 17, 13), 2, False), (24, (4, 8, 24), 1, True), (5, (2, 9, 7), 1, True),
+                                                (24, (2, 6, 6), 0, False), (3, (3, 1, 5), 2, False)])
+def test_superpixel_kernels_against_oracle(C, shape, nu, with_mt):
+    """Cost and gradient incl. image borders (zero padding per image), the one-sided clip, 1-pixel-high images, batches
+    without unlabeled rows, and accumulation on top of the mean-teacher gradient."""
+    losses = pkg("losses")
+    rng = np.random.RandomState(C + nu)
+    B = shape[0]
+    logits = rng.standard_normal(shape + (C,)) * 3
+    teacher = rng.standard_normal(shape + (C,)) * 3
+    labels = rng.randint(0, C, size=shape)
+    if nu:
+        labels[B - nu:] = rng.randint(0, 3, size=(nu,) + shape[1:])
+    w = rng.uniform(0.2, 2.0, size=shape)
+    lg = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+    if with_mt:
+        ref = K.segmentation_mean_teacher_superpixel_lambda_loss(lg, torch.tensor(labels), torch.tensor(w), nu, torch.tensor(teacher), 0.8, 2.5)
+    else:
+        ref = K.segmentation_superpixel_lambda_loss(lg, torch.tensor(labels), torch.tensor(w), nu, 2.5)
+    (dref,) = torch.autograd.grad(ref, [lg])
+    args = [_t(logits), _t(labels, torch.int32), _t(w), torch.full((B, 1), nu, dtype=torch.int32, device=DEV)]
+    if with_mt:
+        args += [_t(teacher), torch.full((B, 1), 0.8, device=DEV)]
+    args += [torch.full((B, 1), 2.5, device=DEV)]
+    fn = losses.segmentation_mean_teacher_superpixel_lambda_loss if with_mt else losses.segmentation_superpixel_lambda_loss
+    loss = fn(args)
+    _close(loss, ref.item(), "loss")
+    _close(losses.last_gradient(), dref.numpy(), "dlogits")
+
+
+@pytest.mark.parametrize("with_mt", [False, True])
+def test_superpixel_student_step_against_oracle(with_mt):
+    """A whole step of an ENet student with the superpixel (and mean-teacher) lambda loss, two unlabeled rows."""
+    models, losses = pkg("models"), pkg("losses")
+    name, nc, B, H, W, seed = "enet-naive-upsampling", 24, 3, 32, 32, 13
+    w0 = E.init_weights(name, nc, seed=seed, perturb=True)
+    for k in w0:
+        if k.endswith("/alpha"):
+            w0[k] = np.ones_like(w0[k])
+    T = losses.ModelLambdaLossType
+    mb = models.get_model(name, (None, None, 3), nc, T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL if with_mt
+                          else T.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL)
+    model = mb.model
+    assert mb.name.endswith("-MT-SP" if with_mt else "-SP") and model.input_names[-1] == "unlabeled_cost_coeff"
+    _compile(model)
+    cw = np.ones(nc, dtype=np.float32)
+    cw[0] = 0
+    images, labels, pw = E.synthetic_batch(B, H, W, nc, seed=seed + 100, block=8, class_weights=cw)
+    rng = np.random.RandomState(seed)
+    labels[1:] = np.repeat(np.repeat(rng.randint(0, 3, size=(2, H // 4, W // 4)), 4, axis=1), 4, axis=2)
+    mt_logits = rng.standard_normal((B, H, W, nc)).astype(np.float32) * 2
+    masks = E.make_dropout_masks(name, B, seed)
+    stream = torch.cuda.Stream()
+    cm_total = np.zeros((nc, nc), dtype=np.int64)
+    for step, (mtc, spc) in enumerate(((1.5, 4.0), (0.0, 30.0))):
+        model.set_weights([w0[k] for k in model.weight_names()])
+        model._ensure_buffers(B, H, W)
+        g = model.graph
+        saved = g.drop_groups
+        g.drop_groups = []
+        for k, m in masks.items():
+            g.drop_views[k].copy_(torch.from_numpy(m.astype(np.float32)))
+        ref = E.train_step(name, w0, images, labels, pw, masks, collect=True,
+                           mean_teacher=dict(num_unlabeled=2, mt_logits=mt_logits, coefficient=mtc) if with_mt else None,
+                           superpixel=dict(num_unlabeled=2, coefficient=spc))
+        model.use_hip_graph = step > 0
+        x = [images, labels, pw, np.full((B, 1), 2, np.int32)]
+        if with_mt:
+            x += [mt_logits, np.full((B, 1), mtc, np.float32)]
+        x += [np.full((B, 1), spc, np.float32)]
+        with torch.cuda.stream(stream):
+            outs = model.train_on_batch(x, None)
+        torch.cuda.synchronize()
+        g.drop_groups = saved
+        _close(outs[0], ref["loss"], "loss (step {})".format(step), atol_rel=1e-6)
+        _close(g.dlogits, ref["dlogits"], "dlogits (step {})".format(step))
+        cost = K.unlabeled_superpixel_cost(torch.tensor(labels[1:].astype(np.int64)), torch.tensor(ref["logits"][1:]), spc)
+        _close(model.superpixel_cost(), float(cost), "superpixel term", atol_rel=1e-6)
+        for k, gr in ref["grads"].items():
+            got = g.store.gviews[k].cpu().numpy().astype(np.float64)
+            scale = np.abs(gr).max()
+            assert np.abs(got - gr).max() <= 1e-3 * scale + 2e-6, "grad {} (step {})".format(k, step)
+        lab0 = labels.copy()
+        lab0[1:] = 0
+        cm_total += K.confusion_matrix_np(lab0, g.logits.cpu().numpy(), nc, [0])
+        assert np.array_equal(outs[6], cm_total)
+
+
+def test_trainer_superpixel_inputs():
+    trainers = pkg("trainers")
+    cfg = {"input_shape": [None, None, 3], "random_seed": 5, "optimizer": {"name": "adam", "learning_rate": 1e-3},
+           "mean_teacher_params": {"ema_smoothing_coefficient_function": "lambda x: 0.99", "consistency_cost_coefficient_function": "lambda x: 2.0"},
+           "superpixel_params": {"unlabeled_cost_coefficient_function": "lambda x: 0.5 * (x + 1)"}}
+    tr = trainers.SegmentationTrainer("segmentation_semi_supervised_mean_teacher_superpixel", "enet-naive-upsampling", "t",
+                                      config=cfg, num_classes=24)
+    assert tr.using_mean_teacher_method and tr.using_superpixel_method
+    B, H, W = 2, 32, 32
+    images, labels, pw = E.synthetic_batch(B, H, W, 24, seed=3, block=8)
+    labels[1] = (labels[1] % 3)
+    x, _ = tr.modify_batch_data(1, [images, labels, pw, np.ones((B, 1), np.int32), images], None, validation=False)
+    assert len(x) == 7 and np.allclose(x[5], 2.0) and np.allclose(x[6], 1.0)
+    outs = tr.model.train_on_batch(x, None)
+    tr.on_batch_end(1)
+    assert np.isfinite(outs[0]) and tr.model.superpixel_cost() > 0 and tr.model.consistency_cost() >= 0
+    xv, _ = tr.modify_batch_data(2, [images, labels, pw, np.zeros((B, 1), np.int32)], None, validation=True)
+    assert len(xv) == 7 and not np.any(xv[5]) and not np.any(xv[6])
+    tr.model.test_on_batch(xv, None)
+    assert tr.model.superpixel_cost() == 0.0 and tr.model.consistency_cost() == 0.0
