@@ -116,7 +116,8 @@ class ExtendedModel(object):
         """Weights by Keras name ('layer/kernel', ...) in a .npz container (h5py is not available on this platform)."""
         if os.path.exists(filepath) and not overwrite:
             raise IOError("{} exists".format(filepath))
-        np.savez(filepath, **{k.replace("/", "::"): v for k, v in self.get_weights_dict().items()})
+        with open(filepath, "wb") as f:      # a file object keeps the caller's name (checkpoint templates end in .hdf5)
+            np.savez(f, **{k.replace("/", "::"): v for k, v in self.get_weights_dict().items()})
 
     def load_weights(self, filepath, by_name=False):
         with np.load(filepath, allow_pickle=False) as z:
@@ -137,7 +138,8 @@ class ExtendedModel(object):
             for k, t in self.optimizer.slot_tensors().items():
                 d["optimizer_weights::" + k] = t.detach().cpu().numpy()
             d["optimizer_weights::iterations"] = np.array(self.optimizer.iterations, dtype=np.int64)
-        np.savez(filepath, **d)
+        with open(filepath, "wb") as f:
+            np.savez(f, **d)
 
     def load_optimizer_weights(self, filepath) -> bool:
         """False when the file holds no (or incompatible) optimizer state, True after restoring it."""

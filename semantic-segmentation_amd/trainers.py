@@ -315,6 +315,60 @@ class SegmentationTrainer(object):
     def on_training_end(self):
         pass
 
+    # ------------------------------------------------------------------------------------------------
+    # checkpoints (src/trainers.py:1167-1238, 1367-1389); the container is .npz whatever the file is called
+    # ------------------------------------------------------------------------------------------------
+    def _populate_path_template(self, path, *args, **kwargs):
+        """src/trainers.py:1136-1139: fills {model_folder} and any further fields the caller names (epoch, val_loss)."""
+        return path.format(model_folder=self.model_folder_name, *args, **kwargs)
+
+    @staticmethod
+    def _get_latest_weights_file_path(weights_directory_path, include_early_stop=False):
+        """The checkpoint '<str>.<epoch>-<val_loss>.<str>' with the largest epoch in the directory (of the given file)."""
+        folder = weights_directory_path if os.path.isdir(weights_directory_path) else os.path.dirname(weights_directory_path)
+        if not os.path.isdir(folder):
+            return None
+        files = sorted(os.listdir(folder))
+        if not include_early_stop:
+            files = [f for f in files if 'early_stop' not in f]
+        best, best_epoch = None, -100
+        for f in files:
+            if os.path.isfile(os.path.join(folder, f)) and ".hdf5" in f:
+                try:
+                    epoch = int(f.split('.')[1].rsplit('-', 1)[0])
+                except (IndexError, ValueError):
+                    continue
+                if epoch > best_epoch:
+                    best, best_epoch = f, epoch
+        return os.path.join(folder, best) if best is not None else None
+
+    def _load_latest_weights_for_model(self, model, weights_directory_path, include_early_stop=False) -> int:
+        """Loads the newest checkpoint into `model` and returns the epoch to continue from (0 when there is none)."""
+        path = self._get_latest_weights_file_path(weights_directory_path, include_early_stop=include_early_stop)
+        if path is None:
+            return 0
+        try:
+            model.load_weights(path)
+            return int(os.path.basename(path).split('.')[1].rsplit('-', 1)[0]) + 1
+        except Exception:      # src/trainers.py:1234-1236: any failure means "start from scratch"
+            return 0
+
+    def save_model_weights(self, epoch_index, val_loss, file_extension=''):
+        template = (self.config.get('keras_model_checkpoint') or {}).get('checkpoint_file_path') or self.config.get('keras_model_checkpoint_file_path')
+        if template is None:
+            raise ValueError('the configuration names no checkpoint file path')
+        file_path = self._populate_path_template(template, epoch=epoch_index, val_loss=val_loss) + file_extension
+        os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
+        self.model.save_weights(file_path, overwrite=True)
+        return file_path
+
+    def save_optimizer_settings(self, model, file_extension=''):
+        file_path = self._populate_path_template(self.config['optimizer_checkpoint_file_path']) + file_extension
+        os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
+        with open(file_path, 'w') as f:
+            f.write(json.dumps(model.optimizer.get_config()))
+        return file_path
+
     def global_confusion_matrix(self) -> np.ndarray:
         cm = self.model._cm.clone()
         if self.reducer is not None:

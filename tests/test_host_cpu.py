@@ -258,3 +258,21 @@ def test_predict_oracle_padding_known_answer():
     assert np.array_equal(x[3, 0], np.array([9.0, 8.0, 7.0], np.float32)) and np.array_equal(x[0, 0], x[3, 3])
     final, topk = P.finish([np.arange(4 * 4 * 3, dtype=np.float32).reshape(4, 4, 3)], [pads], 100.0, 2)
     assert final.shape == (3, 2, 3) and final[0, 0].tolist() == [300.0, 4.0, 5.0] and topk[:, 0, 0].tolist() == [0, 2]
+
+
+def test_latest_checkpoint_discovery(tmp_path):
+    """src/trainers.py:1167-1207: '<str>.<epoch>-<val_loss>.<str>' names, largest epoch wins, early-stop files are skipped
+    unless asked for, files without the .hdf5 marker or a parsable epoch are ignored."""
+    tr = pkg("trainers").SegmentationTrainer
+    d = tmp_path / "checkpoints"
+    d.mkdir()
+    for name in ("weights.02-0.75.hdf5", "weights.10-0.41.hdf5", "weights.09-0.40.hdf5", "weights.12-0.39.hdf5.early_stop",
+                 "notes.txt", "weights.xx-0.1.hdf5", "weights.11-0.2.npz"):
+        (d / name).write_bytes(b"")
+    f = tr._get_latest_weights_file_path
+    assert os.path.basename(f(str(d))) == "weights.10-0.41.hdf5"
+    assert os.path.basename(f(str(d / "weights.{epoch:02d}-{val_loss:.2f}.hdf5"))) == "weights.10-0.41.hdf5"
+    assert os.path.basename(f(str(d), include_early_stop=True)) == "weights.12-0.39.hdf5.early_stop"
+    assert f(str(tmp_path / "missing" / "x.hdf5")) is None
+    (tmp_path / "empty").mkdir()
+    assert f(str(tmp_path / "empty")) is None

@@ -242,3 +242,30 @@ def test_frozen_layers_and_optimizer_state_roundtrip(tmp_path):
     assert mbc.load_optimizer_weights(str(tmp_path / "ckpt.npz")) is True
     c.save_weights(str(tmp_path / "weights_only.npz"))
     assert mbc.load_optimizer_weights(str(tmp_path / "weights_only.npz")) is False
+
+
+def test_trainer_checkpoint_resume(tmp_path):
+    """save_model_weights / _load_latest_weights_for_model (src/trainers.py:1209-1238, 1367-1374): the newest checkpoint is
+    found by its epoch, restored bit for bit, and training continues from the following epoch."""
+    trainers = pkg("trainers")
+    cfg = {"input_shape": [None, None, 3], "random_seed": 8, "optimizer": {"name": "sgd", "learning_rate": 0.01, "momentum": 0.9},
+           "keras_model_checkpoint": {"checkpoint_file_path": str(tmp_path) + "/{model_folder}/checkpoints/weights.{epoch:02d}-{val_loss:.2f}.hdf5"},
+           "optimizer_checkpoint_file_path": str(tmp_path) + "/{model_folder}/checkpoints/optimizer/optimizer-checkpoint.json"}
+    tr = trainers.SegmentationTrainer("segmentation_supervised", "enet-max-unpooling", "run1", config=cfg, num_classes=24)
+    images, labels, pw = E.synthetic_batch(2, 32, 32, 24, seed=1, block=8)
+    x = [images, labels, pw, np.zeros((2, 1), np.int32)]
+    tr.model.train_on_batch(x, None)
+    p1 = tr.save_model_weights(epoch_index=1, val_loss=0.5)
+    w1 = tr.model.get_weights()
+    tr.model.train_on_batch(x, None)
+    p4 = tr.save_model_weights(epoch_index=4, val_loss=0.25)
+    w4 = tr.model.get_weights()
+    assert p1.endswith("run1/checkpoints/weights.01-0.50.hdf5") and p4.endswith("weights.04-0.25.hdf5")
+    oc = tr.save_optimizer_settings(tr.model)
+    import json
+    assert json.load(open(oc))["momentum"] == 0.9
+    tr2 = trainers.SegmentationTrainer("segmentation_supervised", "enet-max-unpooling", "run1", config=cfg, num_classes=24)
+    assert tr2._load_latest_weights_for_model(tr2.model, p1) == 5
+    assert all(np.array_equal(a, b) for a, b in zip(tr2.model.get_weights(), w4))
+    assert not all(np.array_equal(a, b) for a, b in zip(w1, w4))
+    assert tr2._load_latest_weights_for_model(tr2.model, str(tmp_path / "nothing" / "here.hdf5")) == 0
