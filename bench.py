@@ -190,7 +190,8 @@ def measure_roofline(model, stream, steps=3):
     kernel launch (forward and data gradient) with HIP events on the launch stream and records the kernel variant with
     the algorithmic bytes / flops of that launch (ssmi_profile_*).  The dominant kernel is the variant with the largest
     summed duration per step; its roofline entry is  sum(algorithmic work of its launches) / sum(their durations),
-    i.e. average work per launch over average launch duration, against the HBM peak when its arithmetic intensity is
+    i.e. average work per launch over average launch duration (net of the bracket's own cost, measured around an empty
+    kernel in the same run, so that it is comparable with a kernel trace's per-kernel duration), against the HBM peak when its arithmetic intensity is
     below the fp32-matrix ridge (157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B) and against the fp32 MFMA peak otherwise."""
     import ctypes as C
     L = pkg("_lib").lib()
@@ -207,12 +208,13 @@ def measure_roofline(model, stream, steps=3):
         L.profile_end(C.byref(cnt))
     model.use_hip_graph = True
     model.grad_sync = saved_sync
+    overhead_ms = float(L.profile_bracket_overhead_ms())      # what the event bracket adds around an empty kernel
     records = []
     name = C.create_string_buffer(128)
     ms, by, fl = C.c_float(), C.c_double(), C.c_double()
     for i in range(cnt.value):
         L.profile_get(i, name, 128, C.byref(ms), C.byref(by), C.byref(fl))
-        records.append((name.value.decode(), ms.value, by.value, fl.value))
+        records.append((name.value.decode(), max(ms.value - overhead_ms, 1e-4), by.value, fl.value))
     agg = {}
     for kernel, ms_, by, fl in records:
         r = agg.setdefault(kernel, [0.0, 0.0, 0.0, 0])
@@ -234,7 +236,7 @@ def measure_roofline(model, stream, steps=3):
               "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
               "arithmetic_intensity_flop_per_byte": round(ai, 2), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),
               "kernel_ms_per_step": round(ms / steps, 3), "all_conv_fwd_bwd_data_ms_per_step": round(conv_ms, 3),
-              "traffic": traffic}
+              "event_bracket_overhead_us": round(overhead_ms * 1e3, 2), "traffic": traffic}
     if ai < F32_MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:
         return dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4)}, **common)

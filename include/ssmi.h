@@ -48,6 +48,10 @@ const char* ssmi_last_kernel(void);
 ssmi_status ssmi_profile_begin(void);
 ssmi_status ssmi_profile_end(int32_t* count);
 ssmi_status ssmi_profile_get(int32_t index, char* name, int32_t name_len, float* ms, double* bytes, double* flops);
+/* What an event bracket adds to any launch: median time between two events recorded around an EMPTY kernel on the
+ * profiled stream, measured by the last ssmi_profile_end().  _get returns raw durations; subtract this to compare with a
+ * kernel trace (rocprofv3 reports the kernel's own begin/end timestamps). */
+float ssmi_profile_bracket_overhead_ms(void);
 int32_t ssmi_version(void);
 
 /* ------------------------------------------------------------------------------------------------------

@@ -97,6 +97,7 @@ _PROTOS = {
     "ssmi_predict_prepare": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssmi_predict_accumulate": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "ssmi_predict_topk": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "ssmi_profile_bracket_overhead_ms": (_f32, []),
     "ssmi_graph_begin_capture": (_i32, [_vp]),
     "ssmi_graph_end_capture": (_i32, [_vp, C.POINTER(_vp)]),
     "ssmi_graph_launch": (_i32, [_vp, _vp]),
@@ -104,7 +105,7 @@ _PROTOS = {
 }
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 

@@ -4,6 +4,7 @@
 #include <vector>
 
 #include "common.h"
+#include <algorithm>
 
 namespace ssmi {
 
@@ -114,10 +115,17 @@ struct ProfileRecord {
 };
 static bool g_profiling = false;
 static std::vector<ProfileRecord> g_records;
+static hipStream_t g_profile_stream = nullptr;
+static float g_bracket_overhead_ms = 0.f;
+
+// Calibration launch for the event brackets: its own execution time is negligible, so the time between the two events
+// around it is what the bracket itself adds to any kernel (event packets + the launch latency on either side).
+__global__ void profile_null_kernel() {}
 
 ProfileScope::ProfileScope(hipStream_t st, double bytes, double flops) : st_(st), bytes_(bytes), flops_(flops) {
   if (!g_profiling) return;
   if (hipEventCreate(&e0_) != hipSuccess || hipEventCreate(&e1_) != hipSuccess) { e0_ = e1_ = nullptr; return; }
+  g_profile_stream = st_;
   hipEventRecord(e0_, st_);
 }
 
@@ -154,6 +162,27 @@ ssmi_status ssmi_profile_begin(void) {
 ssmi_status ssmi_profile_end(int32_t* count) {
   SSMI_REQUIRE(count != nullptr, SSMI_E_INVALID_ARG, "profile_end: count is NULL");
   g_profiling = false;
+  g_bracket_overhead_ms = 0.f;
+  if (!g_records.empty()) {
+    // median of nine brackets around an empty kernel on the same stream (one untimed warm-up first)
+    float t[9];
+    hipEvent_t a, b;
+    SSMI_HIP(hipEventCreate(&a));
+    SSMI_HIP(hipEventCreate(&b));
+    for (int i = -1; i < 9; ++i) {
+      SSMI_HIP(hipEventRecord(a, g_profile_stream));
+      hipLaunchKernelGGL(profile_null_kernel, dim3(1), dim3(64), 0, g_profile_stream);
+      SSMI_HIP(hipEventRecord(b, g_profile_stream));
+      SSMI_HIP(hipEventSynchronize(b));
+      float ms = 0.f;
+      SSMI_HIP(hipEventElapsedTime(&ms, a, b));
+      if (i >= 0) t[i] = ms;
+    }
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    std::sort(t, t + 9);
+    g_bracket_overhead_ms = t[4];
+  }
   for (auto& r : g_records) {
     SSMI_HIP(hipEventSynchronize(r.e1));
     SSMI_HIP(hipEventElapsedTime(&r.ms, r.e0, r.e1));
@@ -170,6 +199,7 @@ ssmi_status ssmi_profile_get(int32_t index, char* name, int32_t name_len, float*
   *ms = r.ms; *bytes = r.bytes; *flops = r.flops;
   return SSMI_OK;
 }
+float ssmi_profile_bracket_overhead_ms(void) { return g_bracket_overhead_ms; }
 int32_t ssmi_version(void) { return 100; }
 
 ssmi_status ssmi_adam_step(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,
