@@ -1305,6 +1305,19 @@ static ssmi_status make_sizes(const Geo& g, Sizes* sz) {
 }
 
 // Picks the LDS-weight kernel when the kernel matrix fits in 64 KiB of LDS; returns false otherwise.
+// SSMI_CONV_KERNEL = "lds" / "direct" / "tile": forces a kernel family for A/B measurements and tests (0 = automatic)
+static int conv_kernel_override() {
+  static const int force = [] {
+    const char* e = getenv("SSMI_CONV_KERNEL");
+    if (e == nullptr) return 0;
+    if (e[0] == 'l') return 1;
+    if (e[0] == 'd') return 2;
+    if (e[0] == 't') return 3;
+    return 0;
+  }();
+  return force;
+}
+
 static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float* in, const float* w, const float* bias,
                             const float* add, float* out, hipStream_t st, ssmi_status* status, float* part = nullptr,
                             int* part_rows = nullptr, BnBwdArgs bb = BnBwdArgs{}) {
@@ -1319,14 +1332,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   a.tiles_x = a.tiles_y = a.pmin_y = a.pmin_x = a.PH = a.PW = a.CP = a.patch_off = 0;
   const int ntaps = g.kh * g.kw;
   if (ntaps > kMaxTaps) return false;
-  static const int force = [] {
-    const char* e = getenv("SSMI_CONV_KERNEL");     // "lds" / "direct" / "tile": overrides for A/B measurements
-    if (e == nullptr) return 0;
-    if (e[0] == 'l') return 1;
-    if (e[0] == 'd') return 2;
-    if (e[0] == 't') return 3;
-    return 0;
-  }();
+  const int force = conv_kernel_override();
   if (force == 2) return false;
   const int s = g.stride;
   const int qh = mode == 0 ? g.ho : (g.h + s - 1) / s, qw = mode == 0 ? g.wo : (g.w + s - 1) / s;
@@ -1447,12 +1453,114 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
 
 // bb.x != nullptr (stride 1 only): the kernel also writes the column sums of the fused BN backward to bb.part[row][3][cin];
 // *part_rows = rows.
+// ---------------------------------------------------------------------------------------------------
+// 2x2 / stride-2 data gradient = forward of a 2x2 / stride-2 transposed convolution ("pixel shuffle"): every dy pixel
+// owns a private 2x2 block of dx, so the four stride phases are four column groups of ONE GEMM
+//     dx[n, 2y+a, 2x+b, ci] = bias[ci] + add[...] + sum_co dy[n, y, x, co] * w[a, b, ci, co]
+//     C[p, j] = sum_k A[p, k] * w[j * cout + k],   j = (a*2 + b) * cin + ci
+// A wave owns 32 dy pixels x NT*32 columns: dy is read once (not once per phase), and for x_ld == cin the columns of
+// one output row (a fixed) are 2*cin contiguous floats, so a store instruction writes 128 contiguous bytes.
+// ---------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void conv_bwd_data_2x2s2_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ add,
+                                                                  const float* __restrict__ bias, float* __restrict__ dx) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const unsigned M = (unsigned)(g.n * g.ho * g.wo);
+  const unsigned tile0 = (blockIdx.x * 4u + (unsigned)wave) * 32u;
+  if (tile0 >= M) return;
+  const int N = 4 * g.cin;
+  const int jbase = blockIdx.y * 32 * NT;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
+  const unsigned p = tile0 + (unsigned)r;
+  const unsigned yo = p < M ? p * (unsigned)g.y_ld * 4u : kOOB;
+  unsigned wo_[NT];
+  bool jv[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = jbase + t * 32 + r;
+    jv[t] = j < N;
+    wo_[t] = jv[t] ? (unsigned)j * (unsigned)g.cout * 4u : kOOB;
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // reduction over cout in blocks of 8 (lane half hh takes channels 4*hh.. of the block for A and B alike)
+  auto fetch = [&](int k0, f32x4& a, f32x4 (&b)[NT]) {
+    const unsigned ko = k0 < g.cout ? (unsigned)(k0 + 4 * hh) * 4u : kOOB;
+    a = bload4(ry, (yo + ko) | ((yo | ko) & kOOB));
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b[t] = bload4(rw, (wo_[t] + ko) | ((wo_[t] | ko) & kOOB));
+  };
+  auto mma = [&](const f32x4& a, const f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[q], b[t][q], acc[t]);
+  };
+  f32x4 a0, a1, b0[NT], b1[NT];
+  fetch(0, a0, b0);
+  for (int k0 = 0; k0 < g.cout; k0 += 16) {
+    fetch(k0 + 8, a1, b1);             // past the end: zeros
+    mma(a0, b0);
+    fetch(k0 + 16, a0, b0);
+    if (k0 + 8 < g.cout) mma(a1, b1);
+  }
+  // epilogue: dx pixel of (p, a, b) = 4p - 2x + a*W + b  (W = 2*wo; x = p mod wo)
+  const __amdgpu_buffer_rsrc_t rdx = make_rsrc(dx, sz.x_bytes);
+  const __amdgpu_buffer_rsrc_t radd = make_rsrc(add ? add : dx, add ? sz.x_bytes : 0u);
+  const unsigned x0 = tile0 % (unsigned)g.wo;
+  unsigned rowpix[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const unsigned off = (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+    const unsigned po = tile0 + off;
+    const unsigned xi = (x0 + off) % (unsigned)g.wo;
+    rowpix[i] = po < M ? 4u * po - 2u * xi : 0xFFFFFFFFu;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int j = jbase + t * 32 + r;
+    const int ph = jv[t] ? j / g.cin : 0;
+    const int ci = jv[t] ? j - ph * g.cin : 0;
+    const unsigned coff = (unsigned)((ph >> 1) * g.w + (ph & 1));      // pixel offset of the phase inside the 2x2 block
+    const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cin * 4u), jv[t] ? (unsigned)ci * 4u : kOOB) : 0.f;
+    unsigned o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      o[i] = (jv[t] && rowpix[i] != 0xFFFFFFFFu) ? ((rowpix[i] + coff) * (unsigned)g.x_ld + (unsigned)ci) * 4u : kOOB;
+    float av[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) av[i] = bload(radd, o[i]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) bstore(rdx, o[i], acc[t][i] + bv + av[i]);
+  }
+}
+
 static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w, const float* add, const float* bias,
                                    float* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
   ProfileScope prof(st, conv_bytes(g, add != nullptr), conv_flops(g));
+  if (g.kh == 2 && g.kw == 2 && g.stride == 2 && g.dil == 1 && g.pad_t == 0 && g.pad_l == 0 && g.h == 2 * g.ho &&
+      g.w == 2 * g.wo && g.cout % 8 == 0 && g.y_ld % 4 == 0 && bb.x == nullptr && part_rows == nullptr &&
+      ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 && conv_kernel_override() == 0) {
+    const int N = 4 * g.cin;
+    const int nt = N <= 32 ? 1 : (N <= 64 ? 2 : (N % 96 == 0 ? 3 : 4));
+    const int64_t M = (int64_t)g.n * g.ho * g.wo;
+    dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((N + 32 * nt - 1) / (32 * nt)), 1);
+    set_last_kernel("conv_bwd_data_2x2s2_kernel<%d>", nt);
+#define L(NT) hipLaunchKernelGGL((conv_bwd_data_2x2s2_kernel<NT>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx)
+    if (nt == 1) L(1); else if (nt == 2) L(2); else if (nt == 3) L(3); else L(4);
+#undef L
+    SSMI_LAUNCH_CHECK();
+    return SSMI_OK;
+  }
   if (launch_gemm_lds(g, sz, 1, dy, w, bias, add, dx, st, &e, nullptr, part_rows, bb)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.h * g.w, 128);
   const int s = g.stride;

@@ -96,7 +96,7 @@ def test_conv2d_fwd_bwd(case):
         _check(store.gviews["c/bias"], bt.grad, "db")
 
 
-@pytest.mark.parametrize("k,cin,cout,N,H,W", [(3, 16, 16, 2, 6, 5), (3, 4, 4, 1, 8, 8), (2, 16, 24, 2, 5, 7), (2, 16, 5, 1, 4, 4)])
+@pytest.mark.parametrize("k,cin,cout,N,H,W", [(3, 16, 16, 2, 6, 5), (3, 4, 4, 1, 8, 8), (2, 16, 24, 2, 5, 7), (2, 16, 5, 1, 4, 4), (2, 16, 24, 1, 3, 40), (2, 32, 64, 2, 4, 33)])
 def test_conv2d_transpose_fwd_bwd(k, cin, cout, N, H, W):
     eng = pkg("engine")
     rng = np.random.RandomState(k * 100 + cin)
