@@ -1791,8 +1791,12 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
   }
 
   const int spb = p.use_lds ? 1 : 4 / a.wps;
-  // about two workgroups per CU per tile group; more strips only add partial-sum traffic
-  int target = ((p.use_lds ? 512 : 256) * spb) / p.groups;
+  // About one workgroup per CU per tile group.  Every strip writes a full [K_aug x cout] partial sum that the reduce
+  // kernel reads back, which at 512 strips is more traffic than the operands themselves; the weight gradients run
+  // beside the data-gradient chain on their own stream, so they do not need to fill the chip on their own
+  // (ENet step: 512 strips 11.12 ms, 256: 10.88, 128: 11.56).  SSMI_WG_STRIPS overrides for measurements.
+  static const int strips_lds = [] { const char* e = getenv("SSMI_WG_STRIPS"); return e ? atoi(e) : 256; }();
+  int target = ((p.use_lds ? strips_lds : 256) * spb) / p.groups;
   if (target < spb) target = spb;
   if (target > R) target = R;
   a.rows_per_strip = (R + target - 1) / target;
