@@ -298,6 +298,14 @@ ssmi_status ssmi_superpixel_cost_fwd_bwd(const float* logits, const int32_t* mas
                                          float* dlogits, int32_t accumulate_grad, float* loss_io, int32_t accumulate_loss,
                                          float* cost_out, void* ws, size_t ws_bytes, void* stream);
 
+/* Classification cost of the encoder-only models (src/losses.py:579-588 called from
+ * classification_categorical_crossentropy_lambda_loss :636-652): y_true [n, classes] soft / multi-hot labels, weights
+ * [n, classes]:  loss = -mean_n sum_c y * log(clip(softmax(logits), epsilon, 1)) * w   (settings.EPSILON = 1e-6);
+ * dlogits (nullable) = grad_scale * dloss/dlogits; the clip passes no gradient below epsilon. */
+ssmi_status ssmi_classification_xent_fwd_bwd(const float* logits, const float* y_true, const float* weights, int32_t n,
+                                             int32_t num_classes, float epsilon, float grad_scale, float* dlogits,
+                                             float* loss_out, void* stream);
+
 /* Teacher weights as an exponential moving average of the student's (src/trainers.py:1692-1706):
  *   teacher[i] = fl32(fl32(a) * teacher[i]) + fl32(fl32(1 - a) * student[i])   (no fused multiply-add, like numpy)
  * applied to a whole arena; `1 - a` is formed in double before rounding, as the reference's Python float does. */
@@ -340,6 +348,11 @@ ssmi_status ssmi_copy_ld(const float* src, int32_t src_ld, float* dst, int32_t d
                          int32_t accumulate, void* stream);
 /* SpatialDropout2D as its own layer (src/models.py:876): y[n,p,c] = x[n,p,c] * table[n,c]; the same call is its gradient. */
 ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t n, int64_t hw, int32_t c, void* stream);
+/* AveragePooling2D with the pool size of the whole map + Flatten, and GlobalAveragePooling2D (the heads of the
+ * encoder-only models, src/models.py:985-993, 1040-1048, 1347-1354, 1667): y[n, c] = mean over hw pixels of x[n, p, c];
+ * backward dx[n, p, c] = dy[n, c] / hw. */
+ssmi_status ssmi_global_avgpool_fwd(const float* x, int32_t n, int64_t hw, int32_t c, float* y, void* stream);
+ssmi_status ssmi_global_avgpool_bwd(const float* dy, int32_t n, int64_t hw, int32_t c, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Input contract on the device (src/generators.py:711-770, 1787-1825): from the uint8 crops of a batch to the tensors

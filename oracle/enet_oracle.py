@@ -107,10 +107,27 @@ def _dec_bottleneck_spec(spec, p, cin, cout, upsample, variant):
     _prelu(spec, p + "_prelu_3", cout)
 
 
+ENCODER_ONLY = "-encoder-only"      # src/models.py:83-124: names of the classification variants
+
+
+def split_name(model_name: str) -> Tuple[str, bool]:
+    """(segmentation model name, encoder_only)."""
+    if model_name.endswith(ENCODER_ONLY):
+        return model_name[:-len(ENCODER_ONLY)], True
+    return model_name, False
+
+
+def _dense(spec, name, cin, cout):
+    """Keras Dense: kernel (in, out) glorot_uniform, bias zeros."""
+    spec.append((name + "/kernel", (cin, cout), "glorot_uniform", 0))
+    spec.append((name + "/bias", (cout,), "zeros", 0))
+
+
 def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str, int]]:
     """[(key, shape, initializer, fan_in)] in layer-creation order."""
+    model_name, encoder_only = split_name(model_name)
     if model_name in VGG_STYLE:
-        return V.weight_spec(model_name, num_classes)
+        return V.weight_spec(model_name, num_classes, encoder_only)
     if model_name == "enet-naive-upsampling":
         variant = "naive"
     elif model_name == "enet-max-unpooling":
@@ -132,6 +149,9 @@ def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str
     for stage in (2, 3):
         for suffix, kw in ENC_PATTERN:
             _enc_bottleneck_spec(spec, "en_bn_{}.{}".format(stage, suffix), 128, 128, **kw)
+    if encoder_only and variant != "enhanced":      # src/models.py:1040-1048, 1346-1354
+        _dense(spec, "logits", 128, num_classes)
+        return spec
     _dec_bottleneck_spec(spec, "de_bn_4.0", 128, 64, True, variant)
     _dec_bottleneck_spec(spec, "de_bn_4.1", 64, 64, False, variant)
     _dec_bottleneck_spec(spec, "de_bn_4.2", 64, 64, False, variant)
@@ -141,7 +161,9 @@ def weight_spec(model_name: str, num_classes: int) -> List[Tuple[str, tuple, str
         _conv(spec, "final_nn_rs_conv_conv2d", 3, 3, 16, num_classes, True)
         _bn(spec, "final_nn_rs_conv_bnorm", num_classes)
         _prelu(spec, "final_nn_rs_conv_prelu", num_classes)
-        _conv(spec, "logits", 1, 1, num_classes, num_classes, True)
+        _conv(spec, "decoder_logits" if encoder_only else "logits", 1, 1, num_classes, num_classes, True)
+        if encoder_only:      # src/models.py:1665-1668
+            _dense(spec, "logits", num_classes, num_classes)
         return spec
     spec.append(("logits/kernel", (2, 2, num_classes, 16), "he_normal", 2 * 2 * 16))
     spec.append(("logits/bias", (num_classes,), "zeros", 0))
@@ -157,6 +179,9 @@ def init_weights(model_name: str, num_classes: int, seed: int = 14874, perturb: 
     for key, shape, init, fan_in in weight_spec(model_name, num_classes):
         if init == "he_normal":
             w = rng.standard_normal(shape) * np.sqrt(2.0 / fan_in)
+        elif init == "glorot_uniform" and len(shape) == 2:
+            lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+            w = rng.uniform(-lim, lim, size=shape)
         elif init == "glorot_uniform":
             kh, kw, cin, cout = shape
             lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
@@ -181,8 +206,9 @@ def init_weights(model_name: str, num_classes: int, seed: int = 14874, perturb: 
 
 def dropout_layer_rates(model_name: str) -> "OrderedDict[str, Tuple[float, int]]":
     """{sdrop layer name: (rate, channels)} in creation order."""
+    model_name, encoder_only = split_name(model_name)
     if model_name in VGG_STYLE:
-        return V.dropout_layer_rates(model_name)
+        return V.dropout_layer_rates(model_name, encoder_only)
     out: "OrderedDict[str, Tuple[float, int]]" = OrderedDict()
     out["en_bn_1.0_sdrop2d_1"] = (0.01, 64)
     for i in range(4):
@@ -191,7 +217,7 @@ def dropout_layer_rates(model_name: str) -> "OrderedDict[str, Tuple[float, int]]
     for stage in (2, 3):
         for suffix, _ in ENC_PATTERN:
             out["en_bn_{}.{}_sdrop2d_1".format(stage, suffix)] = (0.1, 128)
-    if model_name in ("enet-naive-upsampling", "enet-naive-upsampling-enhanced"):
+    if (model_name == "enet-naive-upsampling" and not encoder_only) or model_name == "enet-naive-upsampling-enhanced":
         for nm, c in (("de_bn_4.0", 64), ("de_bn_4.1", 64), ("de_bn_4.2", 64), ("de_bn_5.0", 16), ("de_bn_5.1", 16)):
             out[nm + "_sdrop2d_1"] = (0.1, c)
     return out
@@ -295,13 +321,21 @@ def _dec_bottleneck(c: _Ctx, x, cout, p, upsample, variant, idx=None):
     return c.prelu(p + "_prelu_3", d + other)
 
 
+def classifier_head(c, x):
+    """AveragePooling2D over the whole map (GlobalAveragePooling2D for the enhanced variant) -> Flatten -> Dense 'logits'
+    (src/models.py:985-993, 1040-1048, 1667-1668)."""
+    pooled = c.keep("avg_pool2d", x.mean(dim=(1, 2)))
+    return pooled @ c.p["logits/kernel"] + c.p["logits/bias"]
+
+
 def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch.Tensor, training: bool = True,
                  drop_masks=None, collect: bool = False):
     """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
     ctx.acts the named intermediate tensors when collect=True."""
+    model_name, encoder_only = split_name(model_name)
     if model_name in VGG_STYLE:
         c = _Ctx(params, training, drop_masks, collect)
-        return V.forward(model_name, c, images), c
+        return V.forward(model_name, c, images, encoder_only), c
     variant = {"enet-naive-upsampling": "naive", "enet-max-unpooling": "unpool",
                "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)
     if variant is None:
@@ -333,6 +367,8 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
         for suffix, kw in ENC_PATTERN:
             x = _enc_bottleneck(c, x, 128, "en_bn_{}.{}".format(stage, suffix), **kw)
     c.keep("encoder", x)
+    if encoder_only and variant != "enhanced":
+        return classifier_head(c, x), c
     x = _dec_bottleneck(c, x, 64, "de_bn_4.0", True, variant, idx_stack.pop() if want else None)
     x = _dec_bottleneck(c, x, 64, "de_bn_4.1", False, variant)
     x = _dec_bottleneck(c, x, 64, "de_bn_4.2", False, variant)
@@ -341,7 +377,9 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
     if variant == "enhanced":
         x = c.conv("final_nn_rs_conv_conv2d", K.upsample_nn2(x))
         x = c.prelu("final_nn_rs_conv_prelu", c.bn("final_nn_rs_conv_bnorm", x))
-        logits = c.conv("logits", x)
+        logits = c.conv("decoder_logits" if encoder_only else "logits", x)
+        if encoder_only:
+            logits = classifier_head(c, logits)
     else:
         logits = c.tconv("logits", x)
     return logits, c
@@ -357,7 +395,7 @@ def trainable_keys(model_name: str, num_classes: int) -> List[str]:
 def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images: np.ndarray, labels: np.ndarray,
                pixel_weights: np.ndarray, drop_masks=None, dtype=torch.float64, collect=False,
                adam: Optional[dict] = None, adam_state: Optional[dict] = None, ignore_classes=(0,),
-               mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None):
+               mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None, classification: bool = False):
     """One supervised training step exactly as the reference assembles it
     (src/trainers.py:2436-2440: total = 1*loss + 0*mean(0*logits)):
     forward (training phase) -> weighted CE -> gradients -> BN moving-average updates -> optional Adam.
@@ -373,9 +411,16 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
     x = torch.tensor(images, dtype=dtype)
     masks = {k: torch.tensor(v, dtype=dtype) for k, v in (drop_masks or {}).items()}
     logits, ctx = enet_forward(model_name, params, x, True, masks, collect)
-    lab = torch.tensor(labels.astype(np.int64))
-    w = torch.tensor(pixel_weights, dtype=dtype)
-    if mean_teacher is None and superpixel is None:
+    if classification:      # labels / pixel_weights are [B, classes] float arrays (src/losses.py:636-652)
+        lab = torch.tensor(labels, dtype=dtype)
+        w = torch.tensor(pixel_weights, dtype=dtype)
+        loss = K.classification_weighted_categorical_crossentropy(lab, logits, w)
+    else:
+        lab = torch.tensor(labels.astype(np.int64))
+        w = torch.tensor(pixel_weights, dtype=dtype)
+    if classification:
+        pass
+    elif mean_teacher is None and superpixel is None:
         loss = K.segmentation_cce_lambda_loss(logits, lab, w, 0)
     else:
         nu = int((mean_teacher or superpixel)["num_unlabeled"])
@@ -410,7 +455,7 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
             new_w[k] = p.numpy()
             st["m"][k], st["v"][k] = m, v
         st["iterations"] += 1
-    cm = K.confusion_matrix_np(labels, logits.detach().numpy(), num_classes, ignore_classes)
+    cm = None if classification else K.confusion_matrix_np(labels, logits.detach().numpy(), num_classes, ignore_classes)
     out = dict(loss=float(loss.detach()), logits=logits.detach().numpy(), grads=gdict, new_weights=new_w, cm=cm)
     if collect:
         out["acts"] = {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in ctx.acts.items()}

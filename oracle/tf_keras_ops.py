@@ -290,6 +290,13 @@ def segmentation_mean_teacher_superpixel_lambda_loss(logits, labels, weights, nu
     return loss
 
 
+def classification_weighted_categorical_crossentropy(y_true, y_pred, class_weights, epsilon=SUPERPIXEL_EPSILON):
+    """src/losses.py:579-588: -mean_n sum_c y_true * log(clip(softmax(y_pred), eps, 1)) * class_weights (tf.clip_by_value
+    passes the gradient inside [eps, 1] only, like torch.clamp)."""
+    sm = torch.clamp(torch.softmax(y_pred, dim=-1), epsilon, 1.0)
+    return -torch.mean(torch.sum(y_true * torch.log(sm) * class_weights, dim=-1))
+
+
 def ema_update_np(teacher, student, a):
     """src/trainers.py:1692-1706 on lists of float32 numpy arrays; `a` is a Python float, so numpy keeps float32."""
     return [a * t + ((1.0 - a) * s) for t, s in zip(teacher, student)]

@@ -48,9 +48,11 @@ def topology(model_name: str):
     return enc, connect, dec
 
 
-def conv_blocks(model_name: str) -> List[Tuple[str, int, int, bool, bool]]:
+def conv_blocks(model_name: str, encoder_only: bool = False) -> List[Tuple[str, int, int, bool, bool]]:
     """Every convolution block in creation order: (name, cin, cout, use_bias, use_activation)."""
     enc, connect, dec = topology(model_name)
+    if encoder_only:      # src/models.py:985-993: the head sits on pool4
+        connect, dec = [], []
     out = []
     c = 3
     widths = []
@@ -70,11 +72,11 @@ def conv_blocks(model_name: str) -> List[Tuple[str, int, int, bool, bool]]:
     return out
 
 
-def weight_spec(model_name: str, num_classes: int):
+def weight_spec(model_name: str, num_classes: int, encoder_only: bool = False):
     """[(key, shape, initializer, fan_in)] in layer-creation order (Keras get_weights() order)."""
     spec = []
     last = 3
-    for name, cin, cout, bias, _ in conv_blocks(model_name):
+    for name, cin, cout, bias, _ in conv_blocks(model_name, encoder_only):
         spec.append((name + "/kernel", (3, 3, cin, cout), "he_normal", 9 * cin))
         if bias:
             spec.append((name + "/bias", (cout,), "zeros", 0))
@@ -84,13 +86,17 @@ def weight_spec(model_name: str, num_classes: int):
         spec.append((bn + "/moving_mean", (cout,), "zeros", 0))
         spec.append((bn + "/moving_variance", (cout,), "ones", 0))
         last = cout
+    if encoder_only:      # Dense: kernel (in, out), glorot_uniform
+        spec.append(("logits/kernel", (last, num_classes), "glorot_uniform", 0))
+        spec.append(("logits/bias", (num_classes,), "zeros", 0))
+        return spec
     spec.append(("logits/kernel", (1, 1, last, num_classes), "he_normal", last))
     spec.append(("logits/bias", (num_classes,), "zeros", 0))
     return spec
 
 
-def dropout_layer_rates(model_name: str) -> "OrderedDict[str, Tuple[float, int]]":
-    return OrderedDict((name + "_dropout", (DROP_RATE, cout)) for name, _, cout, _, _ in conv_blocks(model_name))
+def dropout_layer_rates(model_name: str, encoder_only: bool = False) -> "OrderedDict[str, Tuple[float, int]]":
+    return OrderedDict((name + "_dropout", (DROP_RATE, cout)) for name, _, cout, _, _ in conv_blocks(model_name, encoder_only))
 
 
 def _conv_block(c, x, name, act):
@@ -102,7 +108,7 @@ def _conv_block(c, x, name, act):
     return c.keep(name + "_dropout", c.sdrop(name + "_dropout", y))
 
 
-def forward(model_name: str, c, images):
+def forward(model_name: str, c, images, encoder_only: bool = False):
     """`c` is the oracle context of enet_oracle (_Ctx): named conv / bn / sdrop application."""
     enc, connect, dec = topology(model_name)
     x = images
@@ -112,6 +118,9 @@ def forward(model_name: str, c, images):
             x = _conv_block(c, x, "{}_conv{}".format(prefix, i + 1), True)
         skips.append(x)
         x = c.keep(prefix + "_pool", K.max_pool_2x2(x))
+    if encoder_only:      # AveragePooling2D(pool4's spatial size) -> Flatten -> Dense (src/models.py:985-993)
+        pooled = c.keep("avg_pool2d", x.mean(dim=(1, 2)))
+        return pooled @ c.p["logits/kernel"] + c.p["logits/bias"]
     for name, _ in connect:
         x = _conv_block(c, x, name, True)
     for prefix, n, _, skip in dec:

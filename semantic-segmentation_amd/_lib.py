@@ -83,6 +83,9 @@ _PROTOS = {
     "ssmi_superpixel_workspace_bytes": (_sz, [_i64, _i32]),
     "ssmi_superpixel_cost_fwd_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _f32, _f32, _vp, _i32, _vp, _i32, _vp, _vp,
                                             _sz, _vp]),
+    "ssmi_classification_xent_fwd_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _f32, _f32, _vp, _vp, _vp]),
+    "ssmi_global_avgpool_fwd": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
+    "ssmi_global_avgpool_bwd": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp]),
     "ssmi_ema_update": (_i32, [_vp, _vp, C.c_double, _i64, _vp]),
     "ssmi_metrics_from_cm": (_i32, [_vp, _i32, _u64, C.POINTER(C.c_double)]),
     "ssmi_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),

@@ -389,6 +389,53 @@ __global__ __launch_bounds__(256) void sp_apply_kernel(const float* __restrict__
   }
 }
 
+
+// Classification cost of the encoder-only models (src/losses.py:579-588): soft / multi-hot labels y [n, C], per-sample
+// per-class weights w [n, C]:  loss = -mean_n sum_c y * log(clip(softmax(z), eps, 1)) * w.  The clip passes no gradient
+// where the softmax is below eps.  One workgroup; thread = sample; the per-sample terms are added in order (deterministic).
+__global__ __launch_bounds__(256) void classification_xent_kernel(const float* __restrict__ logits, const float* __restrict__ y,
+                                                                  const float* __restrict__ w, int n, int C, float eps,
+                                                                  float grad_scale, float* __restrict__ dlogits,
+                                                                  float* __restrict__ loss_out) {
+  __shared__ float sm[256];
+  float local = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float* z = logits + (int64_t)i * C;
+    const float* yi = y + (int64_t)i * C;
+    const float* wi = w + (int64_t)i * C;
+    float mx = z[0];
+    for (int j = 1; j < C; ++j) mx = fmaxf(mx, z[j]);
+    float se = 0.f;
+    for (int j = 0; j < C; ++j) se += __expf(z[j] - mx);
+    const float inv = 1.f / se;
+    float li = 0.f, gsum = 0.f;      // gsum = sum_c (dL/ds_c) * s_c over the unclipped classes
+    for (int j = 0; j < C; ++j) {
+      const float s = __expf(z[j] - mx) * inv;
+      const float sc = fminf(fmaxf(s, eps), 1.f);
+      li += yi[j] * __logf(sc) * wi[j];
+      if (s >= eps) gsum += yi[j] * wi[j];     // d(log s)/ds * s = 1
+    }
+    local -= li;
+    if (dlogits) {
+      const float k = grad_scale / (float)n;
+      float* d = dlogits + (int64_t)i * C;
+      for (int j = 0; j < C; ++j) {
+        const float s = __expf(z[j] - mx) * inv;
+        const float a = s >= eps ? yi[j] * wi[j] : 0.f;      // -dL_i/dlog(s_j)
+        d[j] = -k * (a - s * gsum);
+      }
+    }
+  }
+  sm[threadIdx.x] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    const int m = n < 256 ? n : 256;
+    for (int i = 0; i < m; ++i) t += sm[i];
+    *loss_out = t / (float)n;
+  }
+}
+
 // teacher = a * teacher + (1 - a) * student, evaluated in this order (src/trainers.py:1704)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ teacher, const float* __restrict__ student, float a,
                                                   float one_minus_a, int64_t count) {
@@ -507,6 +554,17 @@ ssmi_status ssmi_superpixel_cost_fwd_bwd(const float* logits, const int32_t* mas
   }
   hipLaunchKernelGGL(mt_consistency_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, coef_dev, accumulate_loss,
                      loss_io, cost_out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_classification_xent_fwd_bwd(const float* logits, const float* y_true, const float* weights, int32_t n,
+                                             int32_t num_classes, float epsilon, float grad_scale, float* dlogits,
+                                             float* loss_out, void* stream) {
+  SSMI_REQUIRE(logits && y_true && weights && loss_out && n > 0 && num_classes > 0, SSMI_E_INVALID_ARG,
+               "classification_xent: bad argument");
+  hipLaunchKernelGGL(classification_xent_kernel, dim3(1), dim3(256), 0, as_stream(stream), logits, y_true, weights, n,
+                     num_classes, epsilon, grad_scale, dlogits, loss_out);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }

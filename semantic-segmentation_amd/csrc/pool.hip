@@ -196,6 +196,41 @@ static inline int grid_for(int64_t total) {
   return (int)b;
 }
 
+
+// AveragePooling2D over the whole map / GlobalAveragePooling2D (src/models.py:1044-1046, 1667): y[n, c] = mean_p x[n, p, c].
+// One workgroup per (image, 64-channel group): 4 pixel slices x 64 channels, each slice adds its pixels in order, the four
+// slices are combined through LDS in a fixed order (deterministic), then one multiplication by 1 / pixels.
+__global__ __launch_bounds__(256) void global_avgpool_fwd_kernel(const float* __restrict__ x, int64_t hw, int c,
+                                                                 float* __restrict__ y) {
+  __shared__ float sm[256];
+  const int ch = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+  const float* xb = x + (int64_t)blockIdx.x * hw * c;
+  float s0 = 0.f, s1 = 0.f;
+  if (ch < c) {
+    int64_t p = slice;
+    for (; p + 4 < hw; p += 8) {
+      s0 += xb[p * c + ch];
+      s1 += xb[(p + 4) * c + ch];
+    }
+    if (p < hw) s0 += xb[p * c + ch];
+  }
+  sm[threadIdx.x] = s0 + s1;
+  __syncthreads();
+  if (slice == 0 && ch < c) {
+    const float t = (sm[threadIdx.x] + sm[threadIdx.x + 64]) + (sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
+    y[(int64_t)blockIdx.x * c + ch] = t / (float)hw;
+  }
+}
+
+__global__ __launch_bounds__(256) void global_avgpool_bwd_kernel(const float* __restrict__ dy, int64_t hw, int c,
+                                                                 float* __restrict__ dx, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % c);
+    const int64_t n = i / ((int64_t)hw * c);
+    dx[i] = dy[n * c + ch] / (float)hw;
+  }
+}
+
 }  // namespace ssmi
 
 using namespace ssmi;
@@ -312,6 +347,22 @@ ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t 
 ssmi_status ssmi_fill_f32(float* dst, float value, int64_t count, void* stream) {
   SSMI_REQUIRE(dst && count > 0, SSMI_E_INVALID_ARG, "fill_f32: bad argument");
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(count)), dim3(256), 0, as_stream(stream), dst, value, count);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_global_avgpool_fwd(const float* x, int32_t n, int64_t hw, int32_t c, float* y, void* stream) {
+  SSMI_REQUIRE(x && y && n > 0 && hw > 0 && c > 0, SSMI_E_INVALID_ARG, "global_avgpool_fwd: bad argument");
+  hipLaunchKernelGGL(global_avgpool_fwd_kernel, dim3((unsigned)n, (unsigned)((c + 63) / 64)), dim3(256), 0, as_stream(stream), x,
+                     hw, c, y);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_global_avgpool_bwd(const float* dy, int32_t n, int64_t hw, int32_t c, float* dx, void* stream) {
+  SSMI_REQUIRE(dy && dx && n > 0 && hw > 0 && c > 0, SSMI_E_INVALID_ARG, "global_avgpool_bwd: bad argument");
+  const int64_t total = (int64_t)n * hw * c;
+  hipLaunchKernelGGL(global_avgpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, hw, c, dx, total);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }

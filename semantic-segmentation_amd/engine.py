@@ -98,6 +98,9 @@ class ParamStore:
         for k, s in self.specs.items():
             if s.init == "he_normal":
                 v = rng.standard_normal(s.shape) * np.sqrt(2.0 / s.fan_in)
+            elif s.init == "glorot_uniform" and len(s.shape) == 2:      # Dense
+                lim = np.sqrt(6.0 / (s.shape[0] + s.shape[1]))
+                v = rng.uniform(-lim, lim, size=s.shape)
             elif s.init == "glorot_uniform":
                 kh, kw, cin, cout = s.shape
                 lim = np.sqrt(6.0 / (kh * kw * cin + kh * kw * cout))
@@ -118,10 +121,13 @@ class Conv:
     transposed layer's own in/out channel counts and the kernel has the Keras layout (kh, kw, out, in)."""
 
     def __init__(self, store: ParamStore, name, kh, kw, cin, cout, stride=1, dil=1, padding="same", bias=True,
-                 transpose=False, init="he_normal"):
+                 transpose=False, init="he_normal", kernel_shape=None):
         self.name, self.kh, self.kw, self.cin, self.cout = name, kh, kw, cin, cout
         self.stride, self.dil, self.padding, self.transpose = stride, dil, padding, transpose
-        if transpose:
+        if kernel_shape is not None:      # a Keras Dense kernel (cin, cout): the same memory as a 1x1 convolution kernel
+            assert int(np.prod(kernel_shape)) == kh * kw * cin * cout and not transpose
+            store.add(name + "/kernel", kernel_shape, True, init, kh * kw * cin)
+        elif transpose:
             store.add(name + "/kernel", (kh, kw, cout, cin), True, init, kh * kw * cin)
         else:
             store.add(name + "/kernel", (kh, kw, cin, cout), True, init, kh * kw * cin)
@@ -611,13 +617,13 @@ class EnhancedHead(Block):
     """Head of the enhanced decoder (src/models.py:1779-1794): nearest 2x upsampling -> 3x3 conv (16 -> classes) ->
     BN -> PReLU -> 1x1 conv named 'logits'."""
 
-    def __init__(self, store, cin, num_classes):
-        self.name = "logits"
+    def __init__(self, store, cin, num_classes, final_layer_name="logits"):
+        self.name = final_layer_name
         self.cin, self.num_classes = cin, num_classes
         self.conv_a = Conv(store, "final_nn_rs_conv_conv2d", 3, 3, cin, num_classes, bias=True)
         self.bn = BatchNorm(store, "final_nn_rs_conv_bnorm", num_classes)
         self.bn.add_prelu(store, "final_nn_rs_conv_prelu")
-        self.conv = Conv(store, "logits", 1, 1, num_classes, num_classes, padding="valid", bias=True)
+        self.conv = Conv(store, final_layer_name, 1, 1, num_classes, num_classes, padding="valid", bias=True)
 
     def convs(self):
         return [self.conv_a, self.conv]
@@ -660,6 +666,42 @@ class EnhancedHead(Block):
         cfg.wgrad(self.conv_a, self.xu, self.dya)
         self.conv_a.bwd_data(self.dya, self.dxu, cfg.st)
         L.upsample_nn2x_bwd(_ptr(self.dxu), self.cin, self.n, self.h, self.w, self.cin, _ptr(self.dx), cfg.st)
+        return self.dx
+
+
+class ClassifierHead(Block):
+    """Head of the encoder-only models (src/models.py:985-993, 1040-1048, 1347-1354, 1667-1668): average pooling over the
+    whole map -> Flatten -> Dense(num_classes) named 'logits'.  The Dense layer runs as a 1x1 convolution over n pixels."""
+
+    def __init__(self, store, cin, num_classes):
+        self.name = "logits"
+        self.cin, self.num_classes = cin, num_classes
+        self.dense = Conv(store, "logits", 1, 1, cin, num_classes, padding="valid", bias=True, init="glorot_uniform",
+                          kernel_shape=(cin, num_classes))
+
+    def convs(self):
+        return [self.dense]
+
+    def plan(self, n, h, w, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.n, self.hw = n, h * w
+        self.dense.plan(n, 1, 1)
+        self.pooled = torch.empty(n, 1, 1, self.cin, **f32)
+        self.dpooled = torch.empty_like(self.pooled)
+        self.out = torch.empty(n, self.num_classes, **f32)
+        self.dout = torch.empty_like(self.out)
+        self.dx = torch.empty(n, h, w, self.cin, **f32)
+        return (1, 1, self.num_classes)
+
+    def fwd(self, x, cfg):
+        lib().global_avgpool_fwd(_ptr(x), self.n, self.hw, self.cin, _ptr(self.pooled), cfg.st)
+        self.dense.fwd(self.pooled, self.out, cfg.st)
+        return self.out
+
+    def bwd(self, dout, cfg):
+        cfg.wgrad(self.dense, self.pooled, dout)
+        self.dense.bwd_data(dout, self.dpooled, cfg.st)
+        lib().global_avgpool_bwd(_ptr(self.dpooled), self.n, self.hw, self.cin, _ptr(self.dx), cfg.st)
         return self.dx
 
 
@@ -812,9 +854,9 @@ class ENetGraph(GraphBase):
     """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling` /
     `enet-naive-upsampling-enhanced`."""
 
-    def __init__(self, variant: str, num_classes: int, device="cuda"):
+    def __init__(self, variant: str, num_classes: int, device="cuda", encoder_only: bool = False):
         assert variant in ("naive", "unpool", "enhanced")
-        self.variant, self.num_classes = variant, num_classes
+        self.variant, self.num_classes, self.encoder_only = variant, num_classes, encoder_only
         self.device = torch.device(device)
         st = self.store = ParamStore()
         B = Bottleneck
@@ -826,13 +868,21 @@ class ENetGraph(GraphBase):
         for stage in (2, 3):
             for suffix, kw in ENC_PATTERN:
                 blocks.append(B(st, "en_bn_{}.{}".format(stage, suffix), 128, 128, "enc", variant, dropout_rate=0.1, **kw))
+        if encoder_only and variant != "enhanced":      # src/models.py:1040-1048, 1346-1354: the head sits on the encoder
+            blocks.append(ClassifierHead(st, 128, num_classes))
+            self._finish_init(blocks)
+            return
         ddrop = None if variant == "unpool" else 0.1   # the max-unpooling decoder has no dropout (src/models.py:1576-1607)
         blocks.append(B(st, "de_bn_4.0", 128, 64, "dec", variant, upsample=True, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_4.1", 64, 64, "dec", variant, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_4.2", 64, 64, "dec", variant, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_5.0", 64, 16, "dec", variant, upsample=True, dropout_rate=ddrop))
         blocks.append(B(st, "de_bn_5.1", 16, 16, "dec", variant, dropout_rate=ddrop))
-        blocks.append(EnhancedHead(st, 16, num_classes) if variant == "enhanced" else LogitsHead(st, 16, num_classes))
+        if encoder_only:      # enhanced: the WHOLE network, its last layer renamed, then the classifier (src/models.py:1665-1668)
+            blocks.append(EnhancedHead(st, 16, num_classes, final_layer_name="decoder_logits"))
+            blocks.append(ClassifierHead(st, num_classes, num_classes))
+        else:
+            blocks.append(EnhancedHead(st, 16, num_classes) if variant == "enhanced" else LogitsHead(st, 16, num_classes))
         self._finish_init(blocks)
 
     def _plan_blocks(self, n, h, w, dev):

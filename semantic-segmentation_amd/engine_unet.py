@@ -16,7 +16,8 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from ._lib import lib
-from .engine import ACT_LEAKY, ACT_NONE, BN_EPS, BN_MOMENTUM, BatchNorm, Block, Conv, GraphBase, ParamStore, RunCfg, _ptr
+from .engine import (ACT_LEAKY, ACT_NONE, BN_EPS, BN_MOMENTUM, BatchNorm, Block, ClassifierHead, Conv, GraphBase, ParamStore,
+                     RunCfg, _ptr)
 
 DROP_RATE = 0.1     # src/models.py:841
 LEAKY_ALPHA = 0.1   # src/models.py:840
@@ -267,10 +268,11 @@ SEGNET = dict(
 class UNetSegNetGraph(GraphBase):
     """`unet` / `segnet`: four encoder blocks, (U-Net) the connecting block, four decoder blocks, 1x1 logits."""
 
-    def __init__(self, kind: str, num_classes: int, device="cuda"):
+    def __init__(self, kind: str, num_classes: int, device="cuda", encoder_only: bool = False):
         assert kind in ("unet", "segnet")
+        assert not (encoder_only and kind == "unet")      # the reference has no unet-encoder-only
         topo = UNET if kind == "unet" else SEGNET
-        self.variant, self.num_classes = kind, num_classes
+        self.variant, self.num_classes, self.encoder_only = kind, num_classes, encoder_only
         self.device = torch.device(device)
         st = self.store = ParamStore()
         blocks: List[Block] = []
@@ -280,6 +282,10 @@ class UNetSegNetGraph(GraphBase):
             encs.append(EncoderBlock(st, prefix, n, c, f, first=(i == 0)))
             c = f
         blocks.extend(encs)
+        if encoder_only:      # src/models.py:985-993: average pooling over pool4 -> Flatten -> Dense
+            blocks.append(ClassifierHead(st, c, num_classes))
+            self._finish_init(blocks)
+            return
         if topo["connect"]:
             cb = ConnectingBlock(st, topo["connect"], c)
             blocks.append(cb)

@@ -39,7 +39,7 @@ class LayerInfo:
 class ExtendedModel(object):
 
     def __init__(self, name: str, graph: ENetGraph, input_shape, num_classes: int, lambda_loss: bool,
-                 mean_teacher: bool = False, superpixel: bool = False):
+                 mean_teacher: bool = False, superpixel: bool = False, classification: bool = False):
         self.name = name
         self.graph = graph
         self.input_shape = tuple(input_shape)
@@ -51,6 +51,9 @@ class ExtendedModel(object):
         self.input_names = ["images"] + (["labels", "class_weights", "num_unlabeled"] if lambda_loss else [])
         # superpixel cost over the unlabeled rows (src/models.py:191-196, src/losses.py:439-572): one more input, its coefficient
         self.superpixel = bool(superpixel and lambda_loss)
+        # encoder-only model with the classification lambda loss (src/models.py:197-199, 706-729): labels and class weights
+        # are [batch, classes] float tensors, the logits have rank 2
+        self.classification = bool(classification and lambda_loss)
         if self.mean_teacher:
             self.input_names += ["mt_predictions", "consistency_cost"]
         if self.superpixel:
@@ -190,6 +193,8 @@ class ExtendedModel(object):
                 fns.extend(lst)
         elif metrics:
             fns.extend(metrics)
+        if fns and getattr(self, "classification", False):
+            raise NotImplementedError("the classification models report the loss only; segmentation metrics need rank-4 logits")
         self._metric_fns = fns
         self.metrics_names = ["loss", "loss_loss", "logits_loss"]
         ignore = None
@@ -242,8 +247,12 @@ class ExtendedModel(object):
             return
         dev = self.graph.device
         self.images_buf = torch.zeros(n, h, w, 3, dtype=torch.float32, device=dev)
-        self.labels_buf = torch.zeros(n, h, w, dtype=torch.int32, device=dev)
-        self.weights_buf = torch.zeros(n, h, w, dtype=torch.float32, device=dev)
+        if self.classification:
+            self.labels_buf = torch.zeros(n, self.num_classes, dtype=torch.float32, device=dev)
+            self.weights_buf = torch.zeros(n, self.num_classes, dtype=torch.float32, device=dev)
+        else:
+            self.labels_buf = torch.zeros(n, h, w, dtype=torch.int32, device=dev)
+            self.weights_buf = torch.zeros(n, h, w, dtype=torch.float32, device=dev)
         if self.mean_teacher:
             self.mt_buf = torch.zeros(n, h, w, self.num_classes, dtype=torch.float32, device=dev)
             self.coef_buf = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -342,6 +351,10 @@ class ExtendedModel(object):
                     L.fill_f32(_ptr(self._sp_cost_buf), 0.0, 1, st)
 
         def loss_call(st, want_grad):
+            if self.classification:
+                L.classification_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), n, C_, 10e-7, 1.0,
+                                              _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), st)
+                return
             if self.mean_teacher or self.superpixel:
                 return loss_call_semi(st, want_grad)
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npix, C_, 1.0,

@@ -171,6 +171,50 @@ def segmentation_mean_teacher_superpixel_lambda_loss(args):
     return _semi_supervised(args, 7, True, True)
 
 
+def _classification_xent(y_pred, y_true, class_weights):
+    if y_pred.dim() != 2 or y_true.dim() != 2 or class_weights.dim() != 2:
+        raise ValueError("y_pred, y_true and the class weights must have rank 2 (batch x classes)")
+    if tuple(y_true.shape) != tuple(y_pred.shape) or tuple(class_weights.shape) != tuple(y_pred.shape):
+        raise ValueError("shape mismatch: logits {}, labels {}, weights {}".format(
+            tuple(y_pred.shape), tuple(y_true.shape), tuple(class_weights.shape)))
+    if not y_pred.is_cuda:
+        raise RuntimeError("the loss runs on the GPU only (libssmi.so); got a CPU tensor")
+    L = lib()
+    z, y, w = y_pred.contiguous().float(), y_true.contiguous().float(), class_weights.contiguous().float()
+    loss = torch.zeros((), dtype=torch.float32, device=z.device)
+    dl = torch.empty_like(z)
+    L.classification_xent_fwd_bwd(z.data_ptr(), y.data_ptr(), w.data_ptr(), z.shape[0], z.shape[1], SUPERPIXEL_EPSILON, 1.0,
+                                  dl.data_ptr(), loss.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _last["dlogits"] = dl
+    return loss
+
+
+def classification_weighted_categorical_crossentropy_loss(class_weights):
+    """src/losses.py:603-609: -mean_n sum_c y_true * log(clip(softmax(y_pred), 1e-6, 1)) * class_weights[c]."""
+    if class_weights is None:
+        raise ValueError('Class weights is None. Use a numpy array of ones instead of None.')
+    cw_host = np.asarray(class_weights, dtype=np.float32)
+
+    def loss(y_true, y_pred):
+        cw = torch.from_numpy(cw_host).to(y_pred.device).expand_as(y_pred)
+        return _classification_xent(y_pred, y_true, cw)
+
+    return loss
+
+
+def classification_categorical_crossentropy_lambda_loss(args):
+    """src/losses.py:636-652.  args = [logits BxC, labels BxC float, class weights BxC, num_unlabeled Bx1 int32].  As in
+    the reference only the weights are sliced to the labeled rows, so num_unlabeled must be 0 for the shapes to agree."""
+    if len(args) != 4:
+        raise ValueError('Expected 4 arguments, got: {} ({})'.format(len(args), args))
+    y_pred, y_true, weights, num_unlabeled = args
+    if num_unlabeled.dim() != 2:
+        raise ValueError("num_unlabeled must have rank 2")
+    if int(num_unlabeled.reshape(-1)[0].item()) != 0:
+        raise ValueError("the classification lambda loss requires num_unlabeled == 0 (shape mismatch in the reference)")
+    return _classification_xent(y_pred, y_true, weights)
+
+
 def segmentation_sparse_weighted_categorical_cross_entropy(class_weights):
     """src/losses.py:334-338 (+268-307): y_true BxHxWx1, per-pixel weights = class_weights[y_true]."""
     if class_weights is None:

@@ -28,12 +28,14 @@ def get_lambda_loss_function(model_lambda_loss_type):
         return losses.segmentation_categorical_cross_entropy_lambda_loss
     if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER:
         return losses.segmentation_mean_teacher_lambda_loss
+    if model_lambda_loss_type == ModelLambdaLossType.CLASSIFICATION_CATEGORICAL_CROSS_ENTROPY:
+        return losses.classification_categorical_crossentropy_lambda_loss
     if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL:
         return losses.segmentation_superpixel_lambda_loss
     if model_lambda_loss_type == ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL:
         return losses.segmentation_mean_teacher_superpixel_lambda_loss
     if isinstance(model_lambda_loss_type, ModelLambdaLossType):
-        raise NotImplementedError('lambda loss type {} is not implemented (classification losses)'.format(model_lambda_loss_type))
+        raise NotImplementedError('lambda loss type {} is not implemented (the classification mean-teacher loss)'.format(model_lambda_loss_type))
     raise ValueError('Unknown model lambda loss type: {}'.format(model_lambda_loss_type))
 
 
@@ -73,11 +75,17 @@ class ModelBase(object):
                                                   T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL)
         superpixel = model_lambda_loss_type in (T.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL,
                                                 T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL)
-        lambda_loss = mean_teacher or superpixel or model_lambda_loss_type == T.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY
-        if lambda_loss:      # src/models.py:185-196
+        classification = model_lambda_loss_type == T.CLASSIFICATION_CATEGORICAL_CROSS_ENTROPY
+        if classification and not getattr(graph, "encoder_only", False):
+            raise ValueError('the classification lambda loss needs an encoder-only model (logits of rank 2)')
+        if getattr(graph, "encoder_only", False) and model_lambda_loss_type not in (T.NONE, T.CLASSIFICATION_CATEGORICAL_CROSS_ENTROPY):
+            raise ValueError('encoder-only models take the classification lambda loss, got {}'.format(model_lambda_loss_type))
+        lambda_loss = (mean_teacher or superpixel or classification
+                       or model_lambda_loss_type == T.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
+        if lambda_loss:      # src/models.py:185-199
             self.name = self.name + (('-MT' if mean_teacher else '') + ('-SP' if superpixel else '') or '-CCE')
         self._model = ExtendedModel(self.name, graph, self.input_shape, num_classes, lambda_loss, mean_teacher=mean_teacher,
-                                    superpixel=superpixel)
+                                    superpixel=superpixel, classification=classification)
 
     @property
     def model(self):
@@ -191,36 +199,36 @@ class ENetNaiveUpsampling(ModelBase):
     """src/models.py:1020-1319."""
 
     def __init__(self, input_shape, num_classes, encoder_only=False, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
-        if encoder_only:
-            raise NotImplementedError('encoder-only classification heads are outside the segmentation hot path')
-        super().__init__("ENet-Naive-Upsampling", input_shape, num_classes, model_lambda_loss_type, **kw)
+        self.encoder_only = encoder_only
+        super().__init__("ENet-Naive-Upsampling" if not encoder_only else "ENet-Naive-Upsampling-Encoder-Only", input_shape, num_classes,
+                         model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return ENetGraph("naive", self.num_classes, self.device)
+        return ENetGraph("naive", self.num_classes, self.device, encoder_only=self.encoder_only)
 
 
 class ENetMaxUnpooling(ModelBase):
     """src/models.py:1326-1628."""
 
     def __init__(self, input_shape, num_classes, encoder_only=False, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
-        if encoder_only:
-            raise NotImplementedError('encoder-only classification heads are outside the segmentation hot path')
-        super().__init__("ENet-Max-Unpooling", input_shape, num_classes, model_lambda_loss_type, **kw)
+        self.encoder_only = encoder_only
+        super().__init__("ENet-Max-Unpooling" if not encoder_only else "ENet-Max-Unpooling-Encoder-Only", input_shape, num_classes,
+                         model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return ENetGraph("unpool", self.num_classes, self.device)
+        return ENetGraph("unpool", self.num_classes, self.device, encoder_only=self.encoder_only)
 
 
 class ENetNaiveUpsamplingEnhanced(ModelBase):
     """src/models.py:1642-1796."""
 
     def __init__(self, input_shape, num_classes, encoder_only=False, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
-        if encoder_only:
-            raise NotImplementedError('encoder-only classification heads are outside the segmentation hot path')
-        super().__init__("ENet-Naive-Upsampling-Enhanced", input_shape, num_classes, model_lambda_loss_type, **kw)
+        self.encoder_only = encoder_only
+        super().__init__("ENet-Naive-Upsampling-Enhanced" if not encoder_only else "ENet-Naive-Upsampling-Enhanced-Encoder-Only", input_shape, num_classes,
+                         model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return ENetGraph("enhanced", self.num_classes, self.device)
+        return ENetGraph("enhanced", self.num_classes, self.device, encoder_only=self.encoder_only)
 
 
 class UNetModel(ModelBase):
@@ -237,12 +245,12 @@ class SegNetBasicModel(ModelBase):
     """src/models.py:951-1012."""
 
     def __init__(self, input_shape, num_classes, encoder_only=False, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
-        if encoder_only:
-            raise NotImplementedError('encoder-only classification heads are outside the segmentation hot path')
-        super().__init__("SegNet-Basic", input_shape, num_classes, model_lambda_loss_type, **kw)
+        self.encoder_only = encoder_only
+        super().__init__("SegNet-Basic" if not encoder_only else "SegNet-Basic-Encoder-Only", input_shape, num_classes,
+                         model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return UNetSegNetGraph("segnet", self.num_classes, self.device)
+        return UNetSegNetGraph("segnet", self.num_classes, self.device, encoder_only=self.encoder_only)
 
 
 def get_model(model_name, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):
@@ -257,6 +265,12 @@ def get_model(model_name, input_shape, num_classes, model_lambda_loss_type=Model
         return UNetModel(input_shape, num_classes, model_lambda_loss_type, **kw)
     if model_name == 'segnet':
         return SegNetBasicModel(input_shape, num_classes, False, model_lambda_loss_type, **kw)
-    if model_name in _KNOWN:
-        raise NotImplementedError('encoder-only classification heads ({}) are outside the segmentation hot path'.format(model_name))
+    if model_name == 'enet-naive-upsampling-encoder-only':
+        return ENetNaiveUpsampling(input_shape, num_classes, True, model_lambda_loss_type, **kw)
+    if model_name == 'enet-max-unpooling-encoder-only':
+        return ENetMaxUnpooling(input_shape, num_classes, True, model_lambda_loss_type, **kw)
+    if model_name == 'enet-naive-upsampling-enhanced-encoder-only':
+        return ENetNaiveUpsamplingEnhanced(input_shape, num_classes, True, model_lambda_loss_type, **kw)
+    if model_name == 'segnet-encoder-only':
+        return SegNetBasicModel(input_shape, num_classes, True, model_lambda_loss_type, **kw)
     raise ValueError('Unknown model name: {}'.format(model_name))

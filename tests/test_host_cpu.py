@@ -89,6 +89,30 @@ def test_builder_weight_names_shapes_and_order(name):
         assert o % 4 == 0 and o + n <= o2
 
 
+@pytest.mark.parametrize("name", ["enet-naive-upsampling-encoder-only", "enet-max-unpooling-encoder-only",
+                                  "enet-naive-upsampling-enhanced-encoder-only", "segnet-encoder-only"])
+def test_encoder_only_builders(name):
+    """src/models.py:985-993, 1040-1048, 1346-1354, 1665-1668: encoder (the whole network for the enhanced variant, its last
+    layer renamed 'decoder_logits') -> average pooling -> Dense 'logits' with a Keras (in, out) kernel."""
+    models, losses = pkg("models"), pkg("losses")
+    mb = models.get_model(name, (64, 64, 3), 24, losses.ModelLambdaLossType.CLASSIFICATION_CATEGORICAL_CROSS_ENTROPY, device="cpu")
+    m = mb.model
+    assert mb.name.endswith("-Encoder-Only-CCE") and m.classification
+    spec = E.weight_spec(name, 24)
+    assert m.weight_names() == [k for k, _, _, _ in spec]
+    for k, shape, init, _ in spec:
+        assert m.graph.store.specs[k].shape == tuple(shape) and m.graph.store.specs[k].init == init
+    cin = {"enet-naive-upsampling-encoder-only": 128, "enet-max-unpooling-encoder-only": 128,
+           "enet-naive-upsampling-enhanced-encoder-only": 24, "segnet-encoder-only": 512}[name]
+    assert m.graph.store.specs["logits/kernel"].shape == (cin, 24)
+    names = [l.name for l in m.layers]
+    assert names[-1] == "logits" and ("decoder_logits" in names) == ("enhanced" in name)
+    assert not any(n.startswith(("de_bn", "decoder_block")) for n in names) or "enhanced" in name
+    seg = E.weight_spec(name[:-len("-encoder-only")], 24)
+    if "enhanced" not in name:      # a strict prefix of the segmentation model's weights + the Dense layer
+        assert [k for k, _, _, _ in spec][:-2] == [k for k, _, _, _ in seg][:len(spec) - 2]
+
+
 def test_get_model_errors_like_the_reference():
     models = pkg("models")
     losses = pkg("losses")
@@ -96,8 +120,13 @@ def test_get_model_errors_like_the_reference():
         models.get_model("resnet", (None, None, 3), 24, device="cpu")
     with pytest.raises(ValueError, match="Unknown model lambda loss type"):
         models.get_lambda_loss_function("nope")
-    with pytest.raises(NotImplementedError):
-        models.get_model("enet-naive-upsampling-encoder-only", (None, None, 3), 24, device="cpu")
+    with pytest.raises(NotImplementedError):      # the classification mean-teacher loss is not built
+        models.get_lambda_loss_function(losses.ModelLambdaLossType.CLASSIFICATION_SEMI_SUPERVISED_MEAN_TEACHER)
+    with pytest.raises(ValueError, match="encoder-only"):      # rank-2 logits cannot feed a segmentation loss and vice versa
+        models.get_model("enet-naive-upsampling-encoder-only", (None, None, 3), 24,
+                         losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, device="cpu")
+    with pytest.raises(ValueError, match="encoder-only"):
+        models.get_model("segnet", (None, None, 3), 24, losses.ModelLambdaLossType.CLASSIFICATION_CATEGORICAL_CROSS_ENTROPY, device="cpu")
     assert models.get_lambda_loss_function(losses.ModelLambdaLossType.NONE) is None
     assert models.get_lambda_loss_function(losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY) \
         is losses.segmentation_categorical_cross_entropy_lambda_loss

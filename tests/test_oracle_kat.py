@@ -248,3 +248,29 @@ def test_superpixel_cost_known_answers():
     lab = torch.zeros(1, 3, 3, dtype=torch.int64)
     w = torch.ones(1, 3, 3, dtype=torch.float64)
     assert abs(float(K.segmentation_superpixel_lambda_loss(y, lab, w, 0, 5.0)) - np.log(2.0)) < 1e-14
+
+
+def test_classification_loss_known_answers():
+    """src/losses.py:579-588: two samples, two classes.  Sample 0: softmax (1/2, 1/2), one-hot label on class 0 with weight 3
+    -> 3 ln 2.  Sample 1: softmax of class 1 is ~1e-13, below the clip at 1e-6: the term is -ln(1e-6) * 2 and passes no
+    gradient.  The loss is the mean over the two samples."""
+    z = torch.tensor([[0.0, 0.0], [0.0, -30.0]], dtype=torch.float64, requires_grad=True)
+    y = torch.tensor([[1.0, 0.0], [0.0, 1.0]], dtype=torch.float64)
+    w = torch.tensor([[3.0, 5.0], [7.0, 2.0]], dtype=torch.float64)
+    loss = K.classification_weighted_categorical_crossentropy(y, z, w)
+    assert abs(float(loss) - 0.5 * (3.0 * np.log(2.0) + 2.0 * -np.log(1e-6))) < 1e-12
+    (g,) = torch.autograd.grad(loss, [z])
+    np.testing.assert_allclose(g[0].numpy(), [0.5 * 3.0 * (0.5 - 1.0), 0.5 * 3.0 * 0.5], rtol=1e-12)
+    assert float(g[1].abs().max()) == 0.0
+
+
+def test_encoder_only_oracle_shapes():
+    for name, cin in (("enet-naive-upsampling-encoder-only", 128), ("segnet-encoder-only", 512)):
+        w0 = E.init_weights(name, 7, seed=1)
+        assert w0["logits/kernel"].shape == (cin, 7)
+        lim = np.sqrt(6.0 / (cin + 7))
+        assert np.abs(w0["logits/kernel"]).max() <= lim
+        params = {k: torch.tensor(v) for k, v in w0.items()}
+        with torch.no_grad():
+            logits, _ = E.enet_forward(name, params, torch.zeros(2, 32, 32, 3, dtype=torch.float64), training=False)
+        assert tuple(logits.shape) == (2, 7)
