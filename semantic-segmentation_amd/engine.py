@@ -14,6 +14,7 @@ Reference topology: src/models.py:1054-1319 (ENetNaiveUpsampling), 1360-1628 (EN
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
@@ -290,14 +291,20 @@ class RunCfg:
     Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the latency-bound
     main chain (small BN / merge kernels) is running.  Without a side stream wgrad() launches in place."""
     __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws", "main", "side", "ws2",
-                 "_forked", "_pending")
+                 "_forked", "_pending", "_sides", "_turn")
 
     def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws, main=None, side=None, ws2=None):
         self.training, self.update_moving, self.unbiased_moving = training, update_moving, unbiased_moving
         self.use_dropout, self.st, self.ws = use_dropout, st, ws
+        # `side` / `ws2`: one stream + workspace, or equally long lists of them (blocks take turns)
+        self._sides = None
+        if isinstance(side, (list, tuple)):
+            self._sides = list(zip(side, ws2))
+            side, ws2 = (side[0], ws2[0]) if side else (None, None)
         self.main, self.side, self.ws2 = main, side, ws2
         self._forked = False
         self._pending = []
+        self._turn = 0
 
     def wgrad(self, conv, x, dy):
         if self.side is None:
@@ -310,20 +317,25 @@ class RunCfg:
         stream has queued so far (one fork per block instead of one per convolution)."""
         if self.side is None or not self._pending:
             return
+        side, ws2 = self.side, self.ws2
+        if self._sides:      # blocks take turns (alternating per convolution instead measured slower)
+            side, ws2 = self._sides[self._turn % len(self._sides)]
+            self._turn += 1
         ev = torch.cuda.Event()
         ev.record(self.main)
-        self.side.wait_event(ev)
+        side.wait_event(ev)
         for conv, x, dy in self._pending:
-            conv.bwd_weight(x, dy, self.ws2, self.side.cuda_stream)
+            conv.bwd_weight(x, dy, ws2, side.cuda_stream)
         self._pending = []
         self._forked = True
 
     def join(self):
         self.flush()
         if self.side is not None and self._forked:
-            ev = torch.cuda.Event()
-            ev.record(self.side)
-            self.main.wait_event(ev)
+            for side in ([sd for sd, _ in self._sides] if self._sides else [self.side]):
+                ev = torch.cuda.Event()
+                ev.record(side)
+                self.main.wait_event(ev)
             self._forked = False
 
 
@@ -808,6 +820,14 @@ class GraphBase:
             else self.ws
         if self.side_stream is None and dev.type == "cuda" and self.overlap_weight_gradients:
             self.side_stream = torch.cuda.Stream(device=dev)
+        # Two weight-gradient streams, used by alternate blocks: a strip kernel keeps one latency-bound workgroup per CU,
+        # so two of them beside the data-gradient chain fill the chip better than one (ENet 512x512 batch 16: 10.92 ms with
+        # one stream, 10.38 with two, 11.1 with three).  SSMI_WGRAD_STREAMS overrides for measurements.
+        nside = int(os.environ.get("SSMI_WGRAD_STREAMS", "2"))
+        self.side_streams = self.side_wss = None
+        if nside > 1 and self.side_stream is not None:
+            self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=dev) for _ in range(nside - 1)]
+            self.side_wss = [self.ws2] + [torch.empty_like(self.ws2) for _ in range(nside - 1)]
         self.shape = (n, h, w)
 
     # -- execution ------------------------------------------------------------------------------------
@@ -819,8 +839,10 @@ class GraphBase:
         main = torch.cuda.current_stream()
         st = stream if stream is not None else main.cuda_stream
         side = self.side_stream if (self.overlap_weight_gradients and training and st == main.cuda_stream and st != 0) else None
+        multi = side is not None and getattr(self, "side_streams", None)
         cfg = RunCfg(training, update_moving and training, unbiased_moving,
-                     training if use_dropout is None else use_dropout, st, self.ws, main, side, self.ws2)
+                     training if use_dropout is None else use_dropout, st, self.ws, main,
+                     self.side_streams if multi else side, self.side_wss if multi else self.ws2)
         x = images
         for b in self.blocks:
             x = b.fwd(x, cfg)
