@@ -1,5 +1,5 @@
-"""Per-operator GPU parity through the C ABI against the CPU oracle (fp64), rtol 1e-3 for floating point
-(BASELINE.json north_star), bit-exact for indices and confusion matrices.  Shapes cover the kernel configurations of the
+"""Per-operator GPU parity through the C ABI against the CPU oracle (fp64), rtol 1e-3 for floating point,
+bit-exact for indices and confusion matrices.  Shapes cover the kernel configurations of the
 ENet graphs plus ragged / odd / tie cases."""
 import ctypes as C
 

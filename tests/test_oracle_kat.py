@@ -161,7 +161,7 @@ def test_sgd_momentum_nesterov():
 
 
 def test_enet_parameter_counts_match_the_reference_graph():
-    # trainable parameter counts derived from src/models.py (BASELINE.md section 2)
+    # trainable parameter counts derived from src/models.py
     for name, n in (("enet-naive-upsampling", 364972), ("enet-max-unpooling", 364924)):
         w = E.init_weights(name, 24)
         assert sum(v.size for k, v in w.items() if k.endswith(E.TRAINABLE_SUFFIXES)) == n

@@ -1,7 +1,7 @@
 """GPU parity: full training steps (forward, loss, backward, BN moving updates, Adam) of the HIP path against the CPU
 oracle on identical weights, inputs and dropout masks.
 
-Tolerances (BASELINE.json north_star): rtol 1e-3 for fp32 activations, loss and gradients, measured per tensor against
+Tolerances: rtol 1e-3 for fp32 activations, loss and gradients, measured per tensor against
 the tensor's own scale; pooling indices and confusion matrices bit-exact.  Forward quantities are checked against the
 fp64 oracle at that tolerance.
 
