@@ -161,6 +161,8 @@ def main():
                                          "parallelism": "dp{}".format(world), "pixels_counted": int(cm.sum()),
                                          "miou": round(ev["miou"], 6), "accuracy": round(ev["accuracy"], 6)}}), flush=True)
         if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -182,6 +184,9 @@ def main():
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
+        # rank 0 measured the roofline alone; the others wait here so that no rank tears the group down under it
+        torch.cuda.synchronize()
+        dist.barrier()
         dist.destroy_process_group()
 
 

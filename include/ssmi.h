@@ -145,6 +145,11 @@ ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t
 /* Inference phase: save_mean = moving_mean, save_invstd = 1/sqrt(moving_var + eps). */
 ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_var, int32_t c, float eps,
                                 float* save_mean, float* save_invstd, void* stream);
+/* The same for every BatchNormalization layer of a model in one launch: `state` is an arena holding the layers'
+ * [moving_mean | moving_variance] vectors, is_var[i] != 0 marks the variance elements, out[i] = state[i] for means and
+ * 1 / sqrt(state[i] + eps) for variances (the inference-phase forward of a whole network needs one such launch). */
+ssmi_status ssmi_bn_infer_stats_arena(const float* state, const uint8_t* is_var, int64_t count, float eps, float* out,
+                                      void* stream);
 /* y = act(gamma * (x - mean) * invstd + beta).  x and y dense [npix, c] (x pixel stride ld_x). */
 ssmi_status ssmi_bn_act_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
                             const float* beta, int32_t act, const float* alpha, float slope, float* y, int64_t npix,

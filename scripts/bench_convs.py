@@ -31,6 +31,12 @@ SHAPES = [
     ("3x3 4->4 @256", 3, 3, 4, 4, 1, 1, "same", True, False, 256),
     ("logits t2x2s2 16->24", 2, 2, 16, 24, 2, 1, "same", True, True, 256),
 ]
+if os.environ.get("SSMI_WIDE"):        # the 3x3 layers of SegNet / U-Net at 512x512 (run with batch 4)
+    SHAPES = [("3x3 64->64 @512", 3, 3, 64, 64, 1, 1, "same", True, False, 512),
+              ("3x3 128->128 @256", 3, 3, 128, 128, 1, 1, "same", True, False, 256),
+              ("3x3 256->256 @128", 3, 3, 256, 256, 1, 1, "same", True, False, 128),
+              ("3x3 512->512 @64", 3, 3, 512, 512, 1, 1, "same", True, False, 64),
+              ("3x3 1024->512 @64", 3, 3, 1024, 512, 1, 1, "same", False, False, 64)]
 if os.environ.get("SSMI_SHAPES"):      # comma-separated indices into SHAPES
     SHAPES = [SHAPES[int(i)] for i in os.environ["SSMI_SHAPES"].split(",")]
 dev = torch.device("cuda")

@@ -60,6 +60,7 @@ _PROTOS = {
     "ssmi_bn_workspace_bytes": (_sz, [_i64, _i32]),
     "ssmi_bn_train_stats": (_i32, [_vp, _i64, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_bn_infer_stats": (_i32, [_vp, _vp, _i32, _f32, _vp, _vp, _vp]),
+    "ssmi_bn_infer_stats_arena": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp]),
     "ssmi_bn_act_fwd": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64, _i32, _vp]),
     "ssmi_bn_act_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _i32, _vp,
                                _sz, _vp]),

@@ -507,6 +507,15 @@ ssmi_status launch_bn_bwd_tail(const float* part, int rows, const float* dy, int
   return SSMI_OK;
 }
 
+
+// Inference-phase statistics of EVERY BatchNormalization layer in one launch: the moving statistics live in one arena
+// ([moving_mean | moving_variance] per layer); out mirrors it with mean copied and variance turned into 1/sqrt(var + eps).
+__global__ __launch_bounds__(256) void bn_infer_stats_arena_kernel(const float* __restrict__ state, const uint8_t* __restrict__ is_var,
+                                                                   int64_t count, float eps, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    out[i] = is_var[i] ? 1.f / sqrtf(state[i] + eps) : state[i];
+}
+
 }  // namespace ssmi
 
 using namespace ssmi;
@@ -534,6 +543,16 @@ ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t
   SSMI_LAUNCH_CHECK();
   return launch_bn_stats_final(part, nb, c, npix, eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean,
                                save_invstd, as_stream(stream));
+}
+
+ssmi_status ssmi_bn_infer_stats_arena(const float* state, const uint8_t* is_var, int64_t count, float eps, float* out,
+                                      void* stream) {
+  SSMI_REQUIRE(state && is_var && out && count > 0, SSMI_E_INVALID_ARG, "bn_infer_stats_arena: bad argument");
+  int64_t nb = ceil_div64(count, 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(bn_infer_stats_arena_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), state, is_var, count, eps, out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
 }
 
 ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_var, int32_t c, float eps,

@@ -83,6 +83,14 @@ class ParamStore:
         self.theta = torch.zeros(max(self.n_train, 4), dtype=torch.float32, device=device)
         self.grad = torch.zeros_like(self.theta)
         self.state = torch.zeros(max(self.n_state, 4), dtype=torch.float32, device=device)
+        # per-layer (mean, 1/std) used by the BN kernels, laid out like `state`: in the inference phase one launch fills all
+        # of it from the moving statistics, in the training phase every layer's statistics kernel writes its own slice
+        self.bn_stats = torch.zeros_like(self.state)
+        mask = np.zeros(self.state.numel(), dtype=np.uint8)
+        for k, s in self.specs.items():
+            if not s.trainable and k.endswith("/moving_variance"):
+                mask[s.offset:s.offset + s.size] = 1
+        self.var_mask = torch.from_numpy(mask).to(device)
         for k, s in self.specs.items():
             arena = self.theta if s.trainable else self.state
             self.views[k] = arena[s.offset:s.offset + s.size].view(s.shape)
@@ -256,8 +264,9 @@ class BatchNorm:
         self.alpha = self.dalpha = None
         if self.prelu_name:
             self.alpha, self.dalpha = v[self.prelu_name + "/alpha"], g[self.prelu_name + "/alpha"]
-        self.stats_buf = torch.zeros(2, self.c, dtype=torch.float32, device=device)
-        self.mean, self.invstd = self.stats_buf[0], self.stats_buf[1]
+        sp = self.store.specs
+        om, ov = sp[self.name + "/moving_mean"].offset, sp[self.name + "/moving_variance"].offset
+        self.mean, self.invstd = self.store.bn_stats[om:om + self.c], self.store.bn_stats[ov:ov + self.c]
         self.params = BnParams(_ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta))
         self._pref = C.byref(self.params)
 
@@ -267,7 +276,7 @@ class BatchNorm:
             L.bn_train_stats(_ptr(x), npix, self.c, ld, BN_EPS, BN_MOMENTUM, 1 if unbiased else 0,
                              _ptr(self.mm) if update_moving else None, _ptr(self.mv) if update_moving else None,
                              _ptr(self.mean), _ptr(self.invstd), _ptr(ws), ws.numel() * 4, st)
-        else:
+        elif not getattr(self.store, "infer_stats_batched", False):     # a graph fills every layer's slice in one launch
             L.bn_infer_stats(_ptr(self.mm), _ptr(self.mv), self.c, BN_EPS, _ptr(self.mean), _ptr(self.invstd), st)
 
     def act_fwd(self, x, ld, y, npix, st):
@@ -843,6 +852,10 @@ class GraphBase:
         cfg = RunCfg(training, update_moving and training, unbiased_moving,
                      training if use_dropout is None else use_dropout, st, self.ws, main,
                      self.side_streams if multi else side, self.side_wss if multi else self.ws2)
+        sto = self.store
+        sto.infer_stats_batched = True
+        if not training and sto.n_state:
+            lib().bn_infer_stats_arena(_ptr(sto.state), _ptr(sto.var_mask), sto.n_state, BN_EPS, _ptr(sto.bn_stats), st)
         x = images
         for b in self.blocks:
             x = b.fwd(x, cfg)
