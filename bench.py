@@ -175,7 +175,8 @@ def main():
         cpu = cpu_baseline()
 
     if rank == 0:
-        out = {"metric": "train images/sec @512x512 ENet", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+        family = "ENet" if args.model.startswith("enet") else args.model
+        out = {"metric": "train images/sec @{0}x{0} {1}".format(args.size, family), "value": round(value, 2), "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "{} 24 classes {}x{} per-GPU batch {} fp32 train step (fwd+loss+bwd+Adam), global batch {}".format(
