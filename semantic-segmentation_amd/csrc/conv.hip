@@ -112,14 +112,31 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
         for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[j][t], acc[t]);
     };
     const int nsteps = ntaps * (g.cin >> 3);
-    f32x4 a0, a1;
-    float b0[4][NT], b1[4][NT];
-    fetch(a0, b0);
-    for (int i = 0; i < nsteps; i += 2) {
-      fetch(a1, b1);               // past the end: zeros (tap >= ntaps)
-      mma(a0, b0);
+    if constexpr (NT == 4) {
+      // wide tiles run at two waves per SIMD (accumulators): two steps of operands in flight instead of one, so that a
+      // memory round trip is covered by two steps of MFMA work per wave (three register sets, rotated by full unroll)
+      f32x4 a0, a1, a2;
+      float b0[4][NT], b1[4][NT], b2[4][NT];
       fetch(a0, b0);
-      if (i + 1 < nsteps) mma(a1, b1);
+      fetch(a1, b1);
+      for (int i = 0; i < nsteps; i += 3) {
+        fetch(a2, b2);             // past the end: zeros (tap >= ntaps)
+        mma(a0, b0);
+        fetch(a0, b0);
+        if (i + 1 < nsteps) mma(a1, b1);
+        fetch(a1, b1);
+        if (i + 2 < nsteps) mma(a2, b2);
+      }
+    } else {
+      f32x4 a0, a1;
+      float b0[4][NT], b1[4][NT];
+      fetch(a0, b0);
+      for (int i = 0; i < nsteps; i += 2) {
+        fetch(a1, b1);               // past the end: zeros (tap >= ntaps)
+        mma(a0, b0);
+        fetch(a0, b0);
+        if (i + 1 < nsteps) mma(a1, b1);
+      }
     }
   } else {
     for (int ky = 0; ky < g.kh; ++ky) {
