@@ -83,6 +83,26 @@ def shard_range(global_batch: int, world_size: int, rank: int) -> Tuple[int, int
     return rank * per, (rank + 1) * per
 
 
+class _StdoutToStderr:
+    """Routes the PROCESS's stdout (file descriptor 1, i.e. C libraries too) to stderr for the duration of the block: RCCL
+    prints a version banner to stdout when a communicator is created, which would otherwise land in front of a program's
+    own machine-readable output."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def init_distributed_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, local_rank, world_size)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,14 +110,22 @@ def init_distributed_from_env(backend: Optional[str] = None) -> Tuple[int, int, 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
     dev_index = local % ndev if ndev else 0     # more ranks than devices only happens in single-GPU rehearsals (gloo)
-    if world > 1 and not dist.is_initialized():
+    # SSMI_FORCE_DP=1: a process group of ONE rank, so that the data-parallel step (gradient buckets on the collective
+    # stream between the graph segments) can be exercised and timed on a single GPU
+    force = bool(os.environ.get("SSMI_FORCE_DP")) and world == 1
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
             backend = os.environ.get("SSMI_DIST_BACKEND") or ("nccl" if ndev else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(dev_index)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+            with _StdoutToStderr():
+                dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+                # the first collective creates the communicator (and prints RCCL's banner) if the eager path did not
+                probe = torch.zeros(1, device=torch.device("cuda", dev_index))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
         else:
             if ndev:
                 torch.cuda.set_device(dev_index)
@@ -173,7 +201,7 @@ class SegmentationTrainer(object):
                                                metrics.segmentation_mean_per_class_accuracy(num_classes, nu, ic),
                                                metrics.segmentation_confusion_matrix(num_classes, nu, ic)]})
         self.reducer = None
-        if self.world_size > 1:
+        if self.world_size > 1 or (os.environ.get("SSMI_FORCE_DP") and dist.is_initialized()):
             self.reducer = GradientBucketReducer()
             st = self.model.graph.store
             self.reducer.broadcast_([st.theta, st.state], src=0)
