@@ -93,3 +93,28 @@ def test_shard_range():
     assert cover == list(range(128))
     with pytest.raises(ValueError):
         trainers.shard_range(10, 4, 0)
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_group_runs_the_data_parallel_step():
+    """bench.py with SSMI_FORCE_DP=1: a process group of one rank on the nccl (RCCL) backend drives the bucketed
+    all-reduce between the captured graph segments.  Summing over one rank is the identity, so the loss after the same
+    number of steps must equal the single-process run bit for bit, and stdout must hold exactly one JSON line (RCCL's
+    banner must not reach it)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "2", "--batch", "2", "--size", "64",
+           "--no-cpu-baseline", "--no-roofline"]
+    outs = []
+    for extra in ({}, {"SSMI_FORCE_DP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29547"}):
+        env = dict(os.environ, **extra)
+        env.pop("WORLD_SIZE", None)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        outs.append(json.loads(lines[0]))
+    assert outs[0]["config"]["final_loss"] == outs[1]["config"]["final_loss"]
+    assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0
