@@ -80,6 +80,14 @@ ssmi_status ssmi_same_pad(int32_t in, int32_t k, int32_t stride, int32_t dil, in
 /* Keras Conv2D forward (src/models.py:1056-1060, 1090-1096, 1105-1133, 1142-1147).  bias may be NULL. */
 ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                             void* stream);
+/* Inference-phase fusion: convolution + BatchNormalization with fixed statistics + activation in one launch
+ * (src/models.py: every Conv2D -> BatchNormalization -> PReLU / LeakyReLU chain when the learning phase is 0):
+ *   y = act(gamma * ((conv(x) + bias - mean) * invstd) + beta),  act in {SSMI_ACT_NONE, SSMI_ACT_PRELU (alpha per channel),
+ *   SSMI_ACT_LEAKY (slope)}; mean / invstd come from ssmi_bn_infer_stats(_arena).  Same arithmetic as ssmi_bn_act_fwd. */
+ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+                                         const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                         int32_t act, const float* alpha, float slope, float* y, void* stream);
+
 /* Convolution whose output feeds a training-phase BatchNormalization (every conv -> BN pair of src/models.py, e.g.
  * :1096-1100): same y as ssmi_conv2d_fwd plus the statistics ssmi_bn_train_stats would compute from y (save_mean,
  * save_invstd, moving-average update), with the per-channel sums taken in the convolution kernel's epilogue instead of

@@ -38,7 +38,7 @@ struct Sizes {
 template <int NT, bool VEC>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y, float* __restrict__ part) {
+                                                       float* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 2 * NT * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
@@ -173,8 +173,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
   for (int t = 0; t < NT; ++t) {
     const int c = cbase + t * 32 + r;
     const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cout * 4u), colv[t] ? (unsigned)c * 4u : kOOB) : 0.f;
+    if (bn.mean) {   // uniform; inference phase: BatchNormalization (fixed statistics) + activation applied before the store
+      const int cc = colv[t] ? c : 0;
+      const float mu = bn.mean[cc], is = bn.invstd[cc], ga = bn.gamma[cc], be = bn.beta[cc];
+      const float al = bn.act == SSMI_ACT_PRELU ? bn.alpha[cc] : bn.slope;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
+      for (int i = 0; i < 16; ++i) {
+        const float z = ga * (((acc[t][i] + bv) - mu) * is) + be;
+        bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, (bn.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
+    }
     if (part) {   // per-wave column sums of y and y^2 over the valid rows (BatchNormalization statistics)
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -777,11 +788,24 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
       for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int i = 0; i < NR; ++i) av[m][i] = bload(radd, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB);
+      if (!bwd && bb.mean) {   // uniform; inference-phase forward: BatchNormalization (fixed statistics) + activation
+        const int cc = cv ? col : 0;
+        const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
+        const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < NR; ++i)
-          bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, acc[m][t][i] + bvv + av[m][i]);
+          for (int i = 0; i < NR; ++i) {
+            const float z = ga * (((acc[m][t][i] + bvv) - mu) * is) + be;
+            bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, (bb.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
+          }
+      } else {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int i = 0; i < NR; ++i)
+            bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, acc[m][t][i] + bvv + av[m][i]);
+      }
       if (part) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -1444,20 +1468,21 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
 }
 
 // part != nullptr: the kernel also writes per-workgroup column sums of y and y^2, part[row][2][cout]; *part_rows = rows.
+// bn.mean != nullptr: inference-phase BatchNormalization + activation applied in the epilogue (bn.x stays nullptr).
 static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, const float* bias, float* y,
-                              hipStream_t st, float* part = nullptr, int* part_rows = nullptr) {
+                              hipStream_t st, float* part = nullptr, int* part_rows = nullptr, BnBwdArgs bn = BnBwdArgs{}) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
   ProfileScope prof(st, conv_bytes(g, false), conv_flops(g));
-  if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e, part, part_rows)) return e;
+  if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e, part, part_rows, bn)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   set_last_kernel("conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
-#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part)
+#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
   } else {
@@ -1904,6 +1929,20 @@ ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float
   if (s) return s;
   SSMI_REQUIRE(x && w && y, SSMI_E_INVALID_ARG, "conv2d_fwd: NULL tensor");
   return launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream));
+}
+
+ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+                                         const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                         int32_t act, const float* alpha, float slope, float* y, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(x && w && y && mean && invstd && gamma && beta, SSMI_E_INVALID_ARG, "conv2d_fwd_bn_act_infer: NULL tensor");
+  SSMI_REQUIRE(act == SSMI_ACT_NONE || act == SSMI_ACT_LEAKY || (act == SSMI_ACT_PRELU && alpha), SSMI_E_INVALID_ARG,
+               "conv2d_fwd_bn_act_infer: activation %d", act);
+  BnBwdArgs bn;
+  bn.x = nullptr; bn.ld = 0; bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta; bn.alpha = alpha;
+  bn.slope = slope; bn.act = act; bn.drop = nullptr; bn.hw = 1; bn.part = nullptr;
+  return launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream), nullptr, nullptr, bn);
 }
 
 size_t ssmi_conv2d_fwd_bn_stats_workspace_bytes(const ssmi_conv_desc* d) {

@@ -206,6 +206,15 @@ class Conv:
                                   _ptr(bn.mv) if update_moving else None, _ptr(bn.mean), _ptr(bn.invstd), _ptr(ws),
                                   ws.numel() * 4, st)
 
+    def fwd_bn_act_infer(self, x, y, bn: "BatchNorm", st, act=None, slope=0.0):
+        """Inference phase: convolution + BatchNormalization (statistics already in bn.mean / bn.invstd) + activation in
+        one launch; `y` receives the ACTIVATED output."""
+        assert not self.transpose
+        if act is None:
+            act = ACT_PRELU if bn.alpha is not None else ACT_NONE
+        lib().conv2d_fwd_bn_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
+                                      _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(y), st)
+
     def bwd_data(self, dy, dx, st, add=None):
         L = lib()
         if self.transpose:
@@ -568,17 +577,26 @@ class Bottleneck(Block):
         tr, um, ub = cfg.training, cfg.update_moving, cfg.unbiased_moving
         self.x = x
         i = self.internal
-        self.conv1.fwd_bn(x, self.y1, self.bn1, self.np1, tr, um, ub, ws, st)
-        self.bn1.act_fwd(self.y1, i, self.a1, self.np1, st)
+        # inference phase: BN (fixed statistics) + PReLU ride in the convolution's epilogue, a1 / a2 are written directly
+        fuse1 = not tr and not self.conv1.transpose
+        fuse2 = not tr and not self.conv2.transpose
+        if fuse1:
+            self.conv1.fwd_bn_act_infer(x, self.a1, self.bn1, st)
+        else:
+            self.conv1.fwd_bn(x, self.y1, self.bn1, self.np1, tr, um, ub, ws, st)
+            self.bn1.act_fwd(self.y1, i, self.a1, self.np1, st)
+        src2 = self.a1
         if self.conv2a is not None:
             self.conv2a.fwd(self.a1, self.t, st)
-            self.conv2.fwd_bn(self.t, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
+            src2 = self.t
         elif self.nn_resize:
             L.upsample_nn2x_fwd(_ptr(self.a1), self.n, self.h1, self.w1, i, _ptr(self.a1u), i, st)
-            self.conv2.fwd_bn(self.a1u, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
+            src2 = self.a1u
+        if fuse2:
+            self.conv2.fwd_bn_act_infer(src2, self.a2, self.bn2, st)
         else:
-            self.conv2.fwd_bn(self.a1, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
-        self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
+            self.conv2.fwd_bn(src2, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
+            self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
         self.conv3.fwd_bn(self.a2, self.y3, self.bn3, self.np_out, tr, um, ub, ws, st)
         if self.mode == 1:
             L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin,

@@ -50,6 +50,9 @@ class ConvUnit:
         L = lib()
         bn = self.bn
         self.x = x
+        if not cfg.training and not cfg.use_dropout:      # inference phase: BN + activation in the convolution's epilogue
+            self.conv.fwd_bn_act_infer(x, self.out, bn, cfg.st, act=self.act, slope=LEAKY_ALPHA)
+            return self.out
         self.conv.fwd_bn(x, self.y, bn, self.npix, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws, cfg.st)
         drop = self.drop_mask if cfg.use_dropout else None
         L.bn_act_drop_fwd(_ptr(self.y), self.cout, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), self.act,

@@ -607,3 +607,56 @@ def test_forced_conv_kernel_families(variant):
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         "-k", "test_conv2d_fwd_bwd or fused_bn"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("case", [(1, 1, 128, 32, 1, 1, "valid", False, 2, 9, 7), (3, 3, 32, 32, 1, 2, "same", True, 1, 11, 13),
+                                  (3, 3, 16, 16, 1, 1, "same", True, 2, 10, 12), (1, 1, 64, 16, 1, 1, "valid", False, 1, 33, 20),
+                                  (3, 3, 64, 128, 1, 1, "same", True, 1, 8, 8), (2, 2, 16, 16, 2, 1, "valid", False, 2, 12, 8),
+                                  (3, 3, 3, 13, 2, 1, "same", True, 1, 16, 16)],
+                         ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}".format(*c[:7]))
+def test_conv2d_fwd_bn_act_inference_fusion(case, act):
+    """Inference phase: convolution + BN with fixed statistics + activation in one launch against
+    oracle conv -> batch_norm_infer -> PReLU / LeakyReLU (both kernel families, ragged tiles, every activation)."""
+    kh, kw, cin, cout, stride, dil, padding, bias, N, H, W = case
+    eng = pkg("engine")
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(kh * 10 + cin + cout + act)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=stride, dil=dil, padding=padding, bias=bias)
+    store.materialise(DEV)
+    ho, wo = cv.plan(N, H, W)
+    w = rng.standard_normal((kh, kw, cin, cout)) / np.sqrt(kh * kw * cin)
+    b = rng.standard_normal(cout) if bias else None
+    x = rng.standard_normal((N, H, W, cin))
+    gamma, beta = rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.3
+    mm, mv = rng.standard_normal(cout) * 0.2, rng.uniform(0.5, 1.5, cout)
+    alpha = rng.uniform(0.05, 0.4, cout)
+    store.views["c/kernel"].copy_(_t(w))
+    if bias:
+        store.views["c/bias"].copy_(_t(b))
+    xd, gd, bd, ad = _t(x), _t(gamma), _t(beta), _t(alpha)
+    mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+    mmd, mvd = _t(mm), _t(mv)
+    st = torch.cuda.current_stream().cuda_stream
+    L.bn_infer_stats(mmd.data_ptr(), mvd.data_ptr(), cout, 1e-3, mean.data_ptr(), invstd.data_ptr(), st)
+    y = torch.empty(N, ho, wo, cout, device=DEV)
+    L.conv2d_fwd_bn_act_infer(C.byref(cv.desc), xd.data_ptr(), cv.w.data_ptr(), cv.b.data_ptr() if bias else None,
+                              mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), act,
+                              ad.data_ptr() if act == 1 else None, 0.1, y.data_ptr(), st)
+    ref = K.conv2d(torch.from_numpy(x), torch.from_numpy(w), torch.from_numpy(b) if bias else None, stride, dil, padding)
+    ref = K.batch_norm_infer(ref, torch.from_numpy(gamma), torch.from_numpy(beta), torch.from_numpy(mm), torch.from_numpy(mv))
+    if act == 1:
+        ref = K.prelu(ref, torch.from_numpy(alpha))
+    elif act == 2:
+        ref = K.leaky_relu(ref, 0.1)
+    _check(y, ref, "y")
+    # and it is the composition of the two separate launches bit for bit (the BN kernel takes channel counts % 4 == 0)
+    if cout % 4:
+        return
+    y0 = torch.empty_like(y)
+    y1 = torch.empty_like(y)
+    cv.fwd(xd, y0, st)
+    L.bn_act_fwd(y0.data_ptr(), cout, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), act,
+                 ad.data_ptr() if act == 1 else None, 0.1, y1.data_ptr(), N * ho * wo, cout, st)
+    assert torch.equal(y, y1)
