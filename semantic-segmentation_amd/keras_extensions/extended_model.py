@@ -394,6 +394,14 @@ class ExtendedModel(object):
             scale = 1.0 / self.grad_sync.world_size if self.grad_sync is not None else 1.0
             self.optimizer.apply(grad_scale=scale, stream=st)
 
+        if self.grad_sync is None:
+            # no collective between the segments: one graph for the whole step (also lets the weight gradients of the late
+            # blocks keep running beside the early blocks' data-gradient chain instead of being joined in between)
+            def seg_all(st):
+                seg_a(st)
+                seg_b(st)
+                seg_c(st)
+            return [seg_all]
         return [seg_a, seg_b, seg_c]
 
     def _split_index(self) -> int:
@@ -446,7 +454,7 @@ class ExtendedModel(object):
         if not training:
             return [lambda: None]
         if self.grad_sync is None:
-            return [lambda: None, lambda: None, lambda: None]
+            return [lambda: None]
         rs = self.bucket_ranges()
         gs = self.grad_sync
         grad = self.graph.store.grad
