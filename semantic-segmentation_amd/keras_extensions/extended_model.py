@@ -380,7 +380,8 @@ class ExtendedModel(object):
             for b in reversed(blocks[split:]):
                 d = b.bwd(d, g._cfg)
                 g._cfg.flush()
-            g._cfg.join()
+            if self.grad_sync is not None:      # bucket 1 must be complete before its all-reduce starts
+                g._cfg.join()
             self._d_mid = d
 
         def seg_b(st):
