@@ -660,3 +660,32 @@ def test_conv2d_fwd_bn_act_inference_fusion(case, act):
     L.bn_act_fwd(y0.data_ptr(), cout, mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), act,
                  ad.data_ptr() if act == 1 else None, 0.1, y1.data_ptr(), N * ho * wo, cout, st)
     assert torch.equal(y, y1)
+
+
+def _fuzz_cases(n, seed):
+    """Seeded random convolution configurations: every combination of kernel extent, stride, dilation, padding mode,
+    channel counts around the tile widths (4 / 16 / 32 / 64) and ragged spatial sizes."""
+    rng = np.random.RandomState(seed)
+    chans = [2, 3, 4, 5, 8, 12, 13, 16, 17, 24, 31, 32, 33, 40, 48, 64, 68, 96, 128]
+    out = []
+    while len(out) < n:
+        kh, kw = [(1, 1), (2, 2), (3, 3), (1, 5), (5, 1), (3, 1), (1, 3)][rng.randint(7)]
+        s = int(rng.choice([1, 1, 2]))
+        d = 1 if s == 2 else int(rng.choice([1, 1, 2, 3]))
+        pad = "valid" if (kh, kw) in ((1, 1), (2, 2)) else str(rng.choice(["same", "same", "valid"]))
+        cin, cout = int(rng.choice(chans)), int(rng.choice(chans))
+        N, H, W = int(rng.randint(1, 4)), int(rng.randint(1, 24)), int(rng.randint(1, 40))
+        eh, ew = (kh - 1) * d + 1, (kw - 1) * d + 1
+        if pad == "valid" and (H < eh or W < ew):
+            continue
+        if (kh, kw) == (2, 2) and s == 2 and (H % 2 or W % 2):
+            H, W = H + H % 2, W + W % 2
+        out.append((kh, kw, cin, cout, s, d, pad, bool(rng.randint(2)), N, H, W))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(160, 20240611), ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}_b{}_{}x{}x{}".format(*c))
+def test_conv2d_fuzz(case):
+    """Forward, data gradient (with and without the fused addend) and weight / bias gradient of random configurations
+    against the fp64 oracle."""
+    test_conv2d_fwd_bwd(case)
