@@ -689,3 +689,27 @@ def test_conv2d_fuzz(case):
     """Forward, data gradient (with and without the fused addend) and weight / bias gradient of random configurations
     against the fp64 oracle."""
     test_conv2d_fwd_bwd(case)
+
+
+def _fuzz_bn_bwd_cases(n, seed):
+    """(kh kw cin cout dil N H W act drop) for the fused data-gradient + BN-backward entry point (stride 1, channel
+    counts a multiple of 4 as the BN kernels require)."""
+    rng = np.random.RandomState(seed)
+    chans = [4, 8, 12, 16, 24, 32, 40, 64, 128]
+    out = []
+    for _ in range(n):
+        kh, kw = [(1, 1), (3, 3), (1, 5), (5, 1)][rng.randint(4)]
+        out.append((kh, kw, int(rng.choice(chans)), int(rng.choice(chans)), int(rng.choice([1, 1, 2, 4])), int(rng.randint(1, 4)),
+                    int(rng.randint(2, 20)), int(rng.randint(2, 36)), int(rng.randint(3)), bool(rng.randint(2))))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_bn_bwd_cases(50, 77), ids=lambda c: "k{}x{}_{}to{}_d{}_{}x{}x{}_a{}_drop{}".format(*c))
+def test_conv2d_bwd_data_bn_bwd_fuzz(case):
+    test_conv2d_bwd_data_with_fused_bn_backward(case)
+
+
+@pytest.mark.parametrize("case", _fuzz_cases(50, 99),
+                         ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}_b{}_{}x{}x{}".format(*c))
+def test_conv2d_fwd_bn_stats_fuzz(case):
+    test_conv2d_fwd_with_fused_bn_statistics(case)
