@@ -713,3 +713,25 @@ def test_conv2d_bwd_data_bn_bwd_fuzz(case):
                          ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}_b{}_{}x{}x{}".format(*c))
 def test_conv2d_fwd_bn_stats_fuzz(case):
     test_conv2d_fwd_with_fused_bn_statistics(case)
+
+
+def _rand_cases(n, seed, gen):
+    rng = np.random.RandomState(seed)
+    return [gen(rng) for _ in range(n)]
+
+
+@pytest.mark.parametrize("c,npix,act", _rand_cases(30, 5, lambda r: (int(r.choice([4, 8, 12, 16, 24, 32, 64, 100, 128, 256])),
+                                                                      int(r.randint(1, 3000)), int(r.randint(3)))))
+def test_bn_act_fuzz(c, npix, act):
+    test_bn_act_fwd_bwd(c, npix, act)
+
+
+@pytest.mark.parametrize("n,h,w,c", _rand_cases(30, 6, lambda r: (int(r.randint(1, 4)), int(r.randint(1, 20)), int(r.randint(1, 30)),
+                                                                   int(r.choice([1, 3, 4, 5, 13, 16, 24, 64, 128])))))
+def test_maxpool_fuzz(n, h, w, c):
+    test_maxpool_argmax_unpool_bit_exact(n, h, w, c)
+
+
+@pytest.mark.parametrize("C_,npix", _rand_cases(20, 7, lambda r: (int(r.randint(2, 65)), int(r.randint(1, 4000)))))
+def test_softmax_xent_fuzz(C_, npix):
+    test_softmax_xent_loss_grad_cm(C_, npix)
