@@ -321,13 +321,27 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
         for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[t][j], acc[t]);
     };
     const int nsteps = nvalid * (g.cout >> 3);
-    f32x4 a0, a1, b0[NT], b1[NT];
-    fetch(a0, b0);
-    for (int i = 0; i < nsteps; i += 2) {
-      fetch(a1, b1);               // past the end: zeros
-      mma(a0, b0);
+    if constexpr (NT == 4) {       // two steps of operands in flight, as in the wide forward kernel
+      f32x4 a0, a1, a2, b0[NT], b1[NT], b2[NT];
       fetch(a0, b0);
-      if (i + 1 < nsteps) mma(a1, b1);
+      fetch(a1, b1);
+      for (int i = 0; i < nsteps; i += 3) {
+        fetch(a2, b2);             // past the end: zeros
+        mma(a0, b0);
+        fetch(a0, b0);
+        if (i + 1 < nsteps) mma(a1, b1);
+        fetch(a1, b1);
+        if (i + 2 < nsteps) mma(a2, b2);
+      }
+    } else {
+      f32x4 a0, a1, b0[NT], b1[NT];
+      fetch(a0, b0);
+      for (int i = 0; i < nsteps; i += 2) {
+        fetch(a1, b1);               // past the end: zeros
+        mma(a0, b0);
+        fetch(a0, b0);
+        if (i + 1 < nsteps) mma(a1, b1);
+      }
     }
   } else {
     for (int ky = 0; ky < g.kh; ++ky) {
