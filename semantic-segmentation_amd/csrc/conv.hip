@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
         for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[j][t], acc[t]);
     };
     const int nsteps = ntaps * (g.cin >> 3);
-    if constexpr (NT == 4) {
+    if constexpr (NT >= 2) {
       // wide tiles run at two waves per SIMD (accumulators): two steps of operands in flight instead of one, so that a
       // memory round trip is covered by two steps of MFMA work per wave (three register sets, rotated by full unroll)
       f32x4 a0, a1, a2;
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
         for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[t][j], acc[t]);
     };
     const int nsteps = nvalid * (g.cout >> 3);
-    if constexpr (NT == 4) {       // two steps of operands in flight, as in the wide forward kernel
+    if constexpr (NT >= 2) {       // two steps of operands in flight, as in the wide forward kernel
       f32x4 a0, a1, a2, b0[NT], b1[NT], b2[NT];
       fetch(a0, b0);
       fetch(a1, b1);
