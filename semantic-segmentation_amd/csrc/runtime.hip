@@ -126,12 +126,20 @@ ProfileScope::ProfileScope(hipStream_t st, double bytes, double flops) : st_(st)
   if (!g_profiling) return;
   if (hipEventCreate(&e0_) != hipSuccess || hipEventCreate(&e1_) != hipSuccess) { e0_ = e1_ = nullptr; return; }
   g_profile_stream = st_;
-  hipEventRecord(e0_, st_);
+  if (hipEventRecord(e0_, st_) != hipSuccess) {   // no record for this launch rather than a bogus one
+    (void)hipEventDestroy(e0_);
+    (void)hipEventDestroy(e1_);
+    e0_ = e1_ = nullptr;
+  }
 }
 
 ProfileScope::~ProfileScope() {
   if (!e0_ || !e1_) return;
-  hipEventRecord(e1_, st_);
+  if (hipEventRecord(e1_, st_) != hipSuccess) {
+    (void)hipEventDestroy(e0_);
+    (void)hipEventDestroy(e1_);
+    return;
+  }
   ProfileRecord r;
   snprintf(r.name, sizeof(r.name), "%s", g_kernel);
   r.e0 = e0_; r.e1 = e1_; r.bytes = bytes_; r.flops = flops_; r.ms = -1.f;
@@ -153,7 +161,10 @@ const char* ssmi_last_error(void) { return g_err; }
 const char* ssmi_last_kernel(void) { return g_kernel; }
 
 ssmi_status ssmi_profile_begin(void) {
-  for (auto& r : g_records) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+  for (auto& r : g_records) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
   g_records.clear();
   g_profiling = true;
   return SSMI_OK;
@@ -178,8 +189,8 @@ ssmi_status ssmi_profile_end(int32_t* count) {
       SSMI_HIP(hipEventElapsedTime(&ms, a, b));
       if (i >= 0) t[i] = ms;
     }
-    hipEventDestroy(a);
-    hipEventDestroy(b);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
     std::sort(t, t + 9);
     g_bracket_overhead_ms = t[4];
   }
@@ -257,7 +268,7 @@ ssmi_status ssmi_graph_end_capture(void* stream, ssmi_graph** out) {
   hipGraphExec_t e = nullptr;
   hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
   if (err != hipSuccess) {
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     set_error("hipGraphInstantiate: %s", hipGetErrorString(err));
     return SSMI_E_HIP;
   }
@@ -274,9 +285,13 @@ ssmi_status ssmi_graph_launch(ssmi_graph* g, void* stream) {
 
 ssmi_status ssmi_graph_destroy(ssmi_graph* g) {
   if (!g) return SSMI_OK;
-  hipGraphExecDestroy(g->exec);
-  hipGraphDestroy(g->graph);
+  const hipError_t e1 = hipGraphExecDestroy(g->exec);
+  const hipError_t e2 = hipGraphDestroy(g->graph);
   delete g;
+  if (e1 != hipSuccess || e2 != hipSuccess) {
+    set_error("graph_destroy: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return SSMI_E_HIP;
+  }
   return SSMI_OK;
 }
 
