@@ -495,8 +495,10 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   constexpr int EW = VEC ? 4 : 1;
   constexpr int KB = KQ * EW;             // reduction elements per k-block
   typedef float accv __attribute__((ext_vector_type(NR)));
-  int* tab = reinterpret_cast<int*>(smem);          // [0]=nvt, then {dy, dx, wl_word_offset} per valid tap
-  float* Wl = smem + 4 + 4 * kMaxTaps;
+  // [0]=nvt, then {dy, dx, wl_word_offset} per valid tap, the source tap of every staged slot, and the byte offset
+  // (dy * in_w + dx) * in_ld * 4 of the tap's input pixel relative to the output pixel's own
+  int* tab = reinterpret_cast<int*>(smem);
+  float* Wl = smem + 4 + 5 * kMaxTaps;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = lane & (TS - 1), kq = lane / TS;
   const int s = g.stride;
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
       tab[2 + 3 * n] = dxo;
       tab[3 + 3 * n] = n * a.C_r * a.WS;     // only the valid taps are staged, packed
       tab[4 + 3 * kMaxTaps + n] = t;         // source tap of staged slot n
+      tab[4 + 4 * kMaxTaps + n] = (dyo * a.in_w + dxo) * a.in_ld * 4;
     }
     if (t == 0) tab[0] = __popcll(mask);
   }
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
     bool pv[MT];
     int by[MT], bx[MT], img[MT];
     int lbase[MT];                 // TILE: word offset of the lane's pixel inside the patch
+    unsigned pbase[MT];            // byte offset of the lane's pixel at tap offset (0, 0)
     int n_t = 0, ty0 = 0, tx0 = 0; // TILE: image and origin of this workgroup's tile (uniform)
     if constexpr (TILE) {
       const unsigned tl = (unsigned)grp;
@@ -675,6 +679,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         const int ly = wave * 2 + (M16 ? (m >> 1) : m), lx = (M16 ? (m & 1) * 16 : 0) + c;
         lbase[m] = (ly * a.PW + lx) * a.CP;
         pv[m] = true; by[m] = bx[m] = img[m] = 0;
+        pbase[m] = 0u;
       }
     } else {
       // pixel coordinates in 32-bit arithmetic (M < 2^31: tensors are below 2 GiB); two divisions per pixel
@@ -690,6 +695,8 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         bx[m] = (int)qx * sm_;
         img[m] = (int)n_ * a.in_h * a.in_w;
         lbase[m] = 0;
+        // byte offset of the pixel the zero tap reads; a tap adds its table offset (no multiplication per tap)
+        pbase[m] = (unsigned)(img[m] + by[m] * a.in_w + bx[m]) * (unsigned)a.in_ld * 4u;
       }
     }
     // flat output pixel index of accumulator row `row` of pixel tile m, or 0xFFFFFFFF outside the tensor
@@ -714,17 +721,19 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
     f32x4 A[D][MT];
     int wb[D];
     // the tap-table entry of the NEXT fetch is read at the end of the current one, off the critical path
-    int nty, ntx, nwb;
+    int nty, ntx, nwb, ntoff;
     auto lookup = [&]() {
       const int ts_ = tapi < nvt ? tapi : 0;
       nty = tab[1 + 3 * ts_];
       ntx = tab[2 + 3 * ts_];
       nwb = tab[3 + 3 * ts_];
+      ntoff = tab[4 + 4 * kMaxTaps + ts_];
     };
     lookup();
     auto fetch = [&](f32x4 (&Ab)[MT], int& wbase) {
       const bool tv = tapi < nvt;
       const int ty = nty, tx = ntx;
+      const unsigned toff = (unsigned)ntoff + (unsigned)r0 * 4u;
       wbase = nwb + r0 * a.WS + cbase0 + c;
       if constexpr (TILE) {
         const int toff = tv ? ((ty - a.pmin_y) * a.PW + (tx - a.pmin_x)) * a.CP + r0 : -1;
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         for (int m = 0; m < MT; ++m) {
           const int iy = by[m] + ty, ix = bx[m] + tx;
           const bool ok = tv && pv[m] && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
-          const unsigned off = ok ? ((unsigned)(img[m] + iy * a.in_w + ix) * (unsigned)a.in_ld + (unsigned)r0) * 4u : kOOB;
+          const unsigned off = ok ? pbase[m] + toff : kOOB;
           if (VEC) Ab[m] = bload4(rin, off);
           else Ab[m][0] = bload(rin, off);
         }
@@ -1400,7 +1409,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   a.WS = m16 ? copad + 4 : copad;
   // a stride phase of the data gradient sees at most ceil(k/s)^2 taps (all of them when dilated)
   const int staged_taps = (mode == 0 || g.dil > 1) ? ntaps : ((g.kh + s - 1) / s) * ((g.kw + s - 1) / s);
-  size_t lds = (size_t)(4 + 4 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
+  size_t lds = (size_t)(4 + 5 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
   if (lds > 64 * 1024) return false;
   if ((part || bb.x) && lds < (size_t)12 * nt * ts * 4) lds = (size_t)12 * nt * ts * 4;   // room for the column-sum combine
 
