@@ -1,5 +1,5 @@
 """Per-layer timing of the convolution entry points on the unique conv shapes of ENet @512x512, batch 16."""
-import sys, os, ctypes as C
+import sys, os
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))

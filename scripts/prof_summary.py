@@ -1,4 +1,4 @@
-import csv, sys, glob
+import csv, sys
 f = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 rows = list(csv.DictReader(open(f)))

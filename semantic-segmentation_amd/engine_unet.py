@@ -10,13 +10,12 @@ gradient buffer when the encoder block runs its backward.
 """
 from __future__ import annotations
 
-import ctypes as C
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional
 
 import torch
 
 from ._lib import lib
-from .engine import (ACT_LEAKY, ACT_NONE, BN_EPS, BN_MOMENTUM, BatchNorm, Block, ClassifierHead, Conv, GraphBase, ParamStore,
+from .engine import (ACT_LEAKY, ACT_NONE, BatchNorm, Block, ClassifierHead, Conv, GraphBase, ParamStore,
                      RunCfg, _ptr)
 
 DROP_RATE = 0.1     # src/models.py:841

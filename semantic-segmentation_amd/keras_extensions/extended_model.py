@@ -19,7 +19,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from collections import OrderedDict
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Sequence
 
 import numpy as np
 import torch

@@ -12,7 +12,7 @@ matplotlib / pydensecrf and are not part of this module.
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Sequence
+from typing import List
 
 import numpy as np
 import torch
