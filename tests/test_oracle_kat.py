@@ -258,7 +258,7 @@ def test_classification_loss_known_answers():
     y = torch.tensor([[1.0, 0.0], [0.0, 1.0]], dtype=torch.float64)
     w = torch.tensor([[3.0, 5.0], [7.0, 2.0]], dtype=torch.float64)
     loss = K.classification_weighted_categorical_crossentropy(y, z, w)
-    assert abs(float(loss) - 0.5 * (3.0 * np.log(2.0) + 2.0 * -np.log(1e-6))) < 1e-12
+    assert abs(float(loss.detach()) - 0.5 * (3.0 * np.log(2.0) + 2.0 * -np.log(1e-6))) < 1e-12
     (g,) = torch.autograd.grad(loss, [z])
     np.testing.assert_allclose(g[0].numpy(), [0.5 * 3.0 * (0.5 - 1.0), 0.5 * 3.0 * 0.5], rtol=1e-12)
     assert float(g[1].abs().max()) == 0.0
