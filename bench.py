@@ -87,9 +87,11 @@ def main():
                          "of all ranks summed at the end")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="keep the weight gradients on the main stream")
     ap.add_argument("--eager", action="store_true", help="launch kernels directly instead of replaying HIP graphs")
-    ap.add_argument("--host-inputs", action="store_true",
-                    help="side measurement: every timed step first stages the batch from host (numpy) arrays, as "
-                         "train_on_batch does for a generator's output; the headline value keeps its inputs resident in HBM")
+    ap.add_argument("--host-inputs", nargs="?", const="f32", default=None, choices=["f32", "u8"],
+                    help="side measurement (the headline value keeps its inputs resident in HBM).  f32: every timed step "
+                         "first stages the float32 batch from pageable numpy arrays, as train_on_batch does for a "
+                         "generator's output.  u8: uint8 crops and masks go through pinned double buffers and the "
+                         "device pre-pass (generators.PinnedBatchFeeder), the next batch in flight during the step")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -134,11 +136,25 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        host = [t.cpu().numpy() for t in (images, labels, weights)] + [nu] if args.host_inputs else None
+        host = feeder = None
+        if args.host_inputs == "f32":
+            host = [t.cpu().numpy() for t in (images, labels, weights)] + [nu]
+        elif args.host_inputs == "u8":
+            gen = pkg("generators")
+            hrng = np.random.RandomState(4242 + rank)
+            u8_images = hrng.randint(0, 256, size=(args.batch, args.size, args.size, 3)).astype(np.uint8)
+            u8_masks = hrng.randint(0, 24, size=(args.batch, args.size, args.size)).astype(np.uint8)
+            enc = gen.DeviceBatchEncoder({c: c for c in range(24)}, [0.0] + [1.0] * 23, [0.48, 0.45, 0.40], [0.23, 0.22, 0.23],
+                                         device=dev)
+            feeder = gen.PinnedBatchFeeder(enc, args.batch, args.size, args.size)
+            feeder.submit(u8_images, u8_masks)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             if host is not None:
                 model.set_batch(host)
+            elif feeder is not None:
+                feeder.submit(u8_images, u8_masks)      # the next batch travels while this one trains
+                feeder.feed(model)
             step()
         if args.mode == "eval":
             ev = tr.reduce_evaluation(0.0, args.batch * args.steps)   # sums the int64 matrices over the ranks
@@ -188,7 +204,9 @@ def main():
                "config": {"workload": "{} 24 classes {}x{} per-GPU batch {} fp32 train step (fwd+loss+bwd+Adam), global batch {}".format(
                    args.model, args.size, args.size, args.batch, args.batch * world),
                    "parallelism": "dp{}".format(world), "final_loss": round(loss, 5),
-                   "inputs": "host arrays staged every step (PCIe-inclusive)" if args.host_inputs else "resident in HBM"},
+                   "inputs": {None: "resident in HBM", "f32": "float32 host arrays staged every step (PCIe-inclusive)",
+                              "u8": "uint8 host arrays through pinned double buffers + device pre-pass every step "
+                                    "(PCIe-inclusive, overlapped)"}[args.host_inputs]},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)
     if world > 1:
