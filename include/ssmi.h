@@ -87,6 +87,16 @@ ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float
 ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
                                          int32_t act, const float* alpha, float slope, float* y, void* stream);
+/* The same with a skip tensor added between the normalisation and the activation:
+ *   y = act(gamma * ((conv(x) + bias - mean) * invstd) + beta + skip[pixel * skip_ld + channel])
+ * i.e. the last projection of a regular bottleneck, its BatchNormalization, the Add with the block input and the final
+ * PReLU (src/models.py:1142-1174) in one launch when the learning phase is 0 (SpatialDropout2D is the identity then).
+ * skip has the output's pixel grid, skip_ld >= cout floats per pixel; skip == NULL gives ssmi_conv2d_fwd_bn_act_infer.
+ * Same arithmetic, in the same order, as ssmi_conv2d_fwd -> ssmi_merge_fwd(other_mode 0, drop NULL). */
+ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                             const float* skip, int32_t skip_ld, int32_t act, const float* alpha,
+                                             float slope, float* y, void* stream);
 
 /* Convolution whose output feeds a training-phase BatchNormalization (every conv -> BN pair of src/models.py, e.g.
  * :1096-1100): same y as ssmi_conv2d_fwd plus the statistics ssmi_bn_train_stats would compute from y (save_mean,

@@ -46,6 +46,8 @@ _PROTOS = {
     "ssmi_same_pad": (_i32, [_i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "ssmi_conv2d_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
     "ssmi_conv2d_fwd_bn_act_infer": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp]),
+    "ssmi_conv2d_fwd_bn_add_act_infer": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _f32, _vp,
+                                                _vp]),
     "ssmi_conv2d_fwd_bn_stats_workspace_bytes": (_sz, [_PD]),
     "ssmi_conv2d_fwd_bn_stats": (_i32, [_PD, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_bwd_data": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),

@@ -57,6 +57,10 @@ struct BnBwdArgs {
   const float* drop;       // [n, c] dropout table or nullptr
   unsigned hw;             // pixels per image
   float* part;
+  // forward, inference-phase epilogue only (mean != nullptr): y = act(BN(acc) + skip[pixel * skip_ld + channel]) -
+  // the identity-skip merge of a bottleneck folded into its last convolution (skip == nullptr: no addend)
+  const float* skip;
+  int skip_ld;
 };
 
 // Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.

@@ -177,9 +177,19 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
       const int cc = colv[t] ? c : 0;
       const float mu = bn.mean[cc], is = bn.invstd[cc], ga = bn.gamma[cc], be = bn.beta[cc];
       const float al = bn.act == SSMI_ACT_PRELU ? bn.alpha[cc] : bn.slope;
+      float sk[16];
+      if (bn.skip) {   // uniform; stride 1: the skip tensor has the output's pixel grid
+        const __amdgpu_buffer_rsrc_t rsk = make_rsrc(bn.skip, (unsigned)(M * bn.skip_ld * 4));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+          sk[i] = bload(rsk, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bn.skip_ld + (unsigned)c) * 4u : kOOB);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float z = ga * (((acc[t][i] + bv) - mu) * is) + be;
+        float z = ga * (((acc[t][i] + bv) - mu) * is) + be;
+        if (bn.skip) z += sk[i];
         bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, (bn.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
       }
     } else {
@@ -815,11 +825,24 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
         const int cc = cv ? col : 0;
         const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
         const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
+        float sk[MT][NR];
+        if (bb.skip) {   // uniform; the skip tensor has the output's pixel grid
+          const __amdgpu_buffer_rsrc_t rsk = make_rsrc(bb.skip, (unsigned)(M * bb.skip_ld * 4));
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+              const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
+              const unsigned po = row_pixel(m, row);
+              sk[m][i] = bload(rsk, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.skip_ld + (unsigned)col) * 4u : kOOB);
+            }
+        }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int i = 0; i < NR; ++i) {
-            const float z = ga * (((acc[m][t][i] + bvv) - mu) * is) + be;
+            float z = ga * (((acc[m][t][i] + bvv) - mu) * is) + be;
+            if (bb.skip) z += sk[m][i];
             bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, (bb.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
           }
       } else {
@@ -1962,9 +1985,23 @@ ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x
   SSMI_REQUIRE(x && w && y && mean && invstd && gamma && beta, SSMI_E_INVALID_ARG, "conv2d_fwd_bn_act_infer: NULL tensor");
   SSMI_REQUIRE(act == SSMI_ACT_NONE || act == SSMI_ACT_LEAKY || (act == SSMI_ACT_PRELU && alpha), SSMI_E_INVALID_ARG,
                "conv2d_fwd_bn_act_infer: activation %d", act);
-  BnBwdArgs bn;
-  bn.x = nullptr; bn.ld = 0; bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta; bn.alpha = alpha;
-  bn.slope = slope; bn.act = act; bn.drop = nullptr; bn.hw = 1; bn.part = nullptr;
+  return ssmi_conv2d_fwd_bn_add_act_infer(d, x, w, bias, mean, invstd, gamma, beta, nullptr, 0, act, alpha, slope, y, stream);
+}
+
+ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                             const float* skip, int32_t skip_ld, int32_t act, const float* alpha,
+                                             float slope, float* y, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(x && w && y && mean && invstd && gamma && beta, SSMI_E_INVALID_ARG, "conv2d_fwd_bn_add_act_infer: NULL tensor");
+  SSMI_REQUIRE(act == SSMI_ACT_NONE || act == SSMI_ACT_LEAKY || (act == SSMI_ACT_PRELU && alpha), SSMI_E_INVALID_ARG,
+               "conv2d_fwd_bn_add_act_infer: activation %d", act);
+  SSMI_REQUIRE(!skip || (skip_ld >= d->cout && (int64_t)d->n * d->ho * d->wo * skip_ld * 4 < 0x7FFFFFFFLL), SSMI_E_INVALID_ARG,
+               "conv2d_fwd_bn_add_act_infer: skip tensor stride %d for %d channels", skip_ld, d->cout);
+  BnBwdArgs bn{};
+  bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta; bn.alpha = alpha;
+  bn.slope = slope; bn.act = act; bn.hw = 1; bn.skip = skip; bn.skip_ld = skip ? skip_ld : 0;
   return launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream), nullptr, nullptr, bn);
 }
 
@@ -2034,7 +2071,7 @@ ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const float* dy
                                 dbeta, dalpha, npix, c, ws, ws_bytes, stream);
   }
   float* part = reinterpret_cast<float*>(ws);
-  BnBwdArgs bb;
+  BnBwdArgs bb{};
   bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
   bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
   int rows = 0;

@@ -215,6 +215,13 @@ class Conv:
         lib().conv2d_fwd_bn_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
                                       _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(y), st)
 
+    def fwd_bn_add_act_infer(self, x, y, bn: "BatchNorm", skip, skip_ld, alpha, st):
+        """Inference phase: y = PReLU_alpha(BN(conv(x)) + skip) in one launch (the tail of a regular bottleneck)."""
+        assert not self.transpose
+        lib().conv2d_fwd_bn_add_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
+                                          _ptr(bn.gamma), _ptr(bn.beta), _ptr(skip), skip_ld, ACT_PRELU, _ptr(alpha), 0.0,
+                                          _ptr(y), st)
+
     def bwd_data(self, dy, dx, st, add=None):
         L = lib()
         if self.transpose:
@@ -434,6 +441,9 @@ class InitialBlock(Block):
         return None  # the images need no gradient
 
 
+_NO_FUSED_INFER_MERGE = os.environ.get("SSMI_NO_FUSED_INFER_MERGE") is not None    # A/B switch for measurements
+
+
 class Bottleneck(Block):
     """Encoder bottleneck (src/models.py:1069-1174 / 1373-1481) and decoder bottleneck (1208-1299 / 1520-1610).
 
@@ -597,6 +607,12 @@ class Bottleneck(Block):
         else:
             self.conv2.fwd_bn(src2, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
             self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
+        if (not tr and self.mode == 0 and not (cfg.use_dropout and self.drop_mask is not None)
+                and not _NO_FUSED_INFER_MERGE):
+            # inference phase, identity skip: BN3, the Add and PReLU3 ride in conv3's epilogue (dropout is the identity)
+            self._drop_used = None
+            self.conv3.fwd_bn_add_act_infer(self.a2, self.out, self.bn3, x, self.cin, self.alpha3, st)
+            return self.out
         self.conv3.fwd_bn(self.a2, self.y3, self.bn3, self.np_out, tr, um, ub, ws, st)
         if self.mode == 1:
             L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin,

@@ -662,6 +662,48 @@ def test_conv2d_fwd_bn_act_inference_fusion(case, act):
     assert torch.equal(y, y1)
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(32, 128, 2, 9, 7), (16, 64, 1, 16, 24), (4, 16, 2, 10, 12), (8, 40, 1, 5, 27),
+                                            (32, 128, 1, 32, 32)])
+def test_conv2d_fwd_bn_add_act_inference_fusion(cin, cout, N, H, W):
+    """Inference-phase tail of a regular bottleneck in one launch, PReLU(BN3(conv3(a2)) + x), against the oracle and, bit
+    for bit, against the two launches it replaces (ssmi_conv2d_fwd -> ssmi_merge_fwd with the identity skip)."""
+    eng, lib_mod = pkg("engine"), pkg("_lib")
+    L = lib_mod.lib()
+    rng = np.random.RandomState(cin + cout + H)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "c", 1, 1, cin, cout, padding="valid", bias=False)
+    store.materialise(DEV)
+    cv.plan(N, H, W)
+    w = rng.standard_normal((1, 1, cin, cout)) / np.sqrt(cin)
+    x = rng.standard_normal((N, H, W, cin))
+    skip = rng.standard_normal((N, H, W, cout))
+    gamma, beta = rng.uniform(0.5, 1.5, cout), rng.standard_normal(cout) * 0.3
+    mm, mv = rng.standard_normal(cout) * 0.2, rng.uniform(0.5, 1.5, cout)
+    alpha = rng.uniform(0.05, 0.4, cout)
+    store.views["c/kernel"].copy_(_t(w))
+    xd, sd, gd, bd, ad, mmd, mvd = (_t(v) for v in (x, skip, gamma, beta, alpha, mm, mv))
+    mean, invstd = torch.empty(cout, device=DEV), torch.empty(cout, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    L.bn_infer_stats(mmd.data_ptr(), mvd.data_ptr(), cout, 1e-3, mean.data_ptr(), invstd.data_ptr(), st)
+    y = torch.empty(N, H, W, cout, device=DEV)
+    L.conv2d_fwd_bn_add_act_infer(C.byref(cv.desc), xd.data_ptr(), cv.w.data_ptr(), None, mean.data_ptr(), invstd.data_ptr(),
+                                  gd.data_ptr(), bd.data_ptr(), sd.data_ptr(), cout, 1, ad.data_ptr(), 0.0, y.data_ptr(), st)
+    ref = K.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, 1, 1, "valid")
+    ref = K.batch_norm_infer(ref, torch.from_numpy(gamma), torch.from_numpy(beta), torch.from_numpy(mm), torch.from_numpy(mv))
+    ref = K.prelu(ref + torch.from_numpy(skip), torch.from_numpy(alpha))
+    _check(y, ref, "y")
+    y3, out = torch.empty_like(y), torch.empty_like(y)
+    cv.fwd(xd, y3, st)
+    md = lib_mod.MergeDesc(N, H, W, cout, 0, cout)
+    bn3 = lib_mod.BnParams(mean.data_ptr(), invstd.data_ptr(), gd.data_ptr(), bd.data_ptr())
+    L.merge_fwd(C.byref(md), y3.data_ptr(), C.byref(bn3), None, sd.data_ptr(), None, None, ad.data_ptr(), out.data_ptr(), st)
+    assert torch.equal(y, out)
+    with pytest.raises(lib_mod.SsmiError):      # a skip tensor narrower than the output
+        L.conv2d_fwd_bn_add_act_infer(C.byref(cv.desc), xd.data_ptr(), cv.w.data_ptr(), None, mean.data_ptr(),
+                                      invstd.data_ptr(), gd.data_ptr(), bd.data_ptr(), sd.data_ptr(), cout - 4, 1,
+                                      ad.data_ptr(), 0.0, y.data_ptr(), st)
+
+
 def _fuzz_cases(n, seed):
     """Seeded random convolution configurations: every combination of kernel extent, stride, dilation, padding mode,
     channel counts around the tile widths (4 / 16 / 32 / 64) and ragged spatial sizes."""
