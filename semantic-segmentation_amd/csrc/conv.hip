@@ -1465,10 +1465,15 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   a.q_blk = kb / a.C_r;
   a.r_blk = kb % a.C_r;
   const int64_t M = (int64_t)g.n * qh * qw;
-  const int mt = m16 ? 4 : (nt >= 4 ? 1 : 2);
+  // 16-wide tiles: two pixel tiles (32 pixels) per wave keep the kernel at 120 VGPRs = four waves per SIMD, whose
+  // prologue, multiply and store phases overlap; four tiles (172 VGPRs, two waves per SIMD) measured 14-24 % slower per
+  // layer and 2.6 % per ENet training step, one tile 0.9 % slower than two (MI355X).  SSMI_M16_MT=4 selects the old shape.
+  static const int m16_mt = getenv("SSMI_M16_MT") ? atoi(getenv("SSMI_M16_MT")) : 2;
+  const int mt = m16 ? ((m16_mt == 4 || tile) ? 4 : 2) : (nt >= 4 ? 1 : 2);   // the tile variant is built for 64 pixels
   const int64_t ngroups = ceil_div64(M, (int64_t)mt * ts);
   int64_t bx = tile ? (int64_t)g.n * a.tiles_y * a.tiles_x : ceil_div64(ngroups, 4);
   // enough workgroups to fill the chip, few enough that each stages the kernel matrix for several pixel groups
+  // (measured with 32 pixels per wave: a cap of 512 or 2048 workgroups is 5-15 % slower per layer than 1024)
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, (unsigned)ctiles, mode == 0 ? 1u : (unsigned)(s * s));
   if (part_rows) *part_rows = (int)bx;
@@ -1489,8 +1494,10 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
     set_last_kernel("conv_gemm_lds<%s, %d, %d, %s, %d, false>", m16 ? "true" : "false", mt, nt, vec ? "true" : "false",
                     m16 ? (nblk <= 2 ? 2 : 4) : (nt == 1 ? (nblk <= 4 ? 4 : 8) : (nt == 2 ? 4 : (nblk <= 4 ? 4 : 8))));
     if (m16) {
-      if (nblk <= 2) { if (vec) LG(true, 4, 1, true, 2, false); else LG(true, 4, 1, false, 2, false); }
-      else { if (vec) LG(true, 4, 1, true, 4, false); else LG(true, 4, 1, false, 4, false); }
+#define LM(MT_, D_) do { if (vec) LG(true, MT_, 1, true, D_, false); else LG(true, MT_, 1, false, D_, false); } while (0)
+      if (nblk <= 2) { if (mt == 2) LM(2, 2); else LM(4, 2); }
+      else { if (mt == 2) LM(2, 4); else LM(4, 4); }
+#undef LM
     } else if (nt == 1) {
       if (nblk <= 4) { if (vec) LG(false, 2, 1, true, 4, false); else LG(false, 2, 1, false, 4, false); }
       else { if (vec) LG(false, 2, 1, true, 8, false); else LG(false, 2, 1, false, 8, false); }
