@@ -289,14 +289,20 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
     // Flattened (valid tap of this phase, 8-channel block) reduction, software pipelined like the forward kernel.
     const int ntaps = g.kh * g.kw;
     int tap = -1, c0 = 0;                           // state of the NEXT fetch
+    int tky = 0, tkx = -1;                          // (ky, kx) of `tap`, advanced without divisions
     unsigned yo = kOOB, wtap = kOOB;
     auto nexttap = [&]() {                          // advance to the next tap that contributes to this phase (uniform)
       for (++tap; tap < ntaps; ++tap) {
-        const int ky = tap / g.kw, kx = tap - ky * g.kw;
+        if (++tkx == g.kw) { tkx = 0; ++tky; }
+        const int ky = tky, kx = tkx;
         const int ty0 = pa + g.pad_t - ky * g.dil, tx0 = pb + g.pad_l - kx * g.dil;
-        if (((ty0 % s) + s) % s != 0 || ((tx0 % s) + s) % s != 0) continue;
+        if (s != 1 && (((ty0 % s) + s) % s != 0 || ((tx0 % s) + s) % s != 0)) continue;
         const int ty = iy + g.pad_t - ky * g.dil, tx = ix + g.pad_l - kx * g.dil;
-        const int oy = ty / s, ox = tx / s;         // exact when ty, tx >= 0
+        int oy = ty, ox = tx;
+        if (s != 1) {                               // uniform: stride 1 needs no per-lane divisions
+          oy = ty / s;                              // exact when ty, tx >= 0
+          ox = tx / s;
+        }
         const bool inb = pv && ty >= 0 && tx >= 0 && oy < g.ho && ox < g.wo;
         yo = inb ? img_off + (unsigned)(oy * g.wo + ox) * (unsigned)g.y_ld * 4u : kOOB;
         wtap = (unsigned)(tap * g.cin) * wrow;
@@ -306,11 +312,13 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
       wtap = kOOB;
     };
     nexttap();
-    int nvalid = 0;
-    for (int t = 0; t < ntaps; ++t) {
-      const int ky = t / g.kw, kx = t - ky * g.kw;
-      const int ty0 = pa + g.pad_t - ky * g.dil, tx0 = pb + g.pad_l - kx * g.dil;
-      nvalid += (((ty0 % s) + s) % s == 0 && ((tx0 % s) + s) % s == 0) ? 1 : 0;
+    int nvalid = s == 1 ? ntaps : 0;
+    if (s != 1) {
+      for (int t = 0; t < ntaps; ++t) {
+        const int ky = t / g.kw, kx = t - ky * g.kw;
+        const int ty0 = pa + g.pad_t - ky * g.dil, tx0 = pb + g.pad_l - kx * g.dil;
+        nvalid += (((ty0 % s) + s) % s == 0 && ((tx0 % s) + s) % s == 0) ? 1 : 0;
+      }
     }
     auto fetch = [&](f32x4& a, f32x4 (&b)[NT]) {
       const unsigned co4 = (unsigned)(c0 + 4 * hh) * 4u;
@@ -358,12 +366,12 @@ __global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, con
       const int ty0 = pa + g.pad_t - ky * g.dil;
       if (((ty0 % s) + s) % s != 0) continue;  // uniform
       const int ty = iy + g.pad_t - ky * g.dil;
-      const int oy = ty / s;  // exact when ty >= 0
+      const int oy = s == 1 ? ty : ty / s;  // exact when ty >= 0
       for (int kx = 0; kx < g.kw; ++kx) {
         const int tx0 = pb + g.pad_l - kx * g.dil;
         if (((tx0 % s) + s) % s != 0) continue;  // uniform
         const int tx = ix + g.pad_l - kx * g.dil;
-        const int ox = tx / s;
+        const int ox = s == 1 ? tx : tx / s;
         const bool inb = pv && ty >= 0 && tx >= 0 && oy < g.ho && ox < g.wo;
         const unsigned yo = inb ? img_off + (unsigned)(oy * g.wo + ox) * (unsigned)g.y_ld * 4u : kOOB;
         const unsigned wtap = (unsigned)((ky * g.kw + kx) * g.cin) * wrow;
