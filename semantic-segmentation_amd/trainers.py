@@ -334,6 +334,8 @@ class SegmentationTrainer(object):
         """src/trainers.py:1770-1803 (the path template handling stays with the caller)."""
         if self.teacher_model is None:
             raise ValueError('Teacher model is not set, cannot save teacher model weights')
+        if self.rank != 0:      # one writer per file: rank 0 (see save_model_weights)
+            return
         os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
         self.teacher_model.save(file_path, overwrite=True, include_optimizer=True)
 
@@ -386,15 +388,19 @@ class SegmentationTrainer(object):
         if template is None:
             raise ValueError('the configuration names no checkpoint file path')
         file_path = self._populate_path_template(template, epoch=epoch_index, val_loss=val_loss) + file_extension
-        os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
-        self.model.save_weights(file_path, overwrite=True)
+        # Data parallel: the weights are identical on every rank (same averaged gradients), the BatchNormalization moving
+        # statistics are per replica; one writer per file, rank 0, so a checkpoint carries rank 0's moving statistics.
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
+            self.model.save_weights(file_path, overwrite=True)
         return file_path
 
     def save_optimizer_settings(self, model, file_extension=''):
         file_path = self._populate_path_template(self.config['optimizer_checkpoint_file_path']) + file_extension
-        os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
-        with open(file_path, 'w') as f:
-            f.write(json.dumps(model.optimizer.get_config()))
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(file_path) or ".", exist_ok=True)
+            with open(file_path, 'w') as f:
+                f.write(json.dumps(model.optimizer.get_config()))
         return file_path
 
     def global_confusion_matrix(self) -> np.ndarray:
