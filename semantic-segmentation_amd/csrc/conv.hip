@@ -35,8 +35,13 @@ struct Sizes {
 // VEC: cin % 8 == 0 and 16-byte aligned rows -> each lane loads 4 consecutive channels at once; the k order inside
 // a block of 8 channels is permuted identically for A and B (lane half hh takes channels 4*hh .. 4*hh+3).
 // ---------------------------------------------------------------------------------------------------
+// The second launch bound (workgroups per CU = waves per SIMD) is the occupancy each variant reaches without spilling.
+// Stating it makes the compiler keep the MFMA accumulators in the unified VGPR budget instead of a separate AGPR block:
+// 74 + 16 / 97 + 32 / 152 + 64 registers (5 / 3 / 2 waves per SIMD) became 74 / 97 / 154 (6 / 4 / 3 waves); ENet step
+// 10.19 -> 10.12 ms, 1024x1024 evaluation 5.06 -> 4.93 ms, SegNet step 59.0 -> 58.3 ms.  The strip and tiled
+// weight-gradient kernels measured slower with such bounds (spills, or no gain) and keep the default.
 template <int NT, bool VEC>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const float* __restrict__ x,
+__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const float* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 2 * NT * 32];
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(Geo g, Sizes sz, const fl
 // uniform inside a block.  VEC (cout % 8 == 0): 16-byte loads along co for both dy and the kernel.
 // ---------------------------------------------------------------------------------------------------
 template <int NT, bool VEC>
-__global__ __launch_bounds__(256) void conv_bwd_data_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_bwd_data_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ add,
                                                             const float* __restrict__ bias, float* __restrict__ dx,
@@ -1565,7 +1570,7 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
 // one output row (a fixed) are 2*cin contiguous floats, so a store instruction writes 128 contiguous bytes.
 // ---------------------------------------------------------------------------------------------------
 template <int NT>
-__global__ __launch_bounds__(256) void conv_bwd_data_2x2s2_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
+__global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_bwd_data_2x2s2_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ add,
                                                                   const float* __restrict__ bias, float* __restrict__ dx) {
