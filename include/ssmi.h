@@ -282,6 +282,19 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
                                       int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
                                       int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
                                       int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream);
+/* ssmi_softmax_xent_fwd_bwd for callers that cannot allocate or carry a workspace (code under HIP-graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, results and
+ * arithmetic (bit-identical) as ssmi_softmax_xent_fwd_bwd, but the per-block partial sums of the loss go through a
+ * 16 KiB device array that is part of the library's code object (one copy per GPU, held until the process ends) instead
+ * of `ws`.  The call allocates nothing; the first call on a device looks the array's address up once.  At most
+ * ssmi_softmax_xent_static_max_pixels() pixels (max(npix, npix_metrics)); larger inputs are rejected with
+ * SSMI_E_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that may overlap on one GPU (different
+ * streams) race on it and must be serialised by the caller.  Nothing in the array has to be zero beforehand. */
+int64_t ssmi_softmax_xent_static_max_pixels(void);
+ssmi_status ssmi_softmax_xent_fwd_bwd_static(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                             int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
+                                             int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                             int32_t* bad_labels, void* stream);
 /* Host-side derivations from a confusion matrix (rows = labels): tf.metrics.accuracy / mean_per_class_accuracy /
  * mean_iou as used by src/metrics.py:276-352, and the reference's own numpy definitions
  * (src/scripts/calculate_metrics_from_cfms.py:12-53) which drop ignored classes before averaging.

@@ -3,6 +3,7 @@
 // num_classes is one of the compiled sizes, otherwise re-read from cache.  HBM-bound: reads logits + label + weight,
 // writes dlogits.
 #include "common.h"
+#include <mutex>
 
 namespace ssmi {
 
@@ -481,6 +482,55 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
   hipLaunchKernelGGL(xent_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, loss_out);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same loss pass for callers that cannot allocate (code under HIP-graph capture, tight serving loops): the per-block
+// partial sums live in a file-scope device array instead of a caller-supplied workspace.  Every GPU the library runs on
+// holds its own copy of the array for the life of the process; its address on a device is looked up once, with that
+// device current, and kept.  In host code the array's NAME is only a handle for that lookup, never a device address.
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) double g_xent_scratch[kLossBlocks];      // 16 KiB per GPU
+static constexpr int kMaxDevices = 64;
+static double* g_xent_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_xent_scratch_mu;
+
+// Address of this device's copy of g_xent_scratch (nullptr + error text on failure).  No allocation: the array is part
+// of the code object.
+static double* xent_scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    set_error("softmax_xent_static: cannot identify the current device");
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_xent_scratch_mu);
+  if (g_xent_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_xent_scratch));
+    if (e != hipSuccess || p == nullptr) {
+      set_error("softmax_xent_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      return nullptr;
+    }
+    g_xent_scratch_ptr[dev] = reinterpret_cast<double*>(p);
+  }
+  return g_xent_scratch_ptr[dev];
+}
+
+int64_t ssmi_softmax_xent_static_max_pixels(void) { return (int64_t)1 << 28; }
+
+ssmi_status ssmi_softmax_xent_fwd_bwd_static(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                             int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
+                                             int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                             int32_t* bad_labels, void* stream) {
+  const int64_t span = npix_metrics > npix ? npix_metrics : npix;
+  SSMI_REQUIRE(span <= ssmi_softmax_xent_static_max_pixels(), SSMI_E_UNSUPPORTED,
+               "softmax_xent_static: %lld pixels exceed the maximum of %lld for the allocation-free entry point",
+               (long long)span, (long long)ssmi_softmax_xent_static_max_pixels());
+  double* scratch = xent_scratch_for_current_device();
+  if (scratch == nullptr) return SSMI_E_HIP;
+  // every partial-sum slot the final kernel reads is overwritten by this call's blocks first: nothing to clear
+  return ssmi_softmax_xent_fwd_bwd(logits, labels, weights, npix, num_classes, grad_scale, dlogits, loss_out, cm, npix_metrics,
+                                   ignore_mask, pred_out, bad_labels, scratch, (size_t)kLossBlocks * sizeof(double), stream);
 }
 
 size_t ssmi_mt_consistency_workspace_bytes(int64_t npix) {

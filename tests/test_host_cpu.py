@@ -15,7 +15,7 @@ from oracle import tf_keras_ops as K
 
 def _declared_symbols():
     hdr = open(os.path.join(ROOT, "include", "ssmi.h")).read()
-    return sorted(set(re.findall(r"^(?:ssmi_status|size_t|int32_t|float|const char\*)\s+(ssmi_[a-z0-9_]+)\s*\(", hdr, re.M)))
+    return sorted(set(re.findall(r"^(?:ssmi_status|size_t|int32_t|int64_t|float|const char\*)\s+(ssmi_[a-z0-9_]+)\s*\(", hdr, re.M)))
 
 
 def test_library_exports_every_declared_symbol():

@@ -1,0 +1,63 @@
+"""Allocation-free loss entry point (ssmi_softmax_xent_fwd_bwd_static) against ssmi_softmax_xent_fwd_bwd through the
+C ABI: bit-identical loss, logits gradient, predictions and confusion matrix on two calls in a row, the second with a
+smaller input (the device array keeps the first call's partial sums)."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+_lib = importlib.import_module("semantic-segmentation_amd._lib")
+
+
+def _run_pair(L, npix, ncls, seed, dev, npix_metrics=None):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    logits = (torch.randn(npix_metrics or npix, ncls, generator=g) * 3).to(dev)
+    labels = torch.randint(0, ncls, (npix_metrics or npix,), generator=g, dtype=torch.int32).to(dev)
+    weights = (torch.rand(npix_metrics or npix, generator=g) + 0.25).to(dev)
+    nm = npix_metrics or npix
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for static in (False, True):
+        dl = torch.full((nm, ncls), 7.0, device=dev)
+        loss = torch.zeros(1, device=dev)
+        cm = torch.zeros(ncls, ncls, dtype=torch.int64, device=dev)
+        pred = torch.zeros(nm, dtype=torch.int32, device=dev)
+        bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        args = [logits.data_ptr(), labels.data_ptr(), weights.data_ptr(), npix, ncls, 1.0, dl.data_ptr(), loss.data_ptr(),
+                cm.data_ptr(), nm, 1, pred.data_ptr(), bad.data_ptr()]
+        if static:
+            L.softmax_xent_fwd_bwd_static(*args, st)
+        else:
+            ws = torch.empty(L.softmax_xent_workspace_bytes(npix) // 4 + 16, device=dev)
+            L.softmax_xent_fwd_bwd(*args, ws.data_ptr(), ws.numel() * 4, st)
+        torch.cuda.synchronize()
+        outs.append((loss.cpu(), dl.cpu(), cm.cpu(), pred.cpu(), bad.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert int(outs[0][2].sum()) > 0 and float(outs[0][0]) > 0
+    return float(outs[0][0])
+
+
+def test_static_matches_workspace_entry_point_twice():
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    # first call: 24 classes (the register-resident kernel), more pixels than one round of blocks covers
+    big = _run_pair(L, 3 * 2048 * 256 + 77, 24, 1, dev)
+    # second call, smaller input, fewer blocks than the first call used: stale partial sums must not leak in
+    small = _run_pair(L, 5000, 24, 2, dev)
+    assert big > 0 and small > 0
+    # generic class count, metrics rows beyond the loss rows
+    _run_pair(L, 4096, 7, 3, dev, npix_metrics=6000)
+
+
+def test_static_rejects_oversized_input():
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    t = torch.zeros(64, device=dev)
+    li = torch.zeros(64, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.SsmiError, match="exceed the maximum"):
+        L.softmax_xent_fwd_bwd_static(t.data_ptr(), li.data_ptr(), t.data_ptr(), L.softmax_xent_static_max_pixels() + 1, 24,
+                                      1.0, None, t.data_ptr(), None, 0, 0, None, None, torch.cuda.current_stream().cuda_stream)
