@@ -44,7 +44,10 @@ def synthetic_batch(batch, h, w, nc, seed, device):
 
 def cpu_baseline(seconds_budget=20.0):
     from oracle import enet_oracle as E
-    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    # threads = this job's CPU share: the GPU box exports it as OMP_NUM_THREADS (16 per GPU) while os.cpu_count() reports
+    # the whole machine; without that variable every host core is used
+    host_cores = os.cpu_count() or 1
+    threads = min(host_cores, int(os.environ.get("OMP_NUM_THREADS", str(host_cores))))
     torch.set_num_threads(threads)
     name = "enet-naive-upsampling"
     w = E.init_weights(name, 24, dtype=np.float32)
@@ -63,7 +66,8 @@ def cpu_baseline(seconds_budget=20.0):
         if i >= 2 + 4 and time.time() - t_start > seconds_budget:
             break
     med = float(np.median(times))
-    return {"value": B / med, "unit": "images/s", "cores": threads, "kind": "port",
+    return {"value": B / med, "unit": "images/s", "cores": threads, "cpu_count": host_cores,
+            "torch_threads": torch.get_num_threads(), "kind": "port",
             "sample": "{} timed fwd+bwd+Adam steps (after 2 warm-ups) of enet-naive-upsampling, batch 4 at 512x512, fp32, "
                       "PyTorch-CPU restatement of the Keras/TF graph (TensorFlow unavailable offline); median step {:.3f} s".format(
                           len(times), med)}

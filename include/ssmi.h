@@ -361,6 +361,17 @@ ssmi_status ssmi_sgd_step(float* params, const float* grads, float* moments, int
                           float momentum, float decay, int32_t nesterov, float grad_scale, const float* lr_scale,
                           void* stream);
 
+/* The same updates with the hyper-parameters read from a DEVICE block of 8 floats instead of call arguments, so that a
+ * step captured into a HIP graph follows what the reference's callbacks do to the optimizer between steps
+ * (StepwiseLearningRateScheduler sets lr and beta_2 per step, src/callbacks/stepwise_learning_rate_scheduler.py:50-64;
+ * ReduceLROnPlateau, src/trainers.py:1025-1043): the host rewrites the block, the graph is replayed unchanged.
+ *   Adam: hyper = {lr, beta_1, beta_2, epsilon, decay, grad_scale, unused, unused}
+ *   SGD : hyper = {lr, momentum, decay, nesterov (0 or 1), grad_scale, unused, unused, unused} */
+ssmi_status ssmi_adam_step_hp(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,
+                              int64_t* step, const float* hyper, const float* lr_scale, void* stream);
+ssmi_status ssmi_sgd_step_hp(float* params, const float* grads, float* moments, int64_t count, int64_t* step,
+                             const float* hyper, const float* lr_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------
  * SpatialDropout2D keep/scale table (src/models.py:1151,1267): mask[i] = (u_i >= rate) ? 1/(1-rate) : 0 with
  * u_i from Philox4x32-10 keyed by (seed, *step_counter, stream_id, i).  step_counter is a device int64 (read

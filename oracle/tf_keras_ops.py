@@ -419,3 +419,16 @@ def np_softmax(x: np.ndarray, axis=-1) -> np.ndarray:
     z = x - np.max(x, axis=axis, keepdims=True)
     e = np.exp(z)
     return e / np.sum(e, axis=axis, keepdims=True)
+
+
+def mfb_class_weights(class_probabilities) -> np.ndarray:
+    """src/utils/dataset_utils.py:498-513."""
+    p = np.asarray(class_probabilities, dtype=np.float64)
+    med = np.median(p[p > 0])
+    return np.where(p > 0, med / np.where(p > 0, p, 1.0), 0.0)
+
+
+def enet_class_weights(class_probabilities, c=1.02) -> np.ndarray:
+    """src/utils/dataset_utils.py:515-529."""
+    p = np.asarray(class_probabilities, dtype=np.float64)
+    return np.where(p > 0, 1.0 / np.log(c + p), 0.0)

@@ -96,6 +96,8 @@ _PROTOS = {
     "ssmi_metrics_from_cm": (_i32, [_vp, _i32, _u64, C.POINTER(C.c_double)]),
     "ssmi_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
     "ssmi_sgd_step": (_i32, [_vp, _vp, _vp, _i64, _vp, _f32, _f32, _f32, _i32, _f32, _vp, _vp]),
+    "ssmi_adam_step_hp": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "ssmi_sgd_step_hp": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "ssmi_dropout_mask": (_i32, [_vp, _i64, _f32, _u64, _vp, _u32, _vp]),
     "ssmi_fill_f32": (_i32, [_vp, _f32, _i64, _vp]),
     "ssmi_upsample_nn2x_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

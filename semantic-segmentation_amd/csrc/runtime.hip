@@ -82,6 +82,66 @@ __global__ __launch_bounds__(256) void sgd_apply(float* __restrict__ p, const fl
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same updates with every hyper-parameter read from a small DEVICE block, so that a step captured once into a HIP
+// graph follows later changes of the learning rate / betas / momentum (per-step schedules, reduce-on-plateau): the host
+// rewrites the block between graph launches.  Adam block: {lr, beta_1, beta_2, epsilon, decay, grad_scale, -, -};
+// SGD block: {lr, momentum, decay, nesterov (0 or 1), grad_scale, -, -, -}.
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_prepare_hp(int64_t* step, const float* __restrict__ hp, float* lr_t_out) {
+  const int64_t it = *step;
+  double l = (double)hp[0];
+  if (hp[4] > 0.f) l *= 1.0 / (1.0 + (double)hp[4] * (double)it);
+  const double t = (double)(it + 1);
+  *lr_t_out = (float)(l * (sqrt(1.0 - pow((double)hp[2], t)) / (1.0 - pow((double)hp[1], t))));
+  *step = it + 1;
+}
+
+__global__ __launch_bounds__(256) void adam_apply_hp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                     float* __restrict__ v, float* __restrict__ vhat, int64_t n,
+                                                     const float* __restrict__ lr_t_ptr, const float* __restrict__ hp,
+                                                     const float* __restrict__ lr_scale) {
+  const float lr_t0 = *lr_t_ptr;
+  const float b1 = hp[1], b2 = hp[2], eps = hp[3], gscale = hp[5];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    float den = vi;
+    if (vhat) {
+      den = fmaxf(vhat[i], vi);
+      vhat[i] = den;
+    }
+    const float lr_t = lr_scale ? lr_t0 * lr_scale[i] : lr_t0;
+    p[i] = p[i] - lr_t * mi / (sqrtf(den) + eps);
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+__global__ void sgd_prepare_hp(int64_t* step, const float* __restrict__ hp, float* lr_out) {
+  const int64_t it = *step;
+  double l = (double)hp[0];
+  if (hp[2] > 0.f) l *= 1.0 / (1.0 + (double)hp[2] * (double)it);
+  *lr_out = (float)l;
+  *step = it + 1;
+}
+
+__global__ __launch_bounds__(256) void sgd_apply_hp(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                                                    int64_t n, const float* __restrict__ lr_ptr, const float* __restrict__ hp,
+                                                    const float* __restrict__ lr_scale) {
+  const float lr0 = *lr_ptr;
+  const float momentum = hp[1], gscale = hp[4];
+  const bool nesterov = hp[3] != 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float lr = lr_scale ? lr0 * lr_scale[i] : lr0;
+    const float gi = g[i] * gscale;
+    const float vel = momentum * mom[i] - lr * gi;
+    mom[i] = vel;
+    p[i] = nesterov ? p[i] + momentum * vel - lr * gi : p[i] + vel;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Philox4x32-10 -> SpatialDropout2D keep/scale table
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t (&k)[2]) {
@@ -242,6 +302,34 @@ ssmi_status ssmi_sgd_step(float* params, const float* grads, float* moments, int
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(sgd_apply, dim3((unsigned)nb), dim3(256), 0, st, params, grads, moments, count, lr_eff, momentum, nesterov,
                      grad_scale, lr_scale);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_adam_step_hp(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,
+                              int64_t* step, const float* hyper, const float* lr_scale, void* stream) {
+  SSMI_REQUIRE(params && grads && m && v && step && hyper && count > 0, SSMI_E_INVALID_ARG, "adam_step_hp: bad argument");
+  hipStream_t st = as_stream(stream);
+  float* lr_t = reinterpret_cast<float*>(step + 1);
+  hipLaunchKernelGGL(adam_prepare_hp, dim3(1), dim3(1), 0, st, step, hyper, lr_t);
+  SSMI_LAUNCH_CHECK();
+  int64_t nb = ceil_div64(count, 256 * 4);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(adam_apply_hp, dim3((unsigned)nb), dim3(256), 0, st, params, grads, m, v, vhat, count, lr_t, hyper, lr_scale);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_sgd_step_hp(float* params, const float* grads, float* moments, int64_t count, int64_t* step,
+                             const float* hyper, const float* lr_scale, void* stream) {
+  SSMI_REQUIRE(params && grads && moments && step && hyper && count > 0, SSMI_E_INVALID_ARG, "sgd_step_hp: bad argument");
+  hipStream_t st = as_stream(stream);
+  float* lr_eff = reinterpret_cast<float*>(step + 1);
+  hipLaunchKernelGGL(sgd_prepare_hp, dim3(1), dim3(1), 0, st, step, hyper, lr_eff);
+  SSMI_LAUNCH_CHECK();
+  int64_t nb = ceil_div64(count, 256 * 4);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(sgd_apply_hp, dim3((unsigned)nb), dim3(256), 0, st, params, grads, moments, count, lr_eff, hyper, lr_scale);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }

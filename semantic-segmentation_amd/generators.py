@@ -188,3 +188,16 @@ class PinnedBatchFeeder(object):
         s.consumed.record(main)
         s.consumed_once = True
         self._fed += 1
+
+
+def calculate_mfb_class_weights(class_probabilities):
+    """Median-frequency-balancing class weights (src/utils/dataset_utils.py:498-513): median of the non-zero class
+    probabilities divided by each probability, 0 for classes that never occur."""
+    p = np.array(class_probabilities, dtype=np.float64)
+    med = np.median(p[p > 0.0])
+    return [float(med / v) if v > 0.0 else 0.0 for v in p]
+
+
+def calculate_enet_class_weights(class_probabilities, c=1.02):
+    """ENet class weights (src/utils/dataset_utils.py:515-529): 1 / ln(c + p), 0 for classes that never occur."""
+    return [float(1.0 / np.log(c + v)) if v > 0.0 else 0.0 for v in np.array(class_probabilities)]

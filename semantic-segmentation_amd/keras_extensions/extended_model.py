@@ -71,12 +71,13 @@ class ExtendedModel(object):
         self.metrics_excluded_from_callbacks: List[str] = []
         self._metric_fns: List[Callable] = []
         self.stop_training = False
-        self.seed = 14874
-        self.unbiased_moving_variance = False
+        self._graphs: Dict[tuple, list] = {}
+        self._seed = 14874
+        self._unbiased_moving_variance = False
         self.use_hip_graph = True
         self.grad_sync = None          # trainers.GradientBucketReducer when data-parallel
         self._bufs_shape = None
-        self._graphs: Dict[tuple, list] = {}
+        self._noise_counter = None     # device int64: Philox step of predict_on_batch(use_training_phase_layers=True)
         self._cm = None
         self._ignore_bits = 0
         self._compiled = False
@@ -86,6 +87,47 @@ class ExtendedModel(object):
             lname = key.rsplit("/", 1)[0]
             per_layer.setdefault(lname, []).append(key)
         self.layers = [LayerInfo(n, ks) for n, ks in per_layer.items()]
+
+    # values that are baked into a captured step as kernel arguments: changing them drops the captured graphs
+    @property
+    def seed(self):
+        return self._seed
+
+    @seed.setter
+    def seed(self, v):
+        if int(v) != self._seed:
+            self._clear_graphs()
+        self._seed = int(v)
+
+    @property
+    def unbiased_moving_variance(self):
+        return self._unbiased_moving_variance
+
+    @unbiased_moving_variance.setter
+    def unbiased_moving_variance(self, v):
+        if bool(v) != self._unbiased_moving_variance:
+            self._clear_graphs()
+        self._unbiased_moving_variance = bool(v)
+
+    def _clear_graphs(self):
+        """Drops every captured step, releasing the HIP graph objects."""
+        graphs, self._graphs = self._graphs, {}
+        if not graphs:
+            return
+        L = lib()
+        torch.cuda.synchronize()      # a graph may still be executing
+        for glist in graphs.values():
+            for h in glist:
+                L.graph_destroy(h)
+
+    def close(self):
+        self._clear_graphs()
+
+    def __del__(self):
+        try:
+            self._clear_graphs()
+        except Exception:      # interpreter shutdown: the library or torch may already be gone
+            pass
 
     # ------------------------------------------------------------------------------------------------
     # weights
@@ -198,7 +240,10 @@ class ExtendedModel(object):
         self._metric_fns = fns
         self.metrics_names = ["loss", "loss_loss", "logits_loss"]
         ignore = None
+        nus = set()
         for fn in fns:
+            nu_fn = getattr(fn, "num_unlabeled", 0)
+            nus.add(int(nu_fn.reshape(-1)[0]) if torch.is_tensor(nu_fn) else int(nu_fn or 0))
             nm = "logits_" + fn.__name__
             self.metrics_names.append(nm)
             if getattr(fn, "streaming", False):
@@ -213,6 +258,11 @@ class ExtendedModel(object):
             if ignore is not None and ic != ignore:
                 raise NotImplementedError("all metrics must share the same ignore_classes")
             ignore = ic
+        if len(nus) > 1:
+            raise NotImplementedError("all metrics must share the same num_unlabeled")
+        # src/metrics.py:255-259: in the training phase the metrics see the first batch - num_unlabeled rows only, in the
+        # test phase every row
+        self._metrics_num_unlabeled = nus.pop() if nus else 0
         self._ignore_classes = list(ignore or [])
         self._ignore_bits = metrics_mod.ignore_mask_bits(self._ignore_classes)
         dev = self.graph.device
@@ -220,7 +270,7 @@ class ExtendedModel(object):
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
         self._bad = torch.zeros(1, dtype=torch.int32, device=dev)
         self._compiled = True
-        self._graphs.clear()
+        self._clear_graphs()
 
     @property
     def using_cfm_metric(self):
@@ -265,7 +315,7 @@ class ExtendedModel(object):
         self._num_labeled = n
         self.graph.plan(n, h, w)
         self._bufs_shape = (n, h, w)
-        self._graphs.clear()
+        self._clear_graphs()
 
     @staticmethod
     def _to_dev(dst: torch.Tensor, src):
@@ -305,7 +355,7 @@ class ExtendedModel(object):
                         need = lib().superpixel_workspace_bytes(nu * h * w, self.num_classes)
                         if self._sp_ws is None or self._sp_ws.numel() * 4 < need:
                             self._sp_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.graph.device)
-                            self._graphs.clear()
+                            self._clear_graphs()
                 if nu:
                     # the metrics see zero labels on the unlabeled rows (src/generators.py:1764-1766)
                     self.labels_buf[n - nu:].zero_()
@@ -326,6 +376,10 @@ class ExtendedModel(object):
         n, h, w = self._bufs_shape
         npix = n * h * w
         C_ = self.num_classes
+        nu_m = getattr(self, "_metrics_num_unlabeled", 0)
+        if training and not 0 <= nu_m < n:
+            raise ValueError("metrics were built for {} unlabeled rows per batch, the batch has {} rows".format(nu_m, n))
+        npix_m = (n - nu_m) * h * w if training else npix      # rows the confusion matrix covers
 
         def loss_call_semi(st, want_grad):
             # classification cost over the labeled rows, metrics over every row (src/losses.py:416-422), then the
@@ -335,7 +389,7 @@ class ExtendedModel(object):
             npl = nl * h * w
             dl = _ptr(g.dlogits) if want_grad else None
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npl, C_, 1.0, dl,
-                                   _ptr(self._loss_buf), _ptr(self._cm), npix, self._ignore_bits, None, _ptr(self._bad),
+                                   _ptr(self._loss_buf), _ptr(self._cm), npix_m, self._ignore_bits, None, _ptr(self._bad),
                                    _ptr(g.ws), g.ws.numel() * 4, st)
             if self.mean_teacher:
                 L.mt_consistency_fwd_bwd(_ptr(g.logits), _ptr(self.mt_buf), npix, C_, _ptr(self.coef_buf), 1.0, npl, dl,
@@ -358,7 +412,7 @@ class ExtendedModel(object):
             if self.mean_teacher or self.superpixel:
                 return loss_call_semi(st, want_grad)
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npix, C_, 1.0,
-                                   _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), _ptr(self._cm), npix,
+                                   _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), _ptr(self._cm), npix_m,
                                    self._ignore_bits, None, _ptr(self._bad), _ptr(g.ws), g.ws.numel() * 4, st)
 
         if not training:
@@ -392,8 +446,8 @@ class ExtendedModel(object):
             g._cfg.join()
 
         def seg_c(st):
-            scale = 1.0 / self.grad_sync.world_size if self.grad_sync is not None else 1.0
-            self.optimizer.apply(grad_scale=scale, stream=st)
+            # the hyper-parameter block is flushed by _run before the launch (a copy cannot be part of a captured graph)
+            self.optimizer.apply(grad_scale=self._grad_scale(), stream=st, capturing=True)
 
         if self.grad_sync is None:
             # no collective between the segments: one graph for the whole step (also lets the weight gradients of the late
@@ -421,10 +475,15 @@ class ExtendedModel(object):
         cut = st.specs[first_key].offset
         return [(cut, st.theta.numel()), (0, cut)]
 
+    def _grad_scale(self) -> float:
+        return 1.0 / self.grad_sync.world_size if self.grad_sync is not None else 1.0
+
     def _run(self, training: bool):
         key = (training, self._bufs_shape, self.grad_sync is not None, self._num_labeled)
         stream = torch.cuda.current_stream()
         st = stream.cuda_stream
+        if training:
+            self.optimizer.flush_hyper(self._grad_scale())
         segs = self._segments(training)
         hooks = self._hooks(training)
         if not self.use_hip_graph or st == 0:
@@ -513,10 +572,18 @@ class ExtendedModel(object):
         self._to_dev(self.images_buf, images)
         st = torch.cuda.current_stream().cuda_stream
         if use_training_phase_layers and self.graph.drop_groups:
-            blk = self.optimizer.step_block if self.optimizer is not None else None
-            self.graph.refresh_dropout(self.seed + 1, blk, stream=st)
+            self._refresh_prediction_noise(st)
         self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
         return self.graph.logits.detach().cpu().numpy()
+
+    def _refresh_prediction_noise(self, st):
+        """Fresh SpatialDropout2D tables for a training-phase prediction: the Philox step is a device counter of this
+        model's own that advances with every such call (the reference's teacher draws new noise for every prediction,
+        src/trainers.py:1620-1664; the optimizer's step counter would stand still for a model that is never stepped)."""
+        if self._noise_counter is None:
+            self._noise_counter = torch.zeros(2, dtype=torch.int64, device=self.graph.device)
+        self.graph.refresh_dropout(self.seed + 1, self._noise_counter, stream=st)
+        self._noise_counter[0] += 1
 
     def predict_on_batch_device(self, x, use_training_phase_layers=False) -> torch.Tensor:
         """predict_on_batch without the host round trip: returns the graph's logits buffer (device, [n, h, w, classes]),
@@ -527,8 +594,7 @@ class ExtendedModel(object):
         self._to_dev(self.images_buf, images)
         st = torch.cuda.current_stream().cuda_stream
         if use_training_phase_layers and self.graph.drop_groups:
-            blk = self.optimizer.step_block if self.optimizer is not None else None
-            self.graph.refresh_dropout(self.seed + 1, blk, stream=st)
+            self._refresh_prediction_noise(st)
         self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
         return self.graph.logits
 
@@ -564,31 +630,42 @@ class ExtendedModel(object):
     # ------------------------------------------------------------------------------------------------
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, validation_data=None,
                       validation_steps=None, initial_epoch=0, trainer=None, random_seed=None, **kwargs):
+        from ..callbacks import CallbackList
+        cbs = CallbackList(callbacks, self)      # Keras callback protocol (extended_model.py:933-1093 drives the same hooks)
         history = []
         step_index = initial_epoch * steps_per_epoch
         get = generator.__next__ if hasattr(generator, "__next__") else None
+        self.stop_training = False
+        cbs.on_train_begin()
         for epoch in range(initial_epoch, epochs):
             self.reset_metrics()
+            cbs.on_epoch_begin(epoch)
             logs = {}
             for b in range(steps_per_epoch):
                 batch = get() if get else generator.get_batch(epoch, b)
                 x, y = batch[0], batch[1]
+                cbs.on_batch_begin(b, {"batch": b, "size": int(x[0].shape[0])})
                 if trainer is not None:
                     x, y = trainer.modify_batch_data(step_index, x, y, validation=False)
                 outs = self.train_on_batch(x, y)
+                logs = dict(zip(self.metrics_names, outs))
+                cbs.on_batch_end(b, {k: v for k, v in logs.items() if k not in self.metrics_excluded_from_callbacks})
                 if trainer is not None:
                     trainer.on_batch_end(step_index)
                 step_index += 1
-                logs = dict(zip(self.metrics_names, outs))
             if validation_data is not None:
                 val = self.evaluate_generator(validation_data, validation_steps, trainer=trainer, validation=True)
                 logs.update({"val_" + k: v for k, v in zip(self.metrics_names, val)})
             history.append(logs)
+            excluded = set(self.metrics_excluded_from_callbacks)
+            cb_logs = {k: v for k, v in logs.items() if k not in excluded and (k[4:] if k.startswith("val_") else k) not in excluded}
+            cbs.on_epoch_end(epoch, cb_logs)
             self.reset_metrics()
             if trainer is not None:
                 trainer.on_epoch_end(epoch, step_index, logs)
             if self.stop_training:
                 break
+        cbs.on_train_end()
         if trainer is not None:
             trainer.on_training_end()
         return history

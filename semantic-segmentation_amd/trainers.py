@@ -161,7 +161,7 @@ class SegmentationTrainer(object):
         self.device = device or ("cuda:{}".format(self.local_rank))
         self.num_classes = num_classes
         self.random_seed = int(config.get("random_seed", 14874))
-        self.ignore_classes = list(config.get("ignore_classes", [0]))
+        self.ignore_classes = list(config.get("ignore_classes") or [])      # src/trainers.py:725-736: absent = none ignored
         self.num_epochs = int(config.get("num_epochs", 1))
         self.num_labeled_per_batch = int(config.get("num_labeled_per_batch", 16))
         self.num_unlabeled_per_batch = int(config.get("num_unlabeled_per_batch", 0)) if trainer_type.startswith("segmentation_semi") else 0
@@ -193,7 +193,7 @@ class SegmentationTrainer(object):
             opt = xo.SGD(lr=oc.get("learning_rate", 0.01), momentum=oc.get("momentum", 0.0), decay=oc.get("decay", 0.0))
         else:
             raise ValueError("Unsupported optimizer name: {}".format(name))
-        nu = 0
+        nu = self.num_unlabeled_per_batch      # src/trainers.py:2445-2448: the training metrics skip the unlabeled rows
         ic = self.ignore_classes
         self.model.compile(optimizer=opt, loss={'loss': losses.dummy_loss, 'logits': lambda _, y_pred: 0.0 * y_pred},
                            loss_weights={'loss': 1.0, 'logits': 0.0},
@@ -243,17 +243,10 @@ class SegmentationTrainer(object):
     @staticmethod
     def _schedule(spec):
         """The reference's configs give the schedules as Python lambda source ("lambda x: 0.99 if x < 40000 else
-        0.999", src/trainers.py:1568-1583 evaluates them); callables and plain numbers are accepted too.  The source is
-        evaluated with numpy and a few arithmetic builtins only."""
-        if callable(spec):
-            return spec
-        if isinstance(spec, (int, float)):
-            return lambda step, v=float(spec): v
-        env = {"__builtins__": {}, "np": np, "min": min, "max": max, "float": float, "int": int, "abs": abs, "pow": pow}
-        fn = eval(spec, env)     # noqa: S307 - configuration supplied by the user running the training
-        if not callable(fn):
-            raise ValueError("schedule '{}' does not evaluate to a function".format(spec))
-        return fn
+        0.999", src/trainers.py:1568-1583 evaluates them with eval); callables and plain numbers are accepted too.  The
+        source is parsed and interpreted over a closed arithmetic vocabulary (schedules.parse_schedule), never eval'd."""
+        from .schedules import parse_schedule
+        return parse_schedule(spec)
 
     @property
     def ema_smoothing_coefficient_function(self):
@@ -340,7 +333,61 @@ class SegmentationTrainer(object):
         self.teacher_model.save(file_path, overwrite=True, include_optimizer=True)
 
     def on_epoch_end(self, epoch_index, step_index, logs):
-        pass
+        """src/trainers.py:1709-1768: the mean-teacher trainer saves the teacher beside the student every epoch."""
+        tpl = (self.mean_teacher_method_config or {}).get('teacher_model_checkpoint_file_path')
+        if self.using_mean_teacher_method and tpl and self.teacher_model is not None:
+            val_loss = float(logs.get('val_loss', 0.0)) if logs else 0.0
+            self.save_teacher_model_weights(self._populate_path_template(tpl, epoch=epoch_index, val_loss=val_loss))
+
+    def _get_training_callbacks(self, initial_step=0):
+        """The callbacks src/trainers.py:934-1068 builds from the configuration: model checkpoint (mandatory key
+        'keras_model_checkpoint'), CSV log, early stopping, reduce-LR-on-plateau, stepwise LR scheduler, optimizer
+        checkpoint.  TensorBoard is not available here.  Files are written by rank 0 only."""
+        from . import callbacks as cb
+        cfg = self.config
+        writer = self.rank == 0
+        out = []
+        mc = cfg.get('keras_model_checkpoint')
+        if not mc:
+            raise ValueError('Could not find Keras ModelCheckpoint configuration with key keras_model_checkpoint - would be '
+                             'unable to save model weights')
+        out.append(cb.ModelCheckpoint(filepath=self._populate_path_template_partial(mc.get('checkpoint_file_path')),
+                                      monitor=mc.get('monitor') or 'val_loss', verbose=mc.get('verbose') or 0,
+                                      save_best_only=mc.get('save_best_only') or False,
+                                      save_weights_only=mc.get('save_weights_only') or False, mode=mc.get('mode') or 'auto',
+                                      period=mc.get('period') or 1, enabled=writer))
+        csv_path = cfg.get('keras_csv_log_file_path')
+        if csv_path is not None:
+            csv_path = self._populate_path_template(csv_path)
+            if os.path.exists(csv_path):      # never overwrite an earlier run's log
+                import datetime
+                csv_path = '{}-{:%Y-%m-%d-%H:%M}'.format(csv_path, datetime.datetime.now())
+            out.append(cb.CSVLogger(csv_path, separator=',', append=False, enabled=writer))
+        es = cfg.get('early_stopping')
+        if es is not None:
+            out.append(cb.EarlyStopping(monitor=es.get('monitor') or 'val_loss', min_delta=es.get('min_delta') or 0.0,
+                                        patience=es.get('patience') or 2, verbose=es.get('verbose') or 0,
+                                        mode=es.get('mode') or 'auto'))
+        rl = cfg.get('reduce_lr_on_plateau')
+        if rl is not None:
+            out.append(cb.ReduceLROnPlateau(monitor=rl.get('monitor') or 'val_loss', factor=rl.get('factor') or 0.1,
+                                            patience=rl.get('patience') or 10, min_lr=rl.get('min_lr') or 0,
+                                            epsilon=rl.get('epsilon') or 0.0001, cooldown=rl.get('cooldown') or 0,
+                                            verbose=rl.get('verbose') or 0))
+        sw = cfg.get('stepwise_learning_rate_scheduler')
+        if sw is not None:      # after reduce-on-plateau, so it overrides that callback's changes when both are present
+            out.append(cb.StepwiseLearningRateScheduler(
+                lr_schedule=self._schedule(sw.get('lr_schedule')) if sw.get('lr_schedule') is not None else None,
+                b2_schedule=self._schedule(sw.get('b2_schedule')) if sw.get('b2_schedule') is not None else None,
+                last_scheduled_step=sw.get('last_scheduled_step'), initial_step=initial_step, verbose=sw.get('verbose')))
+        oc = cfg.get('optimizer_checkpoint_file_path')
+        if oc is not None:
+            out.append(cb.OptimizerCheckpoint(self._populate_path_template(oc), enabled=writer))
+        return out
+
+    def _populate_path_template_partial(self, path):
+        """Fills {model_folder} and leaves the per-epoch fields ({epoch:02d}, {val_loss:.2f}) for the checkpoint callback."""
+        return path.replace("{model_folder}", str(self.model_folder_name))
 
     def on_training_end(self):
         pass
@@ -350,6 +397,8 @@ class SegmentationTrainer(object):
     # ------------------------------------------------------------------------------------------------
     def _populate_path_template(self, path, *args, **kwargs):
         """src/trainers.py:1136-1139: fills {model_folder} and any further fields the caller names (epoch, val_loss)."""
+        kwargs.setdefault("log_folder_path", str(self.config.get("log_folder_path", "logs/{model_folder}")).replace(
+            "{model_folder}", str(self.model_folder_name)))
         return path.format(model_folder=self.model_folder_name, *args, **kwargs)
 
     @staticmethod
@@ -436,5 +485,24 @@ class SegmentationTrainer(object):
         return out
 
     def train(self, generator, steps_per_epoch, validation_data=None, validation_steps=None):
-        return self.model.fit_generator(generator, steps_per_epoch, epochs=self.num_epochs, validation_data=validation_data,
-                                        validation_steps=validation_steps, trainer=self, random_seed=self.random_seed)
+        """src/trainers.py:2334-2376.  With 'keras_model_checkpoint' in the configuration the run resumes from the newest
+        checkpoint of that folder ('continue_from_last_checkpoint', default on; weights, optimizer slots and iteration
+        counter) and writes a checkpoint per epoch through the reference's callbacks; without the key (programmatic
+        use, benchmarks) no callbacks run."""
+        callbacks, initial_epoch = [], 0
+        mc = self.config.get('keras_model_checkpoint')
+        if mc:
+            if self.config.get('continue_from_last_checkpoint', True):
+                folder = os.path.dirname(self._populate_path_template_partial(mc.get('checkpoint_file_path')))
+                path = self._get_latest_weights_file_path(folder) if os.path.isdir(folder) else None
+                initial_epoch = self._load_latest_weights_for_model(self.model, folder) if path else 0
+                if initial_epoch and self.config.get('continue_from_optimizer_checkpoint', True):
+                    self.model_wrapper.load_optimizer_weights(path)
+                if initial_epoch and self.reducer is not None:      # every rank continues from rank 0's state
+                    st = self.model.graph.store
+                    self.reducer.broadcast_([st.theta, st.state], src=0)
+            callbacks = self._get_training_callbacks(initial_step=initial_epoch * steps_per_epoch)
+        self.initial_epoch = initial_epoch
+        return self.model.fit_generator(generator, steps_per_epoch, epochs=self.num_epochs, callbacks=callbacks,
+                                        validation_data=validation_data, validation_steps=validation_steps,
+                                        initial_epoch=initial_epoch, trainer=self, random_seed=self.random_seed)

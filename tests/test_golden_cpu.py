@@ -1,6 +1,12 @@
-"""The committed golden vectors (tests/golden/*.npz, written by tests/golden/make_golden.py) against the CPU oracle:
-guards the oracle against drift.  The fixtures are oracle outputs, not reference outputs (the reference ships no
-vectors for this path and cannot run offline): parity unpinned."""
+"""The committed golden vectors against the CPU oracle.
+
+tests/golden/ops.npz and step_*.npz (written by tests/golden/make_golden.py) are oracle outputs, not reference outputs (the
+reference ships no vectors for this path and TensorFlow / Keras cannot run offline): they guard the oracle against drift
+and leave its conv / BN / pooling / loss arithmetic parity-unpinned.
+
+tests/golden/ref_metrics.npz (written by tests/golden/make_reference_metric_vectors.py) holds outputs of the REFERENCE's
+own pure-numpy functions run in the build container: accuracy / MPCA / mIoU from a confusion matrix, its softmax and its
+class-weight formulas.  Those pin the oracle's and the library's metric derivations to the reference itself."""
 import importlib.util
 import os
 
@@ -88,3 +94,42 @@ def test_step_fixture_matches_oracle(model):
     for k in g.files:
         if k.startswith("grad/"):
             np.testing.assert_allclose(r["grads"][k[5:]], g[k], rtol=1e-7, atol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# pinned by the reference's own numpy code (tests/golden/ref_metrics.npz)
+# ------------------------------------------------------------------------------------------------
+
+def test_oracle_metric_derivations_match_the_reference_functions():
+    g = np.load(os.path.join(GOLD, "ref_metrics.npz"))
+    for i, cm in enumerate(g["cm"]):
+        assert K.cfm_accuracy(cm) == g["accuracy"][i]
+        assert abs(K.cfm_mpca(cm, [0]) - g["mpca_ignore0"][i]) <= 1e-15
+        assert abs(K.cfm_miou(cm, [0]) - g["miou_ignore0"][i]) <= 1e-15
+        assert abs(K.cfm_mpca(cm, []) - g["mpca_all"][i]) <= 1e-15
+        assert abs(K.cfm_miou(cm, []) - g["miou_all"][i]) <= 1e-15
+    assert np.array_equal(K.np_softmax(g["softmax_in"], axis=-1), g["softmax_out"])
+    np.testing.assert_allclose(K.mfb_class_weights(g["class_probabilities"]), g["mfb_class_weights"], rtol=0, atol=0)
+    np.testing.assert_allclose(K.enet_class_weights(g["class_probabilities"]), g["enet_class_weights"], rtol=0, atol=0)
+
+
+def test_library_metric_derivations_match_the_reference_functions():
+    """ssmi_metrics_from_cm (host code of libssmi.so, no GPU involved) and the package's numpy helpers against the
+    reference functions' outputs."""
+    import importlib
+    metrics = importlib.import_module("semantic-segmentation_amd.metrics")
+    predict = importlib.import_module("semantic-segmentation_amd.predict")
+    gens = importlib.import_module("semantic-segmentation_amd.generators")
+    g = np.load(os.path.join(GOLD, "ref_metrics.npz"))
+    for i, cm in enumerate(g["cm"]):
+        m = metrics.metrics_from_confusion_matrix(cm, [0])
+        assert abs(m["accuracy"] - g["accuracy"][i]) <= 1e-15
+        assert abs(m["script_mpca"] - g["mpca_ignore0"][i]) <= 1e-14
+        assert abs(m["script_miou"] - g["miou_ignore0"][i]) <= 1e-14
+        m = metrics.metrics_from_confusion_matrix(cm, [])
+        assert abs(m["script_mpca"] - g["mpca_all"][i]) <= 1e-14
+        assert abs(m["script_miou"] - g["miou_all"][i]) <= 1e-14
+    assert np.array_equal(predict.np_softmax(g["softmax_in"], axis=-1), g["softmax_out"])
+    assert np.array_equal(predict.np_softmax(g["softmax_in"].astype(np.float64), theta=0.5, axis=-1), g["softmax_theta_out"])
+    assert np.array_equal(np.array(gens.calculate_mfb_class_weights(g["class_probabilities"])), g["mfb_class_weights"])
+    assert np.array_equal(np.array(gens.calculate_enet_class_weights(g["class_probabilities"])), g["enet_class_weights"])
