@@ -237,9 +237,12 @@ def make_dropout_masks(model_name: str, batch: int, seed: int, dtype=np.float64)
 # --------------------------------------------------------------------------------------
 
 class _Ctx:
-    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect):
+    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect, forced=None):
         self.p = params
         self.training = training
+        # forced: {PReLU layer name: sign tensor (+1 / -1 / 0)} and {"<block>_other_pool2d/argmax": int64 indices}: branches
+        # replayed from another evaluation instead of decided by this one's values
+        self.forced = forced or {}
         self.drop = drop_masks or {}
         self.bn_stats: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.acts: Dict[str, torch.Tensor] = {} if collect else None
@@ -265,6 +268,8 @@ class _Ctx:
         return self.keep(name, y)
 
     def prelu(self, name, x):
+        if name in self.forced:
+            return self.keep(name, K.prelu_forced(x, self.p[name + "/alpha"].reshape(-1), self.forced[name]))
         return self.keep(name, K.prelu(x, self.p[name + "/alpha"].reshape(-1)))
 
     def sdrop(self, name, x):
@@ -289,7 +294,12 @@ def _enc_bottleneck(c: _Ctx, x, cout, p, downsample=False, asymmetric=0, dilated
     e = c.sdrop(p + "_sdrop2d_1", c.bn(p + "_bnorm_3", e))
     other, idx = x, None
     if downsample:
-        if want_idx:
+        fkey = p + "_other_pool2d/argmax"
+        if fkey in c.forced:
+            idx = c.forced[fkey]
+            other = K.max_pool_forced(other, idx)
+            c.keep(fkey, idx)
+        elif want_idx:
             other, idx = K.max_pool_with_argmax(other)
             c.keep(p + "_other_pool2d/argmax", idx)
         else:
@@ -329,7 +339,7 @@ def classifier_head(c, x):
 
 
 def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch.Tensor, training: bool = True,
-                 drop_masks=None, collect: bool = False):
+                 drop_masks=None, collect: bool = False, forced=None):
     """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
     ctx.acts the named intermediate tensors when collect=True."""
     model_name, encoder_only = split_name(model_name)
@@ -340,7 +350,7 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
                "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)
     if variant is None:
         raise ValueError("Unknown model name: {}".format(model_name))
-    c = _Ctx(params, training, drop_masks, collect)
+    c = _Ctx(params, training, drop_masks, collect, forced)
     idx_stack = []
     conv = c.conv("initial_block_conv2d", images, stride=2)
     if variant in ("naive", "enhanced"):
@@ -395,7 +405,8 @@ def trainable_keys(model_name: str, num_classes: int) -> List[str]:
 def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images: np.ndarray, labels: np.ndarray,
                pixel_weights: np.ndarray, drop_masks=None, dtype=torch.float64, collect=False,
                adam: Optional[dict] = None, adam_state: Optional[dict] = None, ignore_classes=(0,),
-               mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None, classification: bool = False):
+               mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None, classification: bool = False,
+               forced: Optional[dict] = None):
     """One supervised training step exactly as the reference assembles it
     (src/trainers.py:2436-2440: total = 1*loss + 0*mean(0*logits)):
     forward (training phase) -> weighted CE -> gradients -> BN moving-average updates -> optional Adam.
@@ -410,7 +421,10 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
         params[k].requires_grad_(True)
     x = torch.tensor(images, dtype=dtype)
     masks = {k: torch.tensor(v, dtype=dtype) for k, v in (drop_masks or {}).items()}
-    logits, ctx = enet_forward(model_name, params, x, True, masks, collect)
+    fz = None
+    if forced:
+        fz = {k: torch.as_tensor(np.asarray(v)).to(torch.int64 if k.endswith("/argmax") else dtype) for k, v in forced.items()}
+    logits, ctx = enet_forward(model_name, params, x, True, masks, collect, fz)
     if classification:      # labels / pixel_weights are [B, classes] float arrays (src/losses.py:636-652)
         lab = torch.tensor(labels, dtype=dtype)
         w = torch.tensor(pixel_weights, dtype=dtype)

@@ -117,6 +117,21 @@ def prelu(x, alpha):
     return torch.relu(x) - alpha * torch.relu(-x)
 
 
+def prelu_forced(x, alpha, sign):
+    """PReLU with the branch of every element given instead of decided by x: sign = +1 takes x, -1 takes alpha * x, 0 the
+    kink (output and gradient 0).  Used by parity tests that replay the branches another evaluation took, so that two
+    correct evaluations of a piecewise-linear network compare like evaluations of a smooth one."""
+    pos = (sign > 0).to(x.dtype)
+    neg = (sign < 0).to(x.dtype)
+    return x * (pos + alpha * neg)
+
+
+def max_pool_forced(x, idx):
+    """2x2 pooling with the selection given (per-image flat NHWC indices as max_pool_with_argmax returns them)."""
+    B = x.shape[0]
+    return torch.gather(x.reshape(B, -1), 1, idx.reshape(B, -1)).reshape(idx.shape)
+
+
 def leaky_relu(x, slope=0.1):
     return torch.relu(x) - slope * torch.relu(-x)
 

@@ -6,8 +6,9 @@ where the CPU oracle would take minutes per step.  All of them are exact (bit fo
   * linearity in the pixel weights: doubling every weight doubles the loss and every gradient exactly (a power-of-two
     scale commutes with every rounding in the backward pass) and leaves the BN statistics and the matrix untouched;
   * the confusion matrix accounts for every pixel whose label is not ignored, rows of ignored labels stay empty;
-  * pooling indices (src/layers/pooling.py:34-50) lie inside their 2x2 window, address the maximum, and unpooling
-    puts the pooled value back at exactly that position;
+  * pooling indices (src/layers/pooling.py:34-50) equal the first maximum of their 2x2 window in scan order (recomputed with
+    torch on the device from the block's own input), address the pooled value, and unpooling (both entry points) puts
+    every pooled value back at exactly that position with zeros elsewhere;
   * inference is independent of the batch composition: an image predicted inside a batch of 4 and alone gives identical logits.
 """
 import numpy as np
@@ -91,19 +92,39 @@ def test_full_size_training_step_properties(name, B):
     assert cm.dtype == np.int64 and int(cm.sum()) == int((labels != 0).sum()) and int(cm[0].sum()) == 0
     assert np.array_equal(cm.sum(axis=1), np.bincount(labels.reshape(-1), minlength=NC) * (np.arange(NC) != 0))
     if name == "enet-max-unpooling":
+        L = pkg("_lib").lib()
         g = m.graph
-        blk = g.by_name["en_bn_1.0"]
-        idx = blk.idx.long()                     # [B, H/4, W/4, C] flat (y*W + x)*C + c into the block's input
-        n, h2, w2, c = idx.shape
-        hin, win = 2 * h2, 2 * w2
-        ch = idx % c
-        xx_ = (idx // c) % win
-        yy_ = idx // (c * win)
-        ar_c = torch.arange(c, device="cuda").view(1, 1, 1, c)
-        ar_y = torch.arange(h2, device="cuda").view(1, h2, 1, 1)
-        ar_x = torch.arange(w2, device="cuda").view(1, 1, w2, 1)
-        assert bool((ch == ar_c).all()) and bool(((yy_ >> 1) == ar_y).all()) and bool(((xx_ >> 1) == ar_x).all())
-        assert int(idx.max()) < hin * win * c and int(idx.min()) >= 0
+        for bname in ("en_bn_1.0", "en_bn_2.0"):
+            blk = g.by_name[bname]
+            xin, pooled = blk.x, blk.pooled          # [B, 2h, 2w, C] block input, [B, h, w, C] pooled skip branch
+            idx = blk.idx.long()                     # per-image flat (y*W + x)*C + c into the block's input
+            n, h2, w2, c = idx.shape
+            hin, win = 2 * h2, 2 * w2
+            assert tuple(xin.shape) == (n, hin, win, c) and int(idx.max()) < hin * win * c and int(idx.min()) >= 0
+            # the index addresses the pooled value ...
+            assert torch.equal(torch.gather(xin.reshape(n, -1), 1, idx.reshape(n, -1)).reshape(idx.shape), pooled)
+            # ... which is the window's maximum, and no earlier window element (scan order h then w) equals it
+            c0, c1, c2, c3 = xin[:, 0::2, 0::2], xin[:, 0::2, 1::2], xin[:, 1::2, 0::2], xin[:, 1::2, 1::2]
+            mx = torch.maximum(torch.maximum(c0, c1), torch.maximum(c2, c3))
+            assert torch.equal(mx, pooled)
+            k = torch.where(c0 == mx, 0, torch.where(c1 == mx, 1, torch.where(c2 == mx, 2, 3)))
+            ar_c = torch.arange(c, device="cuda").view(1, 1, 1, c)
+            ar_y = torch.arange(h2, device="cuda").view(1, h2, 1, 1)
+            ar_x = torch.arange(w2, device="cuda").view(1, 1, w2, 1)
+            expect = ((2 * ar_y + k // 2) * win + 2 * ar_x + k % 2) * c + ar_c
+            assert torch.equal(idx, expect), "argmax indices of {} are not the first maximum of their window".format(bname)
+            # unpooling puts every pooled value back at exactly that position and zeros everywhere else
+            up = torch.full((n, hin, win, c), 7.0, device="cuda")
+            L.maxunpool_local_fwd(pooled.data_ptr(), blk.idx.data_ptr(), n, h2, w2, c, up.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+            up2 = torch.full((n, hin, win, c), 7.0, device="cuda")
+            L.maxunpool_fwd(pooled.data_ptr(), blk.idx.data_ptr(), n, h2, w2, c, up2.data_ptr(),
+                            torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(up, up2)
+            assert torch.equal(torch.gather(up.reshape(n, -1), 1, idx.reshape(n, -1)).reshape(idx.shape), pooled)
+            assert int((up != 0).sum()) == int((pooled != 0).sum())
+            del up, up2
 
 
 def test_full_size_inference_is_batch_independent():
