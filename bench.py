@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: inference-phase forward + loss + confusion matrix (e.g. --size 1024 --batch 10), the matrices "
                          "of all ranks summed at the end")
+    ap.add_argument("--dtype", default=None, choices=["f32", "bf16", "both"],
+                    help="bf16 / both: also time the step with bfloat16 activation storage and report it in the \"bf16\" field "
+                         "(value / dtype stay the float32 measurement).  Default: both on one GPU, f32 on several")
     ap.add_argument("--no-overlap-wgrad", action="store_true", help="keep the weight gradients on the main stream")
     ap.add_argument("--eager", action="store_true", help="launch kernels directly instead of replaying HIP graphs")
     ap.add_argument("--host-inputs", nargs="?", const="f32", default=None, choices=["f32", "u8"],
@@ -118,60 +121,67 @@ def main():
         if world > 1 or os.environ.get("SSMI_BENCH_VERBOSE"):
             print("[bench rank {} +{:.1f}s] {}".format(rank, time.time() - t_begin, msg), file=sys.stderr, flush=True)
     note("trainer ready on {}".format(dev))
-    model = tr.model
     images, labels, weights = synthetic_batch(args.batch, args.size, args.size, 24, 14874 + rank, dev)
     nu = np.zeros((args.batch, 1), dtype=np.int32)
     stream = torch.cuda.Stream(device=dev)
-    if args.eager:
-        model.use_hip_graph = False
-    if args.no_overlap_wgrad:
-        model.graph.overlap_weight_gradients = False
-    with torch.cuda.stream(stream):
-        model.set_batch([images, labels, weights, nu])
-        step = model.train_step_async if args.mode == "train" else model.eval_step_async
-        for i in range(max(args.warmup, 1)):
-            step()
-            if i == 0:
-                stream.synchronize()
-                note("first step done")
-        stream.synchronize()
-        note("warm-up done")
-        model.reset_metrics()
+
+    def timed_run(tr, tag):
+        """W untimed steps, then exactly K timed ones between barrier + synchronize on both sides; max over ranks."""
+        model = tr.model
+        if args.eager:
+            model.use_hip_graph = False
+        if args.no_overlap_wgrad:
+            model.graph.overlap_weight_gradients = False
+        ev = None
+        with torch.cuda.stream(stream):
+            model.set_batch([images, labels, weights, nu])
+            step = model.train_step_async if args.mode == "train" else model.eval_step_async
+            for i in range(max(args.warmup, 1)):
+                step()
+                if i == 0:
+                    stream.synchronize()
+                    note("{}: first step done".format(tag))
+            stream.synchronize()
+            note("{}: warm-up done".format(tag))
+            model.reset_metrics()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            host = feeder = None
+            if args.host_inputs == "f32":
+                host = [t.cpu().numpy() for t in (images, labels, weights)] + [nu]
+            elif args.host_inputs == "u8":
+                gen = pkg("generators")
+                hrng = np.random.RandomState(4242 + rank)
+                u8_images = hrng.randint(0, 256, size=(args.batch, args.size, args.size, 3)).astype(np.uint8)
+                u8_masks = hrng.randint(0, 24, size=(args.batch, args.size, args.size)).astype(np.uint8)
+                enc = gen.DeviceBatchEncoder({c: c for c in range(24)}, [0.0] + [1.0] * 23, [0.48, 0.45, 0.40], [0.23, 0.22, 0.23],
+                                             device=dev)
+                feeder = gen.PinnedBatchFeeder(enc, args.batch, args.size, args.size)
+                feeder.submit(u8_images, u8_masks)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if host is not None:
+                    model.set_batch(host)
+                elif feeder is not None:
+                    feeder.submit(u8_images, u8_masks)      # the next batch travels while this one trains
+                    feeder.feed(model)
+                step()
+            if args.mode == "eval":
+                ev = tr.reduce_evaluation(0.0, args.batch * args.steps)   # sums the int64 matrices over the ranks
+            stream.synchronize()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            elapsed = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        host = feeder = None
-        if args.host_inputs == "f32":
-            host = [t.cpu().numpy() for t in (images, labels, weights)] + [nu]
-        elif args.host_inputs == "u8":
-            gen = pkg("generators")
-            hrng = np.random.RandomState(4242 + rank)
-            u8_images = hrng.randint(0, 256, size=(args.batch, args.size, args.size, 3)).astype(np.uint8)
-            u8_masks = hrng.randint(0, 24, size=(args.batch, args.size, args.size)).astype(np.uint8)
-            enc = gen.DeviceBatchEncoder({c: c for c in range(24)}, [0.0] + [1.0] * 23, [0.48, 0.45, 0.40], [0.23, 0.22, 0.23],
-                                         device=dev)
-            feeder = gen.PinnedBatchFeeder(enc, args.batch, args.size, args.size)
-            feeder.submit(u8_images, u8_masks)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if host is not None:
-                model.set_batch(host)
-            elif feeder is not None:
-                feeder.submit(u8_images, u8_masks)      # the next batch travels while this one trains
-                feeder.feed(model)
-            step()
-        if args.mode == "eval":
-            ev = tr.reduce_evaluation(0.0, args.batch * args.steps)   # sums the int64 matrices over the ranks
-        stream.synchronize()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    loss = float(model._loss_buf.item())
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, float(model._loss_buf.item()), ev
+
+    model = tr.model
+    elapsed, loss, ev = timed_run(tr, "f32")
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
 
@@ -196,6 +206,21 @@ def main():
     if rank == 0 and not args.no_roofline:
         roof = measure_roofline(model, stream)
 
+    # Second measurement, same step with bfloat16 activation storage (float32 arithmetic, parameters and optimizer state).
+    # The headline value above stays the float32 one.
+    bf16 = None
+    want_bf16 = args.dtype in ("bf16", "both") if args.dtype else world == 1
+    if want_bf16:
+        tr.model.close()
+        del model
+        tr16 = trainers.SegmentationTrainer("segmentation_supervised", args.model, "bench", num_classes=24,
+                                            config=dict(cfg, activation_dtype="bf16"))
+        el16, loss16, _ = timed_run(tr16, "bf16")
+        bf16 = {"value": round(args.batch * world * args.steps / el16, 2), "unit": "images/s",
+                "ms_per_step": round(el16 / args.steps * 1e3, 3), "final_loss": round(loss16, 5),
+                "dtype": "bf16 activation and activation-gradient storage; f32 multiply-add, statistics, parameters, Adam",
+                "roofline": measure_roofline(tr16.model, stream) if rank == 0 and not args.no_roofline else None}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -211,7 +236,7 @@ def main():
                    "inputs": {None: "resident in HBM", "f32": "float32 host arrays staged every step (PCIe-inclusive)",
                               "u8": "uint8 host arrays through pinned double buffers + device pre-pass every step "
                                     "(PCIe-inclusive, overlapped)"}[args.host_inputs]},
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "bf16": bf16}
         print(json.dumps(out), flush=True)
     if world > 1:
         # rank 0 measured the roofline alone; the others wait here so that no rank tears the group down under it

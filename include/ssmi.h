@@ -37,6 +37,14 @@ enum {
   SSMI_E_WORKSPACE = -5
 };
 
+/* Element type of ACTIVATION tensors (layer inputs / outputs and their gradients).  Parameters, BatchNormalization
+ * statistics, optimizer state, partial sums and all arithmetic are float32 whatever the activation type; pooling
+ * indices are int32 and confusion matrices int64.  SSMI_BF16 halves the bytes every HBM-bound kernel of the step moves
+ * (north-star configuration "fp32 and bf16 training"; the reference itself is float32 only, src/settings.py).
+ * Entry points whose descriptor carries a `dtype` field take `void*` activation pointers of that type; the others have
+ * a twin with the suffix _bf16 whose activation pointers are `uint16_t*` (bfloat16 bit patterns). */
+enum { SSMI_F32 = 0, SSMI_BF16 = 1 };
+
 const char* ssmi_last_error(void);
 /* Name of the kernel variant the calling thread's last convolution entry point dispatched, as it appears in a
  * rocprofv3 kernel trace (e.g. "conv_gemm_lds<true, 4, 1, true>"); profiling aid, no reference counterpart. */
@@ -61,7 +69,8 @@ int32_t ssmi_version(void);
  * with out-of-range x read as zero.  pad_t/pad_l are the TF "SAME" pad_before values (0 for VALID);
  * ssmi_same_pad() computes them.  x_ld / y_ld are the element strides between consecutive pixels of x / y
  * (>= cin / cout) so that a convolution can read or write a channel slice of a wider tensor (the concat of
- * the initial block, src/models.py:1063).
+ * the initial block, src/models.py:1063).  Activation tensors (x, y, their gradients, add, skip, bn_x) are `void*`: their
+ * element type is d->dtype; kernels, biases and kernel gradients are always float32.
  * ---------------------------------------------------------------------------------------------------- */
 typedef struct ssmi_conv_desc {
   int32_t n, h, w, cin;
@@ -71,6 +80,7 @@ typedef struct ssmi_conv_desc {
   int32_t dil;
   int32_t pad_t, pad_l;
   int32_t x_ld, y_ld;
+  int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x, y, their gradients, `add`, `skip` and `bn_x` */
 } ssmi_conv_desc;
 
 /* TF SAME padding rule: out = ceil(in/stride); total = max((out-1)*stride + (k-1)*dil + 1 - in, 0);
@@ -78,32 +88,32 @@ typedef struct ssmi_conv_desc {
 ssmi_status ssmi_same_pad(int32_t in, int32_t k, int32_t stride, int32_t dil, int32_t* out, int32_t* pad_before);
 
 /* Keras Conv2D forward (src/models.py:1056-1060, 1090-1096, 1105-1133, 1142-1147).  bias may be NULL. */
-ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                             void* stream);
 /* Inference-phase fusion: convolution + BatchNormalization with fixed statistics + activation in one launch
  * (src/models.py: every Conv2D -> BatchNormalization -> PReLU / LeakyReLU chain when the learning phase is 0):
  *   y = act(gamma * ((conv(x) + bias - mean) * invstd) + beta),  act in {SSMI_ACT_NONE, SSMI_ACT_PRELU (alpha per channel),
  *   SSMI_ACT_LEAKY (slope)}; mean / invstd come from ssmi_bn_infer_stats(_arena).  Same arithmetic as ssmi_bn_act_fwd. */
-ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias,
                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                         int32_t act, const float* alpha, float slope, float* y, void* stream);
+                                         int32_t act, const float* alpha, float slope, void* y, void* stream);
 /* The same with a skip tensor added between the normalisation and the activation:
  *   y = act(gamma * ((conv(x) + bias - mean) * invstd) + beta + skip[pixel * skip_ld + channel])
  * i.e. the last projection of a regular bottleneck, its BatchNormalization, the Add with the block input and the final
  * PReLU (src/models.py:1142-1174) in one launch when the learning phase is 0 (SpatialDropout2D is the identity then).
  * skip has the output's pixel grid, skip_ld >= cout floats per pixel; skip == NULL gives ssmi_conv2d_fwd_bn_act_infer.
  * Same arithmetic, in the same order, as ssmi_conv2d_fwd -> ssmi_merge_fwd(other_mode 0, drop NULL). */
-ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias,
                                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                             const float* skip, int32_t skip_ld, int32_t act, const float* alpha,
-                                             float slope, float* y, void* stream);
+                                             const void* skip, int32_t skip_ld, int32_t act, const float* alpha,
+                                             float slope, void* y, void* stream);
 
 /* Convolution whose output feeds a training-phase BatchNormalization (every conv -> BN pair of src/models.py, e.g.
  * :1096-1100): same y as ssmi_conv2d_fwd plus the statistics ssmi_bn_train_stats would compute from y (save_mean,
  * save_invstd, moving-average update), with the per-channel sums taken in the convolution kernel's epilogue instead of
  * a second pass over y.  ws: ssmi_conv2d_fwd_bn_stats_workspace_bytes(d). */
 size_t ssmi_conv2d_fwd_bn_stats_workspace_bytes(const ssmi_conv_desc* d);
-ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                                      float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
                                      float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                                      void* stream);
@@ -111,7 +121,7 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, co
 /* Gradient w.r.t. x (tf.gradients through Conv2D).  dx[n,h,w,cin] (pixel stride x_ld) is fully overwritten:
  * dx = conv_bwd_data(dy, w) + (add ? add : 0), where `add` (nullable) has the layout of dx.  The `add` operand
  * carries the gradient of the block's skip branch (src/models.py:1171). */
-ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
+ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,
                                  void* stream);
 /* Data gradient whose result is the gradient of a BatchNormalization(+activation, +SpatialDropout2D) OUTPUT, i.e. every
  * "BN -> act -> conv" chain walked backwards (src/models.py:1096-1118 and the convolution blocks :846-876).  Same `da`
@@ -120,17 +130,17 @@ ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const
  * stride-1 convolutions the per-channel sums are taken in the data-gradient kernel's epilogue, which saves one pass over
  * da and bn_x; other shapes run the two plain passes.  ws: ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d). */
 size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d);
-ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add,
-                                        float* da, const float* bn_x, int32_t ld_x, const float* mean,
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add,
+                                        void* da, const void* bn_x, int32_t ld_x, const float* mean,
                                         const float* invstd, const float* gamma, const float* beta, int32_t act,
-                                        const float* alpha, float slope, const float* drop, int64_t hw, float* dx_bn,
+                                        const float* alpha, float slope, const float* drop, int64_t hw, void* dx_bn,
                                         float* dgamma, float* dbeta, float* dalpha, void* ws, size_t ws_bytes,
                                         void* stream);
 
 /* Gradient w.r.t. the kernel (and bias when dbias != NULL).  dw/dbias are overwritten.  Deterministic
  * two-stage reduction through `ws`. */
 size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d);
-ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                    void* ws, size_t ws_bytes, void* stream);
 
 /* Keras Conv2DTranspose(padding='same', strides=s) (src/models.py:1244-1250, 1311-1317, 1556-1562, 1620-1626) =
@@ -138,12 +148,12 @@ ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const float* x, cons
  *   tconv input  xt[n, ho, wo, cout],  tconv output yt[n, h, w, cin] (h = ho*stride, w = wo*stride),
  *   kernel (kh, kw, tconv_out = cin, tconv_in = cout)  -- the Keras Conv2DTranspose kernel layout, which is the
  *   HWIO layout of the forward convolution `d`.  bias has cin entries (nullable). */
-ssmi_status ssmi_conv2d_transpose_fwd(const ssmi_conv_desc* d, const float* xt, const float* w, const float* bias,
-                                      float* yt, void* stream);
-ssmi_status ssmi_conv2d_transpose_bwd_data(const ssmi_conv_desc* d, const float* dyt, const float* w, float* dxt,
+ssmi_status ssmi_conv2d_transpose_fwd(const ssmi_conv_desc* d, const void* xt, const float* w, const float* bias,
+                                      void* yt, void* stream);
+ssmi_status ssmi_conv2d_transpose_bwd_data(const ssmi_conv_desc* d, const void* dyt, const float* w, void* dxt,
                                            void* stream);
 size_t ssmi_conv2d_transpose_bwd_weight_workspace_bytes(const ssmi_conv_desc* d);
-ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const float* xt, const float* dyt, float* dw,
+ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const void* xt, const void* dyt, float* dw,
                                              float* dbias, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -209,6 +219,7 @@ typedef struct ssmi_merge_desc {
   int32_t n, h, w, c;
   int32_t other_mode;
   int32_t c_other;
+  int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of main, other, out and their gradients */
 } ssmi_merge_desc;
 
 typedef struct ssmi_bn_params {
@@ -218,9 +229,9 @@ typedef struct ssmi_bn_params {
   const float* beta;
 } ssmi_bn_params;
 
-ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
-                           const float* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
-                           float* out, void* stream);
+ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const void* main, const ssmi_bn_params* bn3, const float* drop,
+                           const void* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
+                           void* out, void* stream);
 /* Backward.  Outputs (all overwritten):
  *   dmain   [n,h,w,c]   gradient w.r.t. the raw `main` tensor (through dropout and BN3, training phase)
  *   dsum    [n,h,w,c]   gradient w.r.t. the pre-activation sum (= gradient of the identity / padded skip branch)
@@ -228,9 +239,9 @@ ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const float* main, const ss
  *                       pushes it through ssmi_bn_act_bwd(act = none) to reach the other-branch convolution
  *   dgamma3, dbeta3, dalpha  parameter gradients */
 size_t ssmi_merge_workspace_bytes(const ssmi_merge_desc* d);
-ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const float* main, const ssmi_bn_params* bn3,
-                           const float* drop, const float* other, const ssmi_bn_params* bn_other, const int32_t* idx,
-                           const float* alpha, float* dmain, float* dsum, float* dother_bn, float* dgamma3,
+ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const void* dout, const void* main, const ssmi_bn_params* bn3,
+                           const float* drop, const void* other, const ssmi_bn_params* bn_other, const int32_t* idx,
+                           const float* alpha, void* dmain, void* dsum, void* dother_bn, float* dgamma3,
                            float* dbeta3, float* dalpha, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
@@ -400,6 +411,52 @@ ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t 
  * backward dx[n, p, c] = dy[n, c] / hw. */
 ssmi_status ssmi_global_avgpool_fwd(const float* x, int32_t n, int64_t hw, int32_t c, float* y, void* stream);
 ssmi_status ssmi_global_avgpool_bwd(const float* dy, int32_t n, int64_t hw, int32_t c, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------
+ * bfloat16 twins of the entry points above whose activation tensors are not described by a descriptor.  Same
+ * arguments and semantics as the function without the suffix (cited there); activation tensors are bfloat16 bit patterns
+ * (uint16_t), everything else (statistics, parameters, tables, indices, partial sums) keeps its type.  Arithmetic is
+ * float32; results are rounded to nearest even when stored.  Pooling compares the bfloat16 values it reads, so indices
+ * are exact for the tensor as stored.
+ * ---------------------------------------------------------------------------------------------------- */
+ssmi_status ssmi_bn_train_stats_bf16(const uint16_t* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
+                                     int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                     float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+ssmi_status ssmi_bn_act_fwd_bf16(const uint16_t* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, int32_t act, const float* alpha, float slope, uint16_t* y, int64_t npix,
+                                 int32_t c, void* stream);
+ssmi_status ssmi_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 uint16_t* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                 size_t ws_bytes, void* stream);
+ssmi_status ssmi_bn_act_drop_fwd_bf16(const uint16_t* x, int32_t ld_x, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                      const float* drop, int64_t hw, uint16_t* y, int32_t ld_y, int64_t npix, int32_t c,
+                                      void* stream);
+ssmi_status ssmi_bn_act_drop_bwd_bf16(const uint16_t* dy, int32_t ld_dy, const uint16_t* x, int32_t ld_x, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                      const float* alpha, float slope, const float* drop, int64_t hw, uint16_t* dx,
+                                      float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                      size_t ws_bytes, void* stream);
+ssmi_status ssmi_maxpool_argmax_fwd_bf16(const uint16_t* x, int32_t n, int32_t h, int32_t w, int32_t c, uint16_t* y,
+                                         int32_t y_ld, int32_t* idx_i32, float* idx_f32, void* stream);
+ssmi_status ssmi_maxpool_argmax_bwd_bf16(const uint16_t* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
+                                         int32_t c, uint16_t* dx, int32_t accumulate, void* stream);
+ssmi_status ssmi_upsample_nn2x_fwd_bf16(const uint16_t* x, int32_t n, int32_t h, int32_t w, int32_t c, uint16_t* y, int32_t y_ld,
+                                        void* stream);
+ssmi_status ssmi_upsample_nn2x_bwd_bf16(const uint16_t* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c,
+                                        uint16_t* dx, void* stream);
+ssmi_status ssmi_copy_ld_bf16(const uint16_t* src, int32_t src_ld, uint16_t* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                              int32_t accumulate, void* stream);
+ssmi_status ssmi_scale_nc_bf16(const uint16_t* x, const float* table, uint16_t* y, int32_t n, int64_t hw, int32_t c, void* stream);
+ssmi_status ssmi_softmax_xent_fwd_bwd_bf16(const uint16_t* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                           int32_t num_classes, float grad_scale, uint16_t* dlogits, float* loss_out,
+                                           int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                           int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream);
+/* float32 <-> bfloat16 conversion of a dense tensor (round to nearest even): the images entering a bfloat16 network and the
+ * logits leaving it for float32 consumers (src/generators.py:732-768 produces float32 batches; predict returns float32). */
+ssmi_status ssmi_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, void* stream);
+ssmi_status ssmi_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Input contract on the device (src/generators.py:711-770, 1787-1825): from the uint8 crops of a batch to the tensors

@@ -237,7 +237,12 @@ def make_dropout_masks(model_name: str, batch: int, seed: int, dtype=np.float64)
 # --------------------------------------------------------------------------------------
 
 class _Ctx:
-    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect, forced=None):
+    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect, forced=None, storage=None):
+        # storage == "bf16": every tensor the device implementation keeps in memory between kernels (convolution outputs,
+        # activated outputs, block outputs, logits) and every stored gradient is rounded to bfloat16 at that point, the
+        # arithmetic in between stays in this evaluation's own precision
+        self.storage = storage
+        self.unrounded = {}
         self.p = params
         self.training = training
         # forced: {PReLU layer name: sign tensor (+1 / -1 / 0)} and {"<block>_other_pool2d/argmax": int64 indices}: branches
@@ -247,21 +252,34 @@ class _Ctx:
         self.bn_stats: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.acts: Dict[str, torch.Tensor] = {} if collect else None
 
+    def q(self, t, fwd=True, bwd=True):
+        return K.round_bf16(t, fwd, bwd) if self.storage == "bf16" else t
+
     def keep(self, name, t):
         if self.acts is not None:
             self.acts[name] = t
         return t
 
     def conv(self, name, x, stride=1, dil=1, padding="same"):
-        return self.keep(name, K.conv2d(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride, dil, padding))
+        y = K.conv2d(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride, dil, padding)
+        if self.storage == "bf16":
+            # the stored tensor is rounded, but a BatchNormalization that consumes it takes its batch statistics from the
+            # convolution's unrounded accumulators (column sums in the kernel epilogue); the gradient of both uses meets in
+            # y and is rounded there, as the stored gradient tensor is
+            y = self.q(y, fwd=False)
+            yq = y + (y.to(torch.bfloat16).to(y.dtype) - y).detach()
+            self.unrounded[id(yq)] = (yq, y)
+            y = yq
+        return self.keep(name, y)
 
     def tconv(self, name, x, stride=2):
-        return self.keep(name, K.conv2d_transpose(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride))
+        return self.keep(name, self.q(K.conv2d_transpose(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride)))
 
     def bn(self, name, x):
         g, b = self.p[name + "/gamma"], self.p[name + "/beta"]
         if self.training:
-            y, mean, var = K.batch_norm_train(x, g, b)
+            src = self.unrounded.get(id(x), (None, x))[1]
+            y, mean, var = K.batch_norm_train(x, g, b, stats_of=src)
             self.bn_stats[name] = (mean.detach(), var.detach())
         else:
             y = K.batch_norm_infer(x, g, b, self.p[name + "/moving_mean"], self.p[name + "/moving_variance"])
@@ -269,8 +287,8 @@ class _Ctx:
 
     def prelu(self, name, x):
         if name in self.forced:
-            return self.keep(name, K.prelu_forced(x, self.p[name + "/alpha"].reshape(-1), self.forced[name]))
-        return self.keep(name, K.prelu(x, self.p[name + "/alpha"].reshape(-1)))
+            return self.keep(name, self.q(K.prelu_forced(x, self.p[name + "/alpha"].reshape(-1), self.forced[name])))
+        return self.keep(name, self.q(K.prelu(x, self.p[name + "/alpha"].reshape(-1))))
 
     def sdrop(self, name, x):
         if self.training and name in self.drop:
@@ -305,7 +323,7 @@ def _enc_bottleneck(c: _Ctx, x, cout, p, downsample=False, asymmetric=0, dilated
         else:
             other = K.max_pool_2x2(other)
         other = K.channel_zero_pad(other, cout)
-    out = c.prelu(p + "_prelu_3", e + other)
+    out = c.prelu(p + "_prelu_3", c.q(e + other, fwd=False))      # the gradient of the sum is a stored tensor
     return (out, idx) if want_idx and downsample else out
 
 
@@ -323,12 +341,12 @@ def _dec_bottleneck(c: _Ctx, x, cout, p, upsample, variant, idx=None):
         d = c.sdrop(p + "_sdrop2d_1", c.bn(p + "_bnorm_3", d))
     other = x
     if cin != cout or upsample:
-        other = c.bn(p + "_other_bnorm_1", c.conv(p + "_other_conv2d", other))
+        other = c.q(c.bn(p + "_other_bnorm_1", c.conv(p + "_other_conv2d", other)), fwd=False)
         if upsample:
             other = K.upsample_nn2(other) if variant in ("naive", "enhanced") else K.max_unpool(other, idx)
     if variant == "unpool":
         d = c.bn(p + "_bnorm_3", d)
-    return c.prelu(p + "_prelu_3", d + other)
+    return c.prelu(p + "_prelu_3", c.q(d + other, fwd=False))
 
 
 def classifier_head(c, x):
@@ -339,7 +357,7 @@ def classifier_head(c, x):
 
 
 def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch.Tensor, training: bool = True,
-                 drop_masks=None, collect: bool = False, forced=None):
+                 drop_masks=None, collect: bool = False, forced=None, storage=None):
     """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
     ctx.acts the named intermediate tensors when collect=True."""
     model_name, encoder_only = split_name(model_name)
@@ -350,8 +368,9 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
                "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)
     if variant is None:
         raise ValueError("Unknown model name: {}".format(model_name))
-    c = _Ctx(params, training, drop_masks, collect, forced)
+    c = _Ctx(params, training, drop_masks, collect, forced, storage)
     idx_stack = []
+    images = c.q(images, bwd=False)
     conv = c.conv("initial_block_conv2d", images, stride=2)
     if variant in ("naive", "enhanced"):
         x = torch.cat([conv, K.max_pool_2x2(images)], dim=3)
@@ -395,6 +414,71 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
     return logits, c
 
 
+def block_table(model_name: str) -> "OrderedDict[str, tuple]":
+    """Bottleneck name -> ("enc" | "dec", output channels, keyword arguments of its builder), network order."""
+    variant = {"enet-naive-upsampling": "naive", "enet-max-unpooling": "unpool",
+               "enet-naive-upsampling-enhanced": "enhanced"}[split_name(model_name)[0]]
+    t: "OrderedDict[str, tuple]" = OrderedDict()
+    t["en_bn_1.0"] = ("enc", 64, dict(downsample=True))
+    for i in range(4):
+        t["en_bn_1.{}".format(i + 1)] = ("enc", 64, {})
+    t["en_bn_2.0"] = ("enc", 128, dict(downsample=True))
+    for stage in (2, 3):
+        for suffix, kw in ENC_PATTERN:
+            t["en_bn_{}.{}".format(stage, suffix)] = ("enc", 128, dict(kw))
+    for name, cout, up in (("de_bn_4.0", 64, True), ("de_bn_4.1", 64, False), ("de_bn_4.2", 64, False),
+                           ("de_bn_5.0", 16, True), ("de_bn_5.1", 16, False)):
+        t[name] = ("dec", cout, dict(upsample=up, variant=variant))
+    return t
+
+
+def block_step(model_name: str, weights, block: str, x: np.ndarray, dout: np.ndarray, drop_masks=None, forced=None,
+               storage: Optional[str] = None, unpool_idx: Optional[np.ndarray] = None, dtype=torch.float64):
+    """ONE block of the network evaluated on its own: forward from the given input `x` (training phase), then the
+    vector-Jacobian product with the given output gradient `dout`.  `block`: a bottleneck name, "initial_block" (x = images)
+    or "head" (everything after de_bn_5.1; dout = gradient of the logits).  Used to check an implementation layer by layer
+    on ITS OWN intermediate tensors, which keeps the comparison meaningful where whole-network differences compound (reduced
+    precision storage).  Returns dict(out, dx, grads{key})."""
+    base, _ = split_name(model_name)
+    variant = {"enet-naive-upsampling": "naive", "enet-max-unpooling": "unpool", "enet-naive-upsampling-enhanced": "enhanced"}[base]
+    prefixes = {"initial_block": ("initial_block",), "head": ("logits", "final_nn_rs_conv")}.get(block, (block + "_",))
+    params = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in weights.items() if k.startswith(prefixes)}
+    tkeys = [k for k in params if k.endswith(TRAINABLE_SUFFIXES)]
+    for k in tkeys:
+        params[k].requires_grad_(True)
+    masks = {k: torch.tensor(v, dtype=dtype) for k, v in (drop_masks or {}).items()}
+    fz = {k: torch.as_tensor(np.asarray(v)).to(torch.int64 if k.endswith("/argmax") else dtype) for k, v in (forced or {}).items()}
+    c = _Ctx(params, True, masks, False, fz, storage)
+    xt = torch.tensor(np.asarray(x), dtype=dtype, requires_grad=block != "initial_block")
+    if block == "initial_block":
+        conv = c.conv("initial_block_conv2d", xt, stride=2)
+        if variant in ("naive", "enhanced"):
+            out = c.prelu("initial_block_prelu", c.bn("initial_block_bnorm", torch.cat([conv, K.max_pool_2x2(xt)], dim=3)))
+        else:
+            out = torch.cat([conv, K.max_pool_with_argmax(xt)[0]], dim=3)
+    elif block == "head":
+        if variant == "enhanced":
+            h = c.conv("final_nn_rs_conv_conv2d", K.upsample_nn2(xt))
+            h = c.prelu("final_nn_rs_conv_prelu", c.bn("final_nn_rs_conv_bnorm", h))
+            out = c.conv("logits", h)
+        else:
+            out = c.tconv("logits", xt)
+    else:
+        kind, cout, kw = block_table(model_name)[block]
+        if kind == "enc":
+            out = _enc_bottleneck(c, xt, cout, block, **kw)
+        else:
+            idx = None if unpool_idx is None else torch.as_tensor(np.asarray(unpool_idx)).to(torch.int64)
+            out = _dec_bottleneck(c, xt, cout, block, kw["upsample"], kw["variant"], idx)
+    wanted = [params[k] for k in tkeys] + ([xt] if xt.requires_grad else [])
+    grads = torch.autograd.grad(out, wanted, grad_outputs=torch.tensor(np.asarray(dout), dtype=dtype), allow_unused=True)
+    gd = {k: (g.detach().numpy() if g is not None else np.zeros(tuple(params[k].shape))) for k, g in zip(tkeys, grads)}
+    dx = grads[-1].detach().numpy() if xt.requires_grad else None
+    if dx is not None and storage == "bf16":
+        dx = torch.from_numpy(dx).to(torch.bfloat16).to(dtype).numpy()      # the block's input gradient is a stored tensor
+    return dict(out=out.detach().numpy(), dx=dx, grads=gd)
+
+
 TRAINABLE_SUFFIXES = ("/kernel", "/bias", "/gamma", "/beta", "/alpha")
 
 
@@ -406,7 +490,7 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
                pixel_weights: np.ndarray, drop_masks=None, dtype=torch.float64, collect=False,
                adam: Optional[dict] = None, adam_state: Optional[dict] = None, ignore_classes=(0,),
                mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None, classification: bool = False,
-               forced: Optional[dict] = None):
+               forced: Optional[dict] = None, storage: Optional[str] = None):
     """One supervised training step exactly as the reference assembles it
     (src/trainers.py:2436-2440: total = 1*loss + 0*mean(0*logits)):
     forward (training phase) -> weighted CE -> gradients -> BN moving-average updates -> optional Adam.
@@ -424,7 +508,7 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
     fz = None
     if forced:
         fz = {k: torch.as_tensor(np.asarray(v)).to(torch.int64 if k.endswith("/argmax") else dtype) for k, v in forced.items()}
-    logits, ctx = enet_forward(model_name, params, x, True, masks, collect, fz)
+    logits, ctx = enet_forward(model_name, params, x, True, masks, collect, fz, storage)
     if classification:      # labels / pixel_weights are [B, classes] float arrays (src/losses.py:636-652)
         lab = torch.tensor(labels, dtype=dtype)
         w = torch.tensor(pixel_weights, dtype=dtype)

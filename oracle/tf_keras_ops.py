@@ -94,11 +94,13 @@ BN_EPS = 1e-3          # Keras BatchNormalization default epsilon
 BN_MOMENTUM = 0.1      # src/models.py:1064,1100,... (weight of the OLD moving value)
 
 
-def batch_norm_train(x, gamma, beta, eps=BN_EPS):
+def batch_norm_train(x, gamma, beta, eps=BN_EPS, stats_of=None):
     """Keras BatchNormalization(axis=-1) in the training phase: statistics over N,H,W, biased
-    variance.  Returns (y, batch_mean, batch_var)."""
-    mean = x.mean(dim=(0, 1, 2))
-    var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+    variance.  Returns (y, batch_mean, batch_var).  `stats_of` (default x itself): the tensor the statistics are taken
+    from, for evaluations that model a stored, rounded x whose statistics came from the unrounded values."""
+    s = x if stats_of is None else stats_of
+    mean = s.mean(dim=(0, 1, 2))
+    var = ((s - mean) ** 2).mean(dim=(0, 1, 2))
     y = (x - mean) * torch.rsqrt(var + eps) * gamma + beta
     return y, mean, var
 
@@ -130,6 +132,24 @@ def max_pool_forced(x, idx):
     """2x2 pooling with the selection given (per-image flat NHWC indices as max_pool_with_argmax returns them)."""
     B = x.shape[0]
     return torch.gather(x.reshape(B, -1), 1, idx.reshape(B, -1)).reshape(idx.shape)
+
+
+class _RoundBf16(torch.autograd.Function):
+    """Identity whose value (forward) and / or incoming gradient (backward) is rounded to bfloat16, round to nearest even:
+    the effect of storing a tensor and / or its gradient in bfloat16 between two float32 computations."""
+
+    @staticmethod
+    def forward(ctx, x, fwd, bwd):
+        ctx.bwd = bwd
+        return x.to(torch.bfloat16).to(x.dtype) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(torch.bfloat16).to(g.dtype) if ctx.bwd else g), None, None
+
+
+def round_bf16(x, fwd=True, bwd=True):
+    return _RoundBf16.apply(x, fwd, bwd)
 
 
 def leaky_relu(x, slope=0.1):

@@ -19,11 +19,12 @@ class SsmiError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
-                ("n", "h", "w", "cin", "ho", "wo", "cout", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "x_ld", "y_ld")]
+                ("n", "h", "w", "cin", "ho", "wo", "cout", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "x_ld", "y_ld",
+                 "dtype")]
 
 
 class MergeDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "c", "other_mode", "c_other")]
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "c", "other_mode", "c_other", "dtype")]
 
 
 class BnParams(C.Structure):
@@ -115,6 +116,15 @@ _PROTOS = {
     "ssmi_graph_destroy": (_i32, [_vp]),
 }
 
+# bfloat16 twins: same prototypes as the float32 entry points (pointers are void* either way)
+for _n in ("bn_train_stats", "bn_act_fwd", "bn_act_bwd", "bn_act_drop_fwd", "bn_act_drop_bwd", "maxpool_argmax_fwd",
+           "maxpool_argmax_bwd", "upsample_nn2x_fwd", "upsample_nn2x_bwd", "copy_ld", "scale_nc", "softmax_xent_fwd_bwd"):
+    _PROTOS["ssmi_" + _n + "_bf16"] = _PROTOS["ssmi_" + _n]
+_PROTOS["ssmi_cast_f32_to_bf16"] = (_i32, [_vp, _vp, _i64, _vp])
+_PROTOS["ssmi_cast_bf16_to_f32"] = (_i32, [_vp, _vp, _i64, _vp])
+
+F32, BF16 = 0, 1      # ssmi dtype codes of activation tensors
+
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 _NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
@@ -152,7 +162,33 @@ class _Lib:
         return call
 
 
+class _TypedView:
+    """The library as seen by a network whose activations are bfloat16: every entry point that has a `_bf16` twin resolves
+    to it, everything else (descriptor-typed convolutions / merges, optimizers, ...) to the plain entry point."""
+
+    def __init__(self, base: "_Lib"):
+        self._base = base
+
+    def __getattr__(self, name):
+        base = self.__dict__["_base"]
+        fn = getattr(base, name + "_bf16", None) or getattr(base, name)
+        setattr(self, name, fn)
+        return fn
+
+
 _lib = None
+
+
+def lib_for(dtype_code: int):
+    """lib() for float32 activations, its bfloat16 view for BF16."""
+    L = lib()
+    if dtype_code == F32:
+        return L
+    if dtype_code == BF16:
+        if not hasattr(L, "_bf16_view"):
+            L._bf16_view = _TypedView(L)
+        return L._bf16_view
+    raise ValueError("unknown activation dtype code {}".format(dtype_code))
 
 
 def lib() -> _Lib:

@@ -40,7 +40,8 @@ __device__ __forceinline__ void block_reduce_groups(f32x4 (&v)[NV], f32x4* sm, i
 // ------------------------------------------------------------------------------------------------
 // statistics
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, int64_t npix, int c4n, int ld,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, int64_t npix, int c4n, int ld,
                                                         float* __restrict__ part) {
   __shared__ f32x4 sm[2 * 256];
   const int ppi = 256 / c4n;
@@ -50,14 +51,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   if (active) {
     // eight pixels per round with all loads in flight at once (a one-load-per-iteration loop costs one memory round
     // trip per pixel); pixels past the end read zeros through the buffer bounds check
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)(npix * ld * 4));
+    const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, (unsigned)(npix * ld * 4));
     const int64_t stride = (int64_t)gridDim.x * ppi;
     for (int64_t p0 = (int64_t)blockIdx.x * ppi + pl; p0 < npix; p0 += stride * 8) {
       f32x4 a[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int64_t p = p0 + u * stride;
-        a[u] = bload4(rx, p < npix ? (unsigned)((p * ld + c4 * 4) * 4) : kOOB);
+        a[u] = Act<T>::ld4(rx, p < npix ? (unsigned)((p * ld + c4 * 4) * 4) : kOOB);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
@@ -174,16 +175,16 @@ __device__ __forceinline__ float act_grad(float z, float a) {
   return z > 0.f ? 1.f : (z < 0.f ? a : 0.f);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, int ld, const float* __restrict__ mean,
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, int ld, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ alpha,
                                                          float slope, const float* __restrict__ drop, int64_t hw,
-                                                         float* __restrict__ y, int y_ld, int64_t total4, int c4n) {
+                                                         T* __restrict__ y, int y_ld, int64_t total4, int c4n) {
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
     const unsigned p = i / (unsigned)c4n;
     const int c = (int)(i - p * (unsigned)c4n) * 4;
-    const f32x4 xv = ld4(x + p * ld + c);
+    const f32x4 xv = Act<T>::gld4(x + p * ld + c);
     const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
     f32x4 a = {slope, slope, slope, slope};
     if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
@@ -191,13 +192,13 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
     if (drop) o = o * ld4(drop + (p / (unsigned)hw) * (unsigned)(c4n * 4) + c);
-    st4(y + p * y_ld + c, o);
+    Act<T>::gst4(y + p * y_ld + c, o);
   }
 }
 
 // backward pass 1: per-channel sums of dz, dz*xhat and (PReLU) dy*min(z,0)
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict__ dy, const float* __restrict__ x, int ld,
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x, int ld,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ alpha, float slope,
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict
     f32x4 a = {slope, slope, slope, slope};
     if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
     // four pixels per round, their eight loads in flight together
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)(npix * ld * 4));
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, (unsigned)(npix * dy_ld * 4));
+    const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, (unsigned)(npix * ld * 4));
+    const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(dy, (unsigned)(npix * dy_ld * 4));
     const int64_t stride = (int64_t)gridDim.x * ppi;
     for (int64_t p0 = (int64_t)blockIdx.x * ppi + pl; p0 < npix; p0 += stride * 4) {
       f32x4 xv[4], d[4];
@@ -223,8 +224,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const float* __restrict
       for (int u = 0; u < 4; ++u) {
         const int64_t p = p0 + u * stride;
         const bool ok = p < npix;
-        xv[u] = bload4(rx, ok ? (unsigned)((p * ld + c) * 4) : kOOB);
-        d[u] = bload4(rd, ok ? (unsigned)((p * dy_ld + c) * 4) : kOOB);   // zero gradient for pixels past the end
+        xv[u] = Act<T>::ld4(rx, ok ? (unsigned)((p * ld + c) * 4) : kOOB);
+        d[u] = Act<T>::ld4(rd, ok ? (unsigned)((p * dy_ld + c) * 4) : kOOB);   // zero gradient for pixels past the end
       }
       if (drop) {
 #pragma unroll
@@ -273,20 +274,20 @@ __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ pa
   coef[2 * c + ch] = (float)(r[1] / (double)npix);
 }
 
-template <int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict__ dy, const float* __restrict__ x, int ld,
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, int ld,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ alpha, float slope,
                                                         const float* __restrict__ drop, int64_t hw, int dy_ld,
-                                                        const float* __restrict__ coef, float* __restrict__ dx,
+                                                        const float* __restrict__ coef, T* __restrict__ dx,
                                                         int64_t total4, int c4n) {
   const int cc = c4n * 4;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
     const unsigned p = i / (unsigned)c4n;
     const int c = (int)(i - p * (unsigned)c4n) * 4;
-    const f32x4 xv = ld4(x + p * ld + c);
-    f32x4 d = ld4(dy + p * dy_ld + c);
+    const f32x4 xv = Act<T>::gld4(x + p * ld + c);
+    f32x4 d = Act<T>::gld4(dy + p * dy_ld + c);
     if (drop) d = d * ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
     const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
     const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
       const float dz = d[j] * act_grad<ACT>(z, a[j]);
       o[j] = k1[j] * (dz - m1[j] - xh * m2[j]);
     }
-    st4(dx + p * ld + c, o);
+    Act<T>::gst4(dx + p * ld + c, o);
   }
 }
 
@@ -309,21 +310,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 struct MergeArgs {
   int n, h, w, c, mode, c_other;
-  const float* main;
+  const void* main;        // activation type
   const float *mean3, *invstd3, *gamma3, *beta3;
   const float* drop;
-  const float* other;
+  const void* other;       // activation type
   const float *mean_o, *invstd_o, *gamma_o, *beta_o;
   const int32_t* idx;
   const float* alpha;
 };
 
 // pre-activation sum s and (optionally) the BN3 intermediates for element group (p, c..c+3)
-template <int MODE>
+template <typename T, int MODE>
 __device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, unsigned p, int c, f32x4& xh3, f32x4& dropv) {
   const unsigned hw = (unsigned)(a.h * a.w);     // every tensor is below 2 GiB: 32-bit element arithmetic
   const unsigned n_ = p / hw;
-  const f32x4 mv = ld4(a.main + p * a.c + c);
+  const T* main_ = static_cast<const T*>(a.main);
+  const T* other_ = static_cast<const T*>(a.other);
+  const f32x4 mv = Act<T>::gld4(main_ + p * a.c + c);
   const f32x4 m = ld4(a.mean3 + c), is = ld4(a.invstd3 + c), g = ld4(a.gamma3 + c), b = ld4(a.beta3 + c);
   dropv = f32x4{1.f, 1.f, 1.f, 1.f};
   if (a.drop) dropv = ld4(a.drop + n_ * (unsigned)a.c + c);
@@ -334,15 +337,15 @@ __device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, unsigned p, int c
     s[j] = (g[j] * xh3[j] + b[j]) * dropv[j];
   }
   if (MODE == 0) {
-    s += ld4(a.other + p * a.c + c);
+    s += Act<T>::gld4(other_ + p * a.c + c);
   } else if (MODE == 1) {
-    if (c < a.c_other) s += ld4(a.other + p * a.c_other + c);
+    if (c < a.c_other) s += Act<T>::gld4(other_ + p * a.c_other + c);
   } else {
     const unsigned rem = p - n_ * hw;
     const int y = (int)(rem / (unsigned)a.w), x = (int)(rem - (unsigned)y * (unsigned)a.w);
     const int h2 = a.h >> 1, w2 = a.w >> 1;
     const unsigned q = (n_ * (unsigned)h2 + (unsigned)(y >> 1)) * (unsigned)w2 + (unsigned)(x >> 1);
-    const f32x4 ov = ld4(a.other + q * a.c + c);
+    const f32x4 ov = Act<T>::gld4(other_ + q * a.c + c);
     const f32x4 mo = ld4(a.mean_o + c), iso = ld4(a.invstd_o + c), go = ld4(a.gamma_o + c), bo = ld4(a.beta_o + c);
     f32x4 o;
 #pragma unroll
@@ -360,25 +363,25 @@ __device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, unsigned p, int c
   return s;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, float* __restrict__ out, int64_t total4, int c4n) {
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, T* __restrict__ out, int64_t total4, int c4n) {
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
     const unsigned p = i / (unsigned)c4n;
     const int c = (int)(i - p * (unsigned)c4n) * 4;
     f32x4 xh3, dv;
-    const f32x4 s = merge_sum<MODE>(a, p, c, xh3, dv);
+    const f32x4 s = merge_sum<T, MODE>(a, p, c, xh3, dv);
     const f32x4 al = ld4(a.alpha + c);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = s[j] > 0.f ? s[j] : al[j] * s[j];
-    st4(out + i * 4, o);
+    Act<T>::gst4(out + (size_t)i * 4, o);
   }
 }
 
 // backward pass 1: dsum = dout * prelu'(s); partial sums of dz = dsum*drop, dz*xhat3 and dout*min(s,0)
-template <int MODE>
-__global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const float* __restrict__ dout,
-                                                        float* __restrict__ dsum, int64_t npix, int c4n,
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __restrict__ dout,
+                                                        T* __restrict__ dsum, int64_t npix, int c4n,
                                                         float* __restrict__ part) {
   __shared__ f32x4 sm[3 * 256];
   const int ppi = 256 / c4n;
@@ -390,8 +393,8 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const float
     const f32x4 al = ld4(a.alpha + c);
     for (unsigned p = blockIdx.x * (unsigned)ppi + (unsigned)pl; p < (unsigned)npix; p += gridDim.x * (unsigned)ppi) {
       f32x4 xh3, dv;
-      const f32x4 s = merge_sum<MODE>(a, p, c, xh3, dv);
-      const f32x4 d = ld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
+      const f32x4 s = merge_sum<T, MODE>(a, p, c, xh3, dv);
+      const f32x4 d = Act<T>::gld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
       f32x4 ds;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const float
         v[1][j] += dz * xh3[j];
         v[2][j] += d[j] * (s[j] < 0.f ? s[j] : 0.f);
       }
-      st4(dsum + (p * c4n + c4) * 4, ds);
+      Act<T>::gst4(dsum + (p * c4n + c4) * 4, ds);
     }
   }
   block_reduce_groups<3>(v, sm, c4n, ppi, active);
@@ -413,15 +416,16 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const float
 }
 
 // backward pass 2: dmain = gamma3*invstd3 * (dsum*drop - mean(dz) - xhat3*mean(dz*xhat3))
-__global__ __launch_bounds__(256) void merge_bwd_apply(const float* __restrict__ dsum, const float* __restrict__ main,
+template <typename T>
+__global__ __launch_bounds__(256) void merge_bwd_apply(const T* __restrict__ dsum, const T* __restrict__ main,
                                                        const float* __restrict__ mean3, const float* __restrict__ invstd3,
                                                        const float* __restrict__ drop, const float* __restrict__ coef,
-                                                       float* __restrict__ dmain, int64_t total4, int c4n, int64_t hw) {
+                                                       T* __restrict__ dmain, int64_t total4, int c4n, int64_t hw) {
   const int cc = c4n * 4;
   for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
     const unsigned p = i / (unsigned)c4n;
     const int c = (int)(i - p * (unsigned)c4n) * 4;
-    const f32x4 ds = ld4(dsum + i * 4), mv = ld4(main + i * 4);
+    const f32x4 ds = Act<T>::gld4(dsum + (size_t)i * 4), mv = Act<T>::gld4(main + (size_t)i * 4);
     const f32x4 m = ld4(mean3 + c), is = ld4(invstd3 + c);
     const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
     f32x4 dv = {1.f, 1.f, 1.f, 1.f};
@@ -432,14 +436,14 @@ __global__ __launch_bounds__(256) void merge_bwd_apply(const float* __restrict__
       const float xh = (mv[j] - m[j]) * is[j];
       o[j] = k1[j] * (ds[j] * dv[j] - m1[j] - xh * m2[j]);
     }
-    st4(dmain + i * 4, o);
+    Act<T>::gst4(dmain + (size_t)i * 4, o);
   }
 }
 
 // gradient w.r.t. BN_o's output for the upsample (2x2 sum) / unpool (gather at idx) skip branches
-template <int MODE>
-__global__ __launch_bounds__(256) void merge_bwd_other(const float* __restrict__ dsum, const int32_t* __restrict__ idx,
-                                                       float* __restrict__ dother, int n, int h, int w, int c4n,
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void merge_bwd_other(const T* __restrict__ dsum, const int32_t* __restrict__ idx,
+                                                       T* __restrict__ dother, int n, int h, int w, int c4n,
                                                        int64_t total4) {
   const int c = c4n * 4;
   const int h2 = h >> 1, w2 = w >> 1;
@@ -452,17 +456,17 @@ __global__ __launch_bounds__(256) void merge_bwd_other(const float* __restrict__
     const int n_ = (int)(t / h2);
     f32x4 o;
     if (MODE == 2) {
-      const float* base = dsum + (((int64_t)n_ * h + 2 * y2) * w + 2 * x2) * c + ch;
-      o = ld4(base) + ld4(base + c) + ld4(base + (int64_t)w * c) + ld4(base + (int64_t)w * c + c);
+      const T* base = dsum + (((int64_t)n_ * h + 2 * y2) * w + 2 * x2) * c + ch;
+      o = Act<T>::gld4(base) + Act<T>::gld4(base + c) + Act<T>::gld4(base + (int64_t)w * c) + Act<T>::gld4(base + (int64_t)w * c + c);
     } else {
-      const int4 iv = *reinterpret_cast<const int4*>(idx + i * 4);
-      const float* base = dsum + (int64_t)n_ * h * w * c;
-      o[0] = base[iv.x];
-      o[1] = base[iv.y];
-      o[2] = base[iv.z];
-      o[3] = base[iv.w];
+      const int4 iv = *reinterpret_cast<const int4*>(idx + (size_t)i * 4);
+      const T* base = dsum + (int64_t)n_ * h * w * c;
+      o[0] = Act<T>::gld(base + iv.x);
+      o[1] = Act<T>::gld(base + iv.y);
+      o[2] = Act<T>::gld(base + iv.z);
+      o[3] = Act<T>::gld(base + iv.w);
     }
-    st4(dother + i * 4, o);
+    Act<T>::gst4(dother + (size_t)i * 4, o);
   }
 }
 
@@ -490,9 +494,10 @@ static ssmi_status check_c(int c, const char* who) {
   return SSMI_OK;
 }
 
-ssmi_status launch_bn_bwd_tail(const float* part, int rows, const float* dy, int ld_dy, const float* x, int ld_x,
+template <typename T>
+ssmi_status launch_bn_bwd_tail(const float* part, int rows, const T* dy, int ld_dy, const T* x, int ld_x,
                                const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                               const float* alpha, float slope, const float* drop, int64_t hw, float* dx, float* dgamma,
+                               const float* alpha, float slope, const float* drop, int64_t hw, T* dx, float* dgamma,
                                float* dbeta, float* dalpha, int64_t npix, int c, float* coef, hipStream_t st) {
   ssmi_status e = launch_bn_bwd_final(part, rows, c, npix, gamma, invstd, dgamma, dbeta,
                                       act == SSMI_ACT_PRELU ? dalpha : nullptr, coef, st);
@@ -500,12 +505,18 @@ ssmi_status launch_bn_bwd_tail(const float* part, int rows, const float* dy, int
   const int c4n = c / 4;
   const int64_t total4 = npix * c4n;
   const int nb2 = ew_blocks(total4);
-#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, total4, c4n)
+#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<T, A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, total4, c4n)
   if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
 #undef L2
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
+template ssmi_status launch_bn_bwd_tail<float>(const float*, int, const float*, int, const float*, int, const float*, const float*,
+                                               const float*, const float*, int, const float*, float, const float*, int64_t, float*,
+                                               float*, float*, float*, int64_t, int, float*, hipStream_t);
+template ssmi_status launch_bn_bwd_tail<bf16>(const float*, int, const bf16*, int, const bf16*, int, const float*, const float*,
+                                              const float*, const float*, int, const float*, float, const float*, int64_t, bf16*,
+                                              float*, float*, float*, int64_t, int, float*, hipStream_t);
 
 
 // Inference-phase statistics of EVERY BatchNormalization layer in one launch: the moving statistics live in one arena
@@ -528,21 +539,39 @@ size_t ssmi_bn_workspace_bytes(int64_t npix, int32_t c) {
   return ((size_t)kMaxRedBlocks * 3 + 3) * (size_t)c * sizeof(float);
 }
 
-ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
-                                int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
-                                float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+}  // extern "C" (templates need C++ linkage)
+
+template <typename T>
+static ssmi_status bn_train_stats_impl(const T* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
+                                       int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                       float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
   ssmi_status s = check_c(c, "bn_train_stats");
   if (s) return s;
   SSMI_REQUIRE(x && save_mean && save_invstd && npix > 0 && ld >= c && ld % 4 == 0, SSMI_E_INVALID_ARG, "bn_train_stats: bad argument");
-  SSMI_REQUIRE(npix * ld * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn_train_stats: tensors of 2 GiB or more are not supported");
+  SSMI_REQUIRE(npix * ld * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn_train_stats: tensors of 2^29 elements or more are not supported");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_train_stats: workspace too small");
   const int c4n = c / 4;
   const int nb = red_blocks(npix, c4n);
   float* part = reinterpret_cast<float*>(ws);
-  hipLaunchKernelGGL(bn_stats_partial, dim3(nb), dim3(256), 0, as_stream(stream), x, npix, c4n, ld, part);
+  hipLaunchKernelGGL(bn_stats_partial<T>, dim3(nb), dim3(256), 0, as_stream(stream), x, npix, c4n, ld, part);
   SSMI_LAUNCH_CHECK();
   return launch_bn_stats_final(part, nb, c, npix, eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean,
                                save_invstd, as_stream(stream));
+}
+
+extern "C" {
+
+ssmi_status ssmi_bn_train_stats(const float* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
+                                int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  return bn_train_stats_impl<float>(x, npix, c, ld, eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean,
+                                    save_invstd, ws, ws_bytes, stream);
+}
+ssmi_status ssmi_bn_train_stats_bf16(const uint16_t* x, int64_t npix, int32_t c, int32_t ld, float eps, float momentum,
+                                     int32_t unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
+                                     float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  return bn_train_stats_impl<bf16>(reinterpret_cast<const bf16*>(x), npix, c, ld, eps, momentum, unbiased_moving, moving_mean,
+                                   moving_var, save_mean, save_invstd, ws, ws_bytes, stream);
 }
 
 ssmi_status ssmi_bn_infer_stats_arena(const float* state, const uint8_t* is_var, int64_t count, float eps, float* out,
@@ -564,16 +593,12 @@ ssmi_status ssmi_bn_infer_stats(const float* moving_mean, const float* moving_va
   return SSMI_OK;
 }
 
-ssmi_status ssmi_bn_act_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
-                            const float* beta, int32_t act, const float* alpha, float slope, float* y, int64_t npix,
-                            int32_t c, void* stream) {
-  return ssmi_bn_act_drop_fwd(x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, y, c, npix, c, stream);
-}
+}  // extern "C"
 
-ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd,
-                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
-                                 const float* drop, int64_t hw, float* y, int32_t ld_y, int64_t npix, int32_t c,
-                                 void* stream) {
+template <typename T>
+static ssmi_status bn_act_drop_fwd_impl(const T* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
+                                        const float* beta, int32_t act, const float* alpha, float slope, const float* drop,
+                                        int64_t hw, T* y, int32_t ld_y, int64_t npix, int32_t c, void* stream) {
   ssmi_status s = check_c(c, "bn_act_fwd");
   if (s) return s;
   SSMI_REQUIRE(x && mean && invstd && gamma && beta && y && npix > 0 && ld_x >= c && ld_x % 4 == 0 && ld_y >= c && ld_y % 4 == 0,
@@ -581,11 +606,11 @@ ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_fwd: PReLU needs alpha");
   SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_fwd: npix must be a multiple of hw");
   SSMI_REQUIRE(npix * ld_x * 4 < 0x7FFFFFFFLL && npix * ld_y * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
-               "bn_act_fwd: tensors of 2 GiB or more are not supported");
+               "bn_act_fwd: tensors of 2^29 elements or more are not supported");
   const int c4n = c / 4;
   const int64_t total4 = npix * c4n;
   const int nb = ew_blocks(total4);
-#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, total4, c4n)
+#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, total4, c4n)
   if (act == SSMI_ACT_NONE) L(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L(SSMI_ACT_LEAKY);
   else { set_error("bn_act_fwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L
@@ -593,26 +618,19 @@ ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean
   return SSMI_OK;
 }
 
-ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const float* mean, const float* invstd,
-                            const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
-                            float* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
-                            size_t ws_bytes, void* stream) {
-  return ssmi_bn_act_drop_bwd(dy, c, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, dx, dgamma, dbeta,
-                              dalpha, npix, c, ws, ws_bytes, stream);
-}
-
-ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, const float* mean,
-                                 const float* invstd, const float* gamma, const float* beta, int32_t act,
-                                 const float* alpha, float slope, const float* drop, int64_t hw, float* dx,
-                                 float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
-                                 size_t ws_bytes, void* stream) {
+namespace ssmi {
+template <typename T>
+ssmi_status bn_act_drop_bwd_impl(const T* dy, int32_t ld_dy, const T* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 const float* drop, int64_t hw, T* dx, float* dgamma, float* dbeta, float* dalpha,
+                                 int64_t npix, int32_t c, void* ws, size_t ws_bytes, void* stream) {
   ssmi_status s = check_c(c, "bn_act_bwd");
   if (s) return s;
   SSMI_REQUIRE(dy && x && mean && invstd && gamma && beta && dx && npix > 0 && ld_x >= c && ld_x % 4 == 0 && ld_dy >= c && ld_dy % 4 == 0,
                SSMI_E_INVALID_ARG, "bn_act_bwd: bad argument");
   SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_bwd: npix must be a multiple of hw");
   SSMI_REQUIRE(npix * ld_x * 4 < 0x7FFFFFFFLL && npix * ld_dy * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
-               "bn_act_bwd: tensors of 2 GiB or more are not supported");
+               "bn_act_bwd: tensors of 2^29 elements or more are not supported");
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_bwd: PReLU needs alpha");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_act_bwd: workspace too small");
   const int c4n = c / 4;
@@ -620,22 +638,30 @@ ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x,
   float* part = reinterpret_cast<float*>(ws);
   float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
   hipStream_t st = as_stream(stream);
-#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<A>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, npix, c4n, part)
+#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<T, A>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, npix, c4n, part)
   if (act == SSMI_ACT_NONE) L1(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L1(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L1(SSMI_ACT_LEAKY);
   else { set_error("bn_act_bwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L1
   SSMI_LAUNCH_CHECK();
-  return launch_bn_bwd_tail(part, nb, dy, ld_dy, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx, dgamma,
-                            dbeta, dalpha, npix, c, coef, st);
+  return launch_bn_bwd_tail<T>(part, nb, dy, ld_dy, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx, dgamma,
+                               dbeta, dalpha, npix, c, coef, st);
 }
+template ssmi_status bn_act_drop_bwd_impl<float>(const float*, int32_t, const float*, int32_t, const float*, const float*, const float*,
+                                                 const float*, int32_t, const float*, float, const float*, int64_t, float*, float*,
+                                                 float*, float*, int64_t, int32_t, void*, size_t, void*);
+template ssmi_status bn_act_drop_bwd_impl<bf16>(const bf16*, int32_t, const bf16*, int32_t, const float*, const float*, const float*,
+                                                const float*, int32_t, const float*, float, const float*, int64_t, bf16*, float*,
+                                                float*, float*, int64_t, int32_t, void*, size_t, void*);
+}  // namespace ssmi
 
-static ssmi_status fill_merge(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
-                              const float* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
+static ssmi_status fill_merge(const ssmi_merge_desc* d, const void* main, const ssmi_bn_params* bn3, const float* drop,
+                              const void* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
                               MergeArgs* a) {
   SSMI_REQUIRE(d && main && bn3 && other && alpha, SSMI_E_INVALID_ARG, "merge: NULL argument");
   SSMI_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0, SSMI_E_SHAPE, "merge: bad shape");
+  SSMI_REQUIRE(d->dtype == SSMI_F32 || d->dtype == SSMI_BF16, SSMI_E_UNSUPPORTED, "merge: unknown dtype %d", d->dtype);
   SSMI_REQUIRE((int64_t)d->n * d->h * d->w * d->c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
-               "merge: tensors of 2 GiB or more are not supported");
+               "merge: tensors of 2^29 elements or more are not supported");
   ssmi_status s = check_c(d->c, "merge");
   if (s) return s;
   SSMI_REQUIRE(d->other_mode >= 0 && d->other_mode <= 3, SSMI_E_INVALID_ARG, "merge: other_mode %d", d->other_mode);
@@ -654,21 +680,122 @@ static ssmi_status fill_merge(const ssmi_merge_desc* d, const float* main, const
   return SSMI_OK;
 }
 
-ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const float* main, const ssmi_bn_params* bn3, const float* drop,
-                           const float* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
-                           float* out, void* stream) {
-  MergeArgs a;
-  ssmi_status s = fill_merge(d, main, bn3, drop, other, bn_other, idx, alpha, &a);
-  if (s) return s;
-  SSMI_REQUIRE(out, SSMI_E_INVALID_ARG, "merge_fwd: out is NULL");
+template <typename T>
+static ssmi_status merge_fwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, T* out, void* stream) {
   const int c4n = d->c / 4;
   const int64_t total4 = (int64_t)d->n * d->h * d->w * c4n;
   const int nb = ew_blocks(total4);
-#define L(M) hipLaunchKernelGGL((merge_fwd_kernel<M>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, total4, c4n)
+#define L(M) hipLaunchKernelGGL((merge_fwd_kernel<T, M>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, total4, c4n)
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
+}
+
+template <typename T>
+static ssmi_status merge_bwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, const ssmi_bn_params* bn3, const float* drop,
+                                  const int32_t* idx, const T* dout, T* dmain, T* dsum, T* dother_bn, float* dgamma3,
+                                  float* dbeta3, float* dalpha, void* ws, void* stream) {
+  hipStream_t st = as_stream(stream);
+  const int c = d->c, c4n = c / 4;
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const int nb = red_blocks(npix, c4n);
+  float* part = reinterpret_cast<float*>(ws);
+  float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
+#define L(M) hipLaunchKernelGGL((merge_bwd_reduce<T, M>), dim3(nb), dim3(256), 0, st, a, dout, dsum, npix, c4n, part)
+  switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
+#undef L
+  SSMI_LAUNCH_CHECK();
+  ssmi_status s = launch_bn_bwd_final(part, nb, c, npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
+  if (s) return s;
+  const int64_t total4 = npix * c4n;
+  hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks(total4)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main), bn3->mean,
+                     bn3->invstd, drop, coef, dmain, total4, c4n, (int64_t)d->h * d->w);
+  SSMI_LAUNCH_CHECK();
+  if (d->other_mode >= 2) {
+    const int64_t t4 = (int64_t)d->n * (d->h / 2) * (d->w / 2) * c4n;
+    if (d->other_mode == 2)
+      hipLaunchKernelGGL((merge_bwd_other<T, 2>), dim3(ew_blocks(t4)), dim3(256), 0, st, dsum, idx, dother_bn, d->n, d->h, d->w, c4n, t4);
+    else
+      hipLaunchKernelGGL((merge_bwd_other<T, 3>), dim3(ew_blocks(t4)), dim3(256), 0, st, dsum, idx, dother_bn, d->n, d->h, d->w, c4n, t4);
+    SSMI_LAUNCH_CHECK();
+  }
+  return SSMI_OK;
+}
+
+extern "C" {
+
+ssmi_status ssmi_bn_act_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
+                            const float* beta, int32_t act, const float* alpha, float slope, float* y, int64_t npix,
+                            int32_t c, void* stream) {
+  return bn_act_drop_fwd_impl<float>(x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, y, c, npix, c, stream);
+}
+ssmi_status ssmi_bn_act_fwd_bf16(const uint16_t* x, int32_t ld_x, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, int32_t act, const float* alpha, float slope, uint16_t* y, int64_t npix,
+                                 int32_t c, void* stream) {
+  return bn_act_drop_fwd_impl<bf16>(reinterpret_cast<const bf16*>(x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1,
+                                    reinterpret_cast<bf16*>(y), c, npix, c, stream);
+}
+
+ssmi_status ssmi_bn_act_drop_fwd(const float* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 const float* drop, int64_t hw, float* y, int32_t ld_y, int64_t npix, int32_t c,
+                                 void* stream) {
+  return bn_act_drop_fwd_impl<float>(x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, y, ld_y, npix, c, stream);
+}
+ssmi_status ssmi_bn_act_drop_fwd_bf16(const uint16_t* x, int32_t ld_x, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                      const float* drop, int64_t hw, uint16_t* y, int32_t ld_y, int64_t npix, int32_t c,
+                                      void* stream) {
+  return bn_act_drop_fwd_impl<bf16>(reinterpret_cast<const bf16*>(x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw,
+                                    reinterpret_cast<bf16*>(y), ld_y, npix, c, stream);
+}
+
+ssmi_status ssmi_bn_act_bwd(const float* dy, const float* x, int32_t ld_x, const float* mean, const float* invstd,
+                            const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                            float* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                            size_t ws_bytes, void* stream) {
+  return bn_act_drop_bwd_impl<float>(dy, c, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, dx, dgamma, dbeta,
+                                     dalpha, npix, c, ws, ws_bytes, stream);
+}
+ssmi_status ssmi_bn_act_bwd_bf16(const uint16_t* dy, const uint16_t* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 uint16_t* dx, float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  return bn_act_drop_bwd_impl<bf16>(reinterpret_cast<const bf16*>(dy), c, reinterpret_cast<const bf16*>(x), ld_x, mean, invstd, gamma,
+                                    beta, act, alpha, slope, nullptr, 1, reinterpret_cast<bf16*>(dx), dgamma, dbeta, dalpha, npix, c,
+                                    ws, ws_bytes, stream);
+}
+
+ssmi_status ssmi_bn_act_drop_bwd(const float* dy, int32_t ld_dy, const float* x, int32_t ld_x, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                 const float* alpha, float slope, const float* drop, int64_t hw, float* dx,
+                                 float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                 size_t ws_bytes, void* stream) {
+  return bn_act_drop_bwd_impl<float>(dy, ld_dy, x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx, dgamma, dbeta,
+                                     dalpha, npix, c, ws, ws_bytes, stream);
+}
+ssmi_status ssmi_bn_act_drop_bwd_bf16(const uint16_t* dy, int32_t ld_dy, const uint16_t* x, int32_t ld_x, const float* mean,
+                                      const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                      const float* alpha, float slope, const float* drop, int64_t hw, uint16_t* dx,
+                                      float* dgamma, float* dbeta, float* dalpha, int64_t npix, int32_t c, void* ws,
+                                      size_t ws_bytes, void* stream) {
+  return bn_act_drop_bwd_impl<bf16>(reinterpret_cast<const bf16*>(dy), ld_dy, reinterpret_cast<const bf16*>(x), ld_x, mean, invstd,
+                                    gamma, beta, act, alpha, slope, drop, hw, reinterpret_cast<bf16*>(dx), dgamma, dbeta, dalpha,
+                                    npix, c, ws, ws_bytes, stream);
+}
+
+ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const void* main, const ssmi_bn_params* bn3, const float* drop,
+                           const void* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,
+                           void* out, void* stream) {
+  MergeArgs a;
+  ssmi_status s = fill_merge(d, main, bn3, drop, other, bn_other, idx, alpha, &a);
+  if (s) return s;
+  SSMI_REQUIRE(out, SSMI_E_INVALID_ARG, "merge_fwd: out is NULL");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return merge_fwd_impl<T>(d, a, static_cast<T*>(out), stream);
+  });
 }
 
 size_t ssmi_merge_workspace_bytes(const ssmi_merge_desc* d) {
@@ -676,9 +803,9 @@ size_t ssmi_merge_workspace_bytes(const ssmi_merge_desc* d) {
   return ssmi_bn_workspace_bytes(0, d->c);
 }
 
-ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const float* main, const ssmi_bn_params* bn3,
-                           const float* drop, const float* other, const ssmi_bn_params* bn_other, const int32_t* idx,
-                           const float* alpha, float* dmain, float* dsum, float* dother_bn, float* dgamma3,
+ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const void* dout, const void* main, const ssmi_bn_params* bn3,
+                           const float* drop, const void* other, const ssmi_bn_params* bn_other, const int32_t* idx,
+                           const float* alpha, void* dmain, void* dsum, void* dother_bn, float* dgamma3,
                            float* dbeta3, float* dalpha, void* ws, size_t ws_bytes, void* stream) {
   MergeArgs a;
   ssmi_status s = fill_merge(d, main, bn3, drop, other, bn_other, idx, alpha, &a);
@@ -686,31 +813,11 @@ ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const float* dout, const fl
   SSMI_REQUIRE(dout && dmain && dsum, SSMI_E_INVALID_ARG, "merge_bwd: NULL gradient tensor");
   SSMI_REQUIRE(d->other_mode < 2 || dother_bn, SSMI_E_INVALID_ARG, "merge_bwd: dother_bn required for mode %d", d->other_mode);
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_merge_workspace_bytes(d), SSMI_E_WORKSPACE, "merge_bwd: workspace too small");
-  hipStream_t st = as_stream(stream);
-  const int c = d->c, c4n = c / 4;
-  const int64_t npix = (int64_t)d->n * d->h * d->w;
-  const int nb = red_blocks(npix, c4n);
-  float* part = reinterpret_cast<float*>(ws);
-  float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
-#define L(M) hipLaunchKernelGGL((merge_bwd_reduce<M>), dim3(nb), dim3(256), 0, st, a, dout, dsum, npix, c4n, part)
-  switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
-#undef L
-  SSMI_LAUNCH_CHECK();
-  s = launch_bn_bwd_final(part, nb, c, npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
-  if (s) return s;
-  const int64_t total4 = npix * c4n;
-  hipLaunchKernelGGL(merge_bwd_apply, dim3(ew_blocks(total4)), dim3(256), 0, st, dsum, main, bn3->mean, bn3->invstd, drop,
-                     coef, dmain, total4, c4n, (int64_t)d->h * d->w);
-  SSMI_LAUNCH_CHECK();
-  if (d->other_mode >= 2) {
-    const int64_t t4 = (int64_t)d->n * (d->h / 2) * (d->w / 2) * c4n;
-    if (d->other_mode == 2)
-      hipLaunchKernelGGL((merge_bwd_other<2>), dim3(ew_blocks(t4)), dim3(256), 0, st, dsum, idx, dother_bn, d->n, d->h, d->w, c4n, t4);
-    else
-      hipLaunchKernelGGL((merge_bwd_other<3>), dim3(ew_blocks(t4)), dim3(256), 0, st, dsum, idx, dother_bn, d->n, d->h, d->w, c4n, t4);
-    SSMI_LAUNCH_CHECK();
-  }
-  return SSMI_OK;
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return merge_bwd_impl<T>(d, a, bn3, drop, idx, static_cast<const T*>(dout), static_cast<T*>(dmain), static_cast<T*>(dsum),
+                             static_cast<T*>(dother_bn), dgamma3, dbeta3, dalpha, ws, stream);
+  });
 }
 
 }  // extern "C"

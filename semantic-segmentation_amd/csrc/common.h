@@ -49,7 +49,7 @@ ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t np
 // produces the gradient of the BN's output: the kernel adds per-workgroup column sums of dz, dz*xhat and d*min(z,0) to
 // part[row][3][c] (x == nullptr: disabled).
 struct BnBwdArgs {
-  const float* x;          // raw input of the BN (the producing convolution's output), pixel stride ld
+  const void* x;           // raw input of the BN (the producing convolution's output, activation type), pixel stride ld
   int ld;
   const float *mean, *invstd, *gamma, *beta, *alpha;
   float slope;
@@ -59,15 +59,22 @@ struct BnBwdArgs {
   float* part;
   // forward, inference-phase epilogue only (mean != nullptr): y = act(BN(acc) + skip[pixel * skip_ld + channel]) -
   // the identity-skip merge of a bottleneck folded into its last convolution (skip == nullptr: no addend)
-  const float* skip;
+  const void* skip;        // activation type
   int skip_ld;
 };
 
 // Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.
-ssmi_status launch_bn_bwd_tail(const float* part, int rows, const float* dy, int ld_dy, const float* x, int ld_x,
+template <typename T>
+ssmi_status launch_bn_bwd_tail(const float* part, int rows, const T* dy, int ld_dy, const T* x, int ld_x,
                                const float* mean, const float* invstd, const float* gamma, const float* beta, int act,
-                               const float* alpha, float slope, const float* drop, int64_t hw, float* dx, float* dgamma,
+                               const float* alpha, float slope, const float* drop, int64_t hw, T* dx, float* dgamma,
                                float* dbeta, float* dalpha, int64_t npix, int c, float* coef, hipStream_t stream);
+// BatchNormalization + activation + spatial dropout backward as two plain passes (bn.hip), any activation type
+template <typename T>
+ssmi_status bn_act_drop_bwd_impl(const T* dy, int32_t ld_dy, const T* x, int32_t ld_x, const float* mean, const float* invstd,
+                                 const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                 const float* drop, int64_t hw, T* dx, float* dgamma, float* dbeta, float* dalpha,
+                                 int64_t npix, int32_t c, void* ws, size_t ws_bytes, void* stream);
 
 // Optional per-launch timing (ssmi_profile_begin / _end): while enabled, a ProfileScope brackets ONE kernel launch with
 // HIP events on the launch stream and records the kernel name (set_last_kernel) with its algorithmic bytes and flops.
@@ -105,6 +112,80 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_
 
 __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, 0);   // dropped when out of range
+}
+
+// ------------------------------------------------------------------------------------------------
+// Activation storage types.  Kernels are templated on the element type T of their activation tensors (float or bf16);
+// parameters, statistics, partial sums and all arithmetic stay float32.  Offsets keep the unit the float32 code uses
+// everywhere - BYTES OF A FLOAT32 TENSOR ("off4" = element index * 4) - and the bf16 accessors halve them, so one
+// address computation serves both types.  The out-of-range marker survives the halving: kOOB >> 1 = 2^30 is beyond any
+// bf16 tensor the size checks admit (element counts below 2^29).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned hi16_in_low_half) {
+  return __builtin_bit_cast(float, hi16_in_low_half << 16);
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 w) {
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, w[0] << 16);
+  v[1] = __builtin_bit_cast(float, w[0] & 0xFFFF0000u);
+  v[2] = __builtin_bit_cast(float, w[1] << 16);
+  v[3] = __builtin_bit_cast(float, w[1] & 0xFFFF0000u);
+  return v;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {   // round to nearest even (v_cvt_pk_bf16_f32)
+  const bf16 x = (bf16)a, y = (bf16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, x) | ((unsigned)__builtin_bit_cast(unsigned short, y) << 16);
+}
+__device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) {
+  u32x2 w;
+  w[0] = pack_bf16x2(v[0], v[1]);
+  w[1] = pack_bf16x2(v[2], v[3]);
+  return w;
+}
+
+template <typename T> struct Act;
+template <> struct Act<float> {
+  static constexpr int kDtype = 0;
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes4) { return make_rsrc(p, bytes4); }
+  static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off4) { return bload(r, off4); }
+  static __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off4) { return bload4(r, off4); }
+  static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned off4, float v) { bstore(r, off4, v); }
+  // plain pointers (element index arithmetic done by the caller on T*)
+  static __device__ __forceinline__ float gld(const float* p) { return *p; }
+  static __device__ __forceinline__ f32x4 gld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void gst(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ void gst4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct Act<bf16> {
+  static constexpr int kDtype = 1;
+  static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes4) { return make_rsrc(p, bytes4 >> 1); }
+  static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off4) {
+    return bf16_bits_to_f32((unsigned)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, off4 >> 1, 0, 0));
+  }
+  static __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off4) {
+    return unpack_bf16x4(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off4 >> 1, 0, 0)));
+  }
+  static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned off4, float v) {
+    const bf16 h = (bf16)v;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, off4 >> 1, 0, 0);
+  }
+  static __device__ __forceinline__ float gld(const bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ f32x4 gld4(const bf16* p) { return unpack_bf16x4(*reinterpret_cast<const u32x2*>(p)); }
+  static __device__ __forceinline__ void gst(bf16* p, float v) { *p = (bf16)v; }
+  static __device__ __forceinline__ void gst4(bf16* p, f32x4 v) { *reinterpret_cast<u32x2*>(p) = pack_bf16x4(v); }
+};
+
+// Calls `body` with a value of the activation type selected by an ssmi_dtype code: dispatch_dtype(dt, [&](auto tag) {
+// using T = decltype(tag); ... }).  Unknown codes return SSMI_E_UNSUPPORTED.
+template <typename F>
+static inline ssmi_status dispatch_dtype(int dtype, F&& body) {
+  if (dtype == SSMI_F32) return body(float{});
+  if (dtype == SSMI_BF16) return body(bf16{});
+  set_error("unknown activation dtype %d", dtype);
+  return SSMI_E_UNSUPPORTED;
 }
 
 // Wave-wide (64 lanes) sum.

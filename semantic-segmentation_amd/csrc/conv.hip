@@ -40,17 +40,17 @@ struct Sizes {
 // 74 + 16 / 97 + 32 / 152 + 64 registers (5 / 3 / 2 waves per SIMD) became 74 / 97 / 154 (6 / 4 / 3 waves); ENet step
 // 10.19 -> 10.12 ms, 1024x1024 evaluation 5.06 -> 4.93 ms, SegNet step 59.0 -> 58.3 ms.  The strip and tiled
 // weight-gradient kernels measured slower with such bounds (spills, or no gain) and keep the default.
-template <int NT, bool VEC>
-__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const float* __restrict__ x,
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
-                                                       float* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
+                                                       T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 2 * NT * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   if (tile0 >= M && part == nullptr) return;   // with statistics every wave reaches the barrier (its rows are masked)
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
+  const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
   const unsigned p = (unsigned)tile0 + (unsigned)r;       // M < 2^31: 32-bit pixel arithmetic
   const bool pv = p < (unsigned)M;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
     auto fetch = [&](f32x4& a, float (&b)[4][NT]) {
       // valid offsets are below 2^31, so OR-ing bit 31 in (kOOB) is the out-of-range mask: no compare/select per load
       const unsigned cib = (unsigned)(c0 + 4 * hh);
-      a = bload4(rx, (xo + cib * 4u) | (xo & kOOB));
+      a = Act<T>::ld4(rx, (xo + cib * 4u) | (xo & kOOB));
       const unsigned wb = wtap + cib * wrow, wm = wtap & kOOB;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
         for (int c0 = 0; c0 < g.cin; c0 += 2) {
           const int ci = c0 + hh;
           const bool cv = ci < g.cin;
-          const float a = bload(rx, cv ? xo + (unsigned)ci * 4u : kOOB);
+          const float a = Act<T>::ld(rx, cv ? xo + (unsigned)ci * 4u : kOOB);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const float b = bload(rw, cv ? wtap + (unsigned)ci * wrow + wcol[t] : kOOB);
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
   }
 
   // branch-free epilogue: rows past the end and masked columns get an out-of-range offset, which the store drops
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(y, sz.y_bytes);
+  const __amdgpu_buffer_rsrc_t ry = Act<T>::rsrc(y, sz.y_bytes);
   unsigned rowoff[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -184,22 +184,22 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
       const float al = bn.act == SSMI_ACT_PRELU ? bn.alpha[cc] : bn.slope;
       float sk[16];
       if (bn.skip) {   // uniform; stride 1: the skip tensor has the output's pixel grid
-        const __amdgpu_buffer_rsrc_t rsk = make_rsrc(bn.skip, (unsigned)(M * bn.skip_ld * 4));
+        const __amdgpu_buffer_rsrc_t rsk = Act<T>::rsrc(bn.skip, (unsigned)(M * bn.skip_ld * 4));
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
-          sk[i] = bload(rsk, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bn.skip_ld + (unsigned)c) * 4u : kOOB);
+          sk[i] = Act<T>::ld(rsk, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bn.skip_ld + (unsigned)c) * 4u : kOOB);
         }
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         float z = ga * (((acc[t][i] + bv) - mu) * is) + be;
         if (bn.skip) z += sk[i];
-        bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, (bn.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
+        Act<T>::st(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, (bn.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) bstore(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
+      for (int i = 0; i < 16; ++i) Act<T>::st(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
     }
     if (part) {   // per-wave column sums of y and y^2 over the valid rows (BatchNormalization statistics)
       float s1 = 0.f, s2 = 0.f;
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
 // blockIdx.z enumerates the stride x stride phases (iy % stride, ix % stride) so the set of contributing taps is
 // uniform inside a block.  VEC (cout % 8 == 0): 16-byte loads along co for both dy and the kernel.
 // ---------------------------------------------------------------------------------------------------
-template <int NT, bool VEC>
-__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_bwd_data_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
+template <typename T, int NT, bool VEC>
+__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_bwd_data_kernel(Geo g, Sizes sz, const T* __restrict__ dy,
                                                             const float* __restrict__ w,
-                                                            const float* __restrict__ add,
-                                                            const float* __restrict__ bias, float* __restrict__ dx,
+                                                            const T* __restrict__ add,
+                                                            const float* __restrict__ bias, T* __restrict__ dx,
                                                             BnBwdArgs bb) {
   __shared__ float bb_sm[4 * 3 * NT * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_b
   const int64_t M = (int64_t)g.n * qh * qw;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
   if (tile0 >= M && bb.x == nullptr) return;   // with the fused BN backward every wave reaches the barrier
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
+  const __amdgpu_buffer_rsrc_t ry = Act<T>::rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
 
   const unsigned p = (unsigned)tile0 + (unsigned)r;       // M < 2^31: 32-bit pixel arithmetic
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_b
     }
     auto fetch = [&](f32x4& a, f32x4 (&b)[NT]) {
       const unsigned co4 = (unsigned)(c0 + 4 * hh) * 4u;
-      a = bload4(ry, (yo + co4) | (yo & kOOB));     // bit 31 of an invalid base is carried over: out of range
+      a = Act<T>::ld4(ry, (yo + co4) | (yo & kOOB));     // bit 31 of an invalid base is carried over: out of range
       const unsigned wb = wtap + co4, wm = wtap & kOOB;
 #pragma unroll
       for (int t = 0; t < NT; ++t) b[t] = bload4(rw, (wb + wcir[t]) | wm | wcim[t]);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_b
         for (int c0 = 0; c0 < g.cout; c0 += 2) {
           const int co = c0 + hh;
           const bool cv = co < g.cout;
-          const float a = bload(ry, cv ? yo + (unsigned)co * 4u : kOOB);
+          const float a = Act<T>::ld(ry, cv ? yo + (unsigned)co * 4u : kOOB);
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const float b = bload(rw, cv ? wtap + wci[t] + (unsigned)co * 4u : kOOB);
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_b
 
   // branch-free epilogue: every skip-gradient load is issued before the first store; rows past the end and masked
   // columns use an out-of-range offset (loads return 0, stores are dropped)
-  const __amdgpu_buffer_rsrc_t rdx = make_rsrc(dx, sz.x_bytes);
-  const __amdgpu_buffer_rsrc_t radd = make_rsrc(add ? add : dx, add ? sz.x_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rdx = Act<T>::rsrc(dx, sz.x_bytes);
+  const __amdgpu_buffer_rsrc_t radd = Act<T>::rsrc(add ? add : dx, add ? sz.x_bytes : 0u);
   unsigned rowoff[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -420,19 +420,19 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_b
     const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cin * 4u), colv[t] ? (unsigned)c * 4u : kOOB) : 0.f;
     float av[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) av[i] = bload(radd, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB);
+    for (int i = 0; i < 16; ++i) av[i] = Act<T>::ld(radd, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bstore(rdx, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv + av[i]);
+    for (int i = 0; i < 16; ++i) Act<T>::st(rdx, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv + av[i]);
     if (bb.x) {   // uniform; stride 1: the output pixel index is the row index
       const int cc = colv[t] ? c : 0;
       const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
       const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
-      const __amdgpu_buffer_rsrc_t rbx = make_rsrc(bb.x, (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4));
+      const __amdgpu_buffer_rsrc_t rbx = Act<T>::rsrc(bb.x, (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4));
       float xr[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
-        xr[i] = bload(rbx, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)c) * 4u : kOOB);
+        xr[i] = Act<T>::ld(rbx, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)c) * 4u : kOOB);
       }
       float s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -506,10 +506,10 @@ struct GemmArgs {
 };
 static constexpr int kMaxTaps = 32;
 
-template <bool M16, int MT, int NT, bool VEC, int D, bool TILE>
-__global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const float* __restrict__ in,
+template <typename T, bool M16, int MT, int NT, bool VEC, int D, bool TILE>
+__global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a, const T* __restrict__ in,
                                                      const float* __restrict__ w, const float* __restrict__ bias,
-                                                     const float* __restrict__ add, float* __restrict__ out,
+                                                     const T* __restrict__ add, T* __restrict__ out,
                                                      float* __restrict__ part, BnBwdArgs bb) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int TS = M16 ? 16 : 32;
@@ -626,11 +626,11 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   const int nvt = tab[0];
   const int K = nvt * a.C_r;
   const int nblk = (K + KB - 1) / KB;
-  const __amdgpu_buffer_rsrc_t rin = make_rsrc(in, bwd ? sz.y_bytes : sz.x_bytes);
+  const __amdgpu_buffer_rsrc_t rin = Act<T>::rsrc(in, bwd ? sz.y_bytes : sz.x_bytes);
   const unsigned out_bytes = bwd ? sz.x_bytes : sz.y_bytes;
-  const __amdgpu_buffer_rsrc_t rout = make_rsrc(out, out_bytes);
-  const __amdgpu_buffer_rsrc_t radd = make_rsrc(add ? add : out, add ? out_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? bias : out, bias ? (unsigned)a.C_o * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rout = Act<T>::rsrc(out, out_bytes);
+  const __amdgpu_buffer_rsrc_t radd = Act<T>::rsrc(add ? add : out, add ? out_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(bias ? (const void*)bias : (const void*)out, bias ? (unsigned)a.C_o * 4u : 0u);
   const int sm_ = bwd ? 1 : s;       // input coordinate = q * sm_ + tap offset
   const int64_t M = (int64_t)g.n * qh * qw;
   const int64_t ngroups = (M + MT * TS - 1) / (MT * TS);
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   float st1[NT], st2[NT], st3[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) st1[t] = st2[t] = st3[t] = 0.f;
-  const __amdgpu_buffer_rsrc_t rbx = make_rsrc(bb.x ? bb.x : out, bb.x ? (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t rbx = Act<T>::rsrc(bb.x ? bb.x : (const void*)out, bb.x ? (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4) : 0u);
 
   static_assert(!TILE || (MT * TS == 64 && NT == 1 && VEC), "tile variant: 64 pixels per wave, one column tile");
   float* patch = smem + a.patch_off;
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
             const bool ev = e0 + u * 256 < elements;
             const int gy = gy0 + py, gx = gx0 + px;
             const bool ok = ev && (unsigned)gy < (unsigned)a.in_h && (unsigned)gx < (unsigned)a.in_w;
-            v[u] = bload4(rin, ok ? ((unsigned)((n_t * a.in_h + gy) * a.in_w + gx) * (unsigned)a.in_ld + (unsigned)(c4 * 4)) * 4u : kOOB);
+            v[u] = Act<T>::ld4(rin, ok ? ((unsigned)((n_t * a.in_h + gy) * a.in_w + gx) * (unsigned)a.in_ld + (unsigned)(c4 * 4)) * 4u : kOOB);
             dw_[u] = ev ? (py * a.PW + px) * a.CP + c4 * 4 : -1;
             c4 += dc4;
             if (c4 >= C4) { c4 -= C4; ++px; }
@@ -769,8 +769,8 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
           const int iy = by[m] + ty, ix = bx[m] + tx;
           const bool ok = tv && pv[m] && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
           const unsigned off = ok ? pbase[m] + toff : kOOB;
-          if (VEC) Ab[m] = bload4(rin, off);
-          else Ab[m][0] = bload(rin, off);
+          if (VEC) Ab[m] = Act<T>::ld4(rin, off);
+          else Ab[m][0] = Act<T>::ld(rin, off);
         }
       }
       tapi += a.q_blk;
@@ -833,21 +833,21 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int i = 0; i < NR; ++i) av[m][i] = bload(radd, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB);
+        for (int i = 0; i < NR; ++i) av[m][i] = Act<T>::ld(radd, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB);
       if (!bwd && bb.mean) {   // uniform; inference-phase forward: BatchNormalization (fixed statistics) + activation
         const int cc = cv ? col : 0;
         const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
         const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
         float sk[MT][NR];
         if (bb.skip) {   // uniform; the skip tensor has the output's pixel grid
-          const __amdgpu_buffer_rsrc_t rsk = make_rsrc(bb.skip, (unsigned)(M * bb.skip_ld * 4));
+          const __amdgpu_buffer_rsrc_t rsk = Act<T>::rsrc(bb.skip, (unsigned)(M * bb.skip_ld * 4));
 #pragma unroll
           for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
               const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
               const unsigned po = row_pixel(m, row);
-              sk[m][i] = bload(rsk, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.skip_ld + (unsigned)col) * 4u : kOOB);
+              sk[m][i] = Act<T>::ld(rsk, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.skip_ld + (unsigned)col) * 4u : kOOB);
             }
         }
 #pragma unroll
@@ -856,14 +856,14 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
           for (int i = 0; i < NR; ++i) {
             float z = ga * (((acc[m][t][i] + bvv) - mu) * is) + be;
             if (bb.skip) z += sk[m][i];
-            bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, (bb.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
+            Act<T>::st(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, (bb.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
           }
       } else {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
           for (int i = 0; i < NR; ++i)
-            bstore(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, acc[m][t][i] + bvv + av[m][i]);
+            Act<T>::st(rout, cv ? rowoff[m][i] + (unsigned)col * 4u : kOOB, acc[m][t][i] + bvv + av[m][i]);
       }
       if (part) {
 #pragma unroll
@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
           for (int i = 0; i < NR; ++i) {
             const int row = M16 ? kq * 4 + i : (i & 3) + 8 * (i >> 2) + 4 * kq;
             const unsigned po = row_pixel(m, row);
-            xr[m][i] = bload(rbx, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)col) * 4u : kOOB);
+            xr[m][i] = Act<T>::ld(rbx, (cv && rowoff[m][i] != kOOB) ? (po * (unsigned)bb.ld + (unsigned)col) * 4u : kOOB);
           }
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -959,9 +959,9 @@ struct WgArgs {
   int nstrips, rows_per_strip;
 };
 
-template <int TPW>
-__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, Sizes sz, WgArgs a, const float* __restrict__ x,
-                                                              const float* __restrict__ dy, float* __restrict__ part) {
+template <typename T, int TPW>
+__global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, Sizes sz, WgArgs a, const T* __restrict__ x,
+                                                              const T* __restrict__ dy, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int spb = 4 / a.wps;
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, Sizes sz, W
   const int widx = wave % a.wps;
   if (strip >= a.nstrips || wave >= spb * a.wps) return;
   const int tile0 = blockIdx.y * (a.wps * TPW) + widx;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), ry = make_rsrc(dy, sz.y_bytes);
+  const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), ry = Act<T>::rsrc(dy, sz.y_bytes);
 
   bool tv[TPW], kv[TPW], kb[TPW], colv[TPW];
   int kyd[TPW], kxd[TPW], kt_[TPW], col[TPW];
@@ -1034,9 +1034,9 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_kernel(Geo g, Sizes sz, W
       for (int j = 0; j < TPW; ++j) {
         const int ix = ox * g.stride + kxd[j];
         const bool xv = yv[j] && ov && (unsigned)ix < (unsigned)g.w;
-        const float t = bload(rx, xv ? xrow[j] + (unsigned)ix * xpix : kOOB);
+        const float t = Act<T>::ld(rx, xv ? xrow[j] + (unsigned)ix * xpix : kOOB);
         av[u][j] = kb[j] ? (ov ? 1.f : 0.f) : t;
-        bv[u][j] = bload(ry, ov ? dyrow + (unsigned)ox * ypix + colb[j] : kOOB);
+        bv[u][j] = Act<T>::ld(ry, ov ? dyrow + (unsigned)ox * ypix + colb[j] : kOOB);
       }
     }
   };
@@ -1087,9 +1087,9 @@ static constexpr int kXvMax = 12, kYvMax = 8;
 
 // M16: 16x16 output tiles on v_mfma_f32_16x16x4_f32 (4 pixels per step) for cout <= 16, where 32-wide tiles would
 // spend half or more of the matrix core on padding columns.
-template <int TPW, bool VEC, bool M16>
-__global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgArgs a, WgLds l, const float* __restrict__ x,
-                                                           const float* __restrict__ dy, float* __restrict__ part) {
+template <typename T, int TPW, bool VEC, bool M16>
+__global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgArgs a, WgLds l, const T* __restrict__ x,
+                                                           const T* __restrict__ dy, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
   const int r = lane & (TS - 1), hh = lane / TS;
   const int strip = blockIdx.x;
   const int tile0 = blockIdx.y * (a.wps * TPW) + wave;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), ry = make_rsrc(dy, sz.y_bytes);
+  const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), ry = Act<T>::rsrc(dy, sz.y_bytes);
   constexpr int EW = VEC ? 4 : 1;   // floats per staged element
 
   // ---- per-lane MFMA operand addressing (fixed for the whole kernel) ----
@@ -1194,8 +1194,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
         const int iy = iy0 + x_kyd[i], ix = ix0 + x_colp[i];
         const bool ok = cv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
         const unsigned off = ok ? (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i] : kOOB;
-        if (VEC) xr[i] = bload4(rx, off);
-        else xr[i][0] = bload(rx, off);
+        if (VEC) xr[i] = Act<T>::ld4(rx, off);
+        else xr[i][0] = Act<T>::ld(rx, off);
       }
     }
 #pragma unroll
@@ -1203,8 +1203,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
       if (i < l.yv_n) {
         const bool ok = cv && y_p[i] < pv;
         const unsigned off = ok ? (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i] : kOOB;
-        if (VEC) yr[i] = bload4(ry, off);
-        else yr[i][0] = bload(ry, (ok && (y_rel[i] >> 2) < (unsigned)g.cout) ? off : kOOB);
+        if (VEC) yr[i] = Act<T>::ld4(ry, off);
+        else yr[i][0] = Act<T>::ld(ry, (ok && (y_rel[i] >> 2) < (unsigned)g.cout) ? off : kOOB);
       }
     }
   };
@@ -1310,8 +1310,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __res
 
 // column sums of a [npix, c] matrix with row stride ld (bias gradient of a transposed convolution).
 // VEC (c % 4 == 0, ld % 4 == 0): thread = (pixel lane, group of 4 channels), 16-byte loads, grid-stride over pixels.
-template <bool VEC>
-__global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ x, int64_t npix, int c, int ld,
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void colsum_partial(const T* __restrict__ x, int64_t npix, int c, int ld,
                                                       float* __restrict__ part) {
   constexpr int EW = VEC ? 4 : 1;
   const int ce = c / EW;                 // elements per pixel
@@ -1324,16 +1324,16 @@ __global__ __launch_bounds__(256) void colsum_partial(const float* __restrict__ 
     int64_t p = (int64_t)blockIdx.x * ppi + pl;
     for (; p + stride < npix; p += 2 * stride) {
       if (VEC) {
-        s0 += *reinterpret_cast<const f32x4*>(x + p * ld + cc * 4);
-        s1 += *reinterpret_cast<const f32x4*>(x + (p + stride) * ld + cc * 4);
+        s0 += Act<T>::gld4(x + p * ld + cc * 4);
+        s1 += Act<T>::gld4(x + (p + stride) * ld + cc * 4);
       } else {
-        s0[0] += x[p * ld + cc];
-        s1[0] += x[(p + stride) * ld + cc];
+        s0[0] += Act<T>::gld(x + p * ld + cc);
+        s1[0] += Act<T>::gld(x + (p + stride) * ld + cc);
       }
     }
     if (p < npix) {
-      if (VEC) s0 += *reinterpret_cast<const f32x4*>(x + p * ld + cc * 4);
-      else s0[0] += x[p * ld + cc];
+      if (VEC) s0 += Act<T>::gld4(x + p * ld + cc * 4);
+      else s0[0] += Act<T>::gld(x + p * ld + cc);
     }
   }
   sm[threadIdx.x] = (pl < ppi) ? s0 + s1 : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1372,6 +1372,7 @@ static ssmi_status check_desc(const ssmi_conv_desc* d) {
   SSMI_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->dil > 0 && d->pad_t >= 0 && d->pad_l >= 0, SSMI_E_SHAPE,
                "conv desc: bad kernel/stride/dilation/pad");
   SSMI_REQUIRE(d->x_ld >= d->cin && d->y_ld >= d->cout, SSMI_E_SHAPE, "conv desc: leading dimension < channels");
+  SSMI_REQUIRE(d->dtype == SSMI_F32 || d->dtype == SSMI_BF16, SSMI_E_UNSUPPORTED, "conv desc: unknown dtype %d", d->dtype);
   // every output position must read at least ... nothing to check; but the output extent must not exceed what the
   // padded input can produce
   const int64_t need_h = (int64_t)(d->ho - 1) * d->stride + (int64_t)(d->kh - 1) * d->dil + 1 - d->pad_t;
@@ -1382,11 +1383,11 @@ static ssmi_status check_desc(const ssmi_conv_desc* d) {
   return SSMI_OK;
 }
 
-// Algorithmic work of one launch (fp32): forward reads x and the kernel and writes y; the data gradient reads dy, the
+// Algorithmic work of one launch (activations of act_size bytes, float32 kernel): forward reads x and the kernel and writes y; the data gradient reads dy, the
 // kernel and the fused addend and writes dx.  flops = 2 * output pixels * taps * cin * cout.
-static double conv_bytes(const Geo& g, bool with_add) {
+static double conv_bytes(const Geo& g, bool with_add, size_t act_size) {
   const double xin = (double)g.n * g.h * g.w * g.cin, yout = (double)g.n * g.ho * g.wo * g.cout;
-  return 4.0 * (xin + yout + (double)g.kh * g.kw * g.cin * g.cout + (with_add ? xin : 0.0));
+  return (double)act_size * (xin + yout + (with_add ? xin : 0.0)) + 4.0 * (double)g.kh * g.kw * g.cin * g.cout;
 }
 static double conv_flops(const Geo& g) {
   return 2.0 * g.n * g.ho * g.wo * (double)g.kh * g.kw * g.cin * g.cout;
@@ -1418,8 +1419,9 @@ static int conv_kernel_override() {
   return force;
 }
 
-static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float* in, const float* w, const float* bias,
-                            const float* add, float* out, hipStream_t st, ssmi_status* status, float* part = nullptr,
+template <typename T>
+static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in, const float* w, const float* bias,
+                            const T* add, T* out, hipStream_t st, ssmi_status* status, float* part = nullptr,
                             int* part_rows = nullptr, BnBwdArgs bb = BnBwdArgs{}) {
   GemmArgs a;
   a.mode = mode;
@@ -1493,7 +1495,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
   hipError_t attr_err = hipSuccess;
 #define LG(M16_, MT_, NT_, V_, D_, T_)                                                                                      \
   do {                                                                                                                      \
-    auto kfn = conv_gemm_lds<M16_, MT_, NT_, V_, D_, T_>;                                                                   \
+    auto kfn = conv_gemm_lds<T, M16_, MT_, NT_, V_, D_, T_>;                                                                   \
     if (lds > 64 * 1024)                                                                                                    \
       attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, g, sz, a, in, w, bias, add, out, part, bb);                           \
@@ -1535,20 +1537,21 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const float
 
 // part != nullptr: the kernel also writes per-workgroup column sums of y and y^2, part[row][2][cout]; *part_rows = rows.
 // bn.mean != nullptr: inference-phase BatchNormalization + activation applied in the epilogue (bn.x stays nullptr).
-static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, const float* bias, float* y,
+template <typename T>
+static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const float* bias, T* y,
                               hipStream_t st, float* part = nullptr, int* part_rows = nullptr, BnBwdArgs bn = BnBwdArgs{}) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
-  ProfileScope prof(st, conv_bytes(g, false), conv_flops(g));
-  if (launch_gemm_lds(g, sz, 0, x, w, bias, nullptr, y, st, &e, part, part_rows, bn)) return e;
+  ProfileScope prof(st, conv_bytes(g, false, sizeof(T)), conv_flops(g));
+  if (launch_gemm_lds<T>(g, sz, 0, x, w, bias, (const T*)nullptr, y, st, &e, part, part_rows, bn)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   set_last_kernel("conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
-#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn)
+#define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<T, NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
   } else {
@@ -1569,11 +1572,11 @@ static ssmi_status launch_fwd(const Geo& g, const float* x, const float* w, cons
 // A wave owns 32 dy pixels x NT*32 columns: dy is read once (not once per phase), and for x_ld == cin the columns of
 // one output row (a fixed) are 2*cin contiguous floats, so a store instruction writes 128 contiguous bytes.
 // ---------------------------------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_bwd_data_2x2s2_kernel(Geo g, Sizes sz, const float* __restrict__ dy,
+template <typename T, int NT>
+__global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_bwd_data_2x2s2_kernel(Geo g, Sizes sz, const T* __restrict__ dy,
                                                                   const float* __restrict__ w,
-                                                                  const float* __restrict__ add,
-                                                                  const float* __restrict__ bias, float* __restrict__ dx) {
+                                                                  const T* __restrict__ add,
+                                                                  const float* __restrict__ bias, T* __restrict__ dx) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const unsigned M = (unsigned)(g.n * g.ho * g.wo);
@@ -1581,7 +1584,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_b
   if (tile0 >= M) return;
   const int N = 4 * g.cin;
   const int jbase = blockIdx.y * 32 * NT;
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
+  const __amdgpu_buffer_rsrc_t ry = Act<T>::rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
   const unsigned p = tile0 + (unsigned)r;
   const unsigned yo = p < M ? p * (unsigned)g.y_ld * 4u : kOOB;
   unsigned wo_[NT];
@@ -1600,7 +1603,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_b
   // reduction over cout in blocks of 8 (lane half hh takes channels 4*hh.. of the block for A and B alike)
   auto fetch = [&](int k0, f32x4& a, f32x4 (&b)[NT]) {
     const unsigned ko = k0 < g.cout ? (unsigned)(k0 + 4 * hh) * 4u : kOOB;
-    a = bload4(ry, (yo + ko) | ((yo | ko) & kOOB));
+    a = Act<T>::ld4(ry, (yo + ko) | ((yo | ko) & kOOB));
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = bload4(rw, (wo_[t] + ko) | ((wo_[t] | ko) & kOOB));
   };
@@ -1619,8 +1622,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_b
     if (k0 + 8 < g.cout) mma(a1, b1);
   }
   // epilogue: dx pixel of (p, a, b) = 4p - 2x + a*W + b  (W = 2*wo; x = p mod wo)
-  const __amdgpu_buffer_rsrc_t rdx = make_rsrc(dx, sz.x_bytes);
-  const __amdgpu_buffer_rsrc_t radd = make_rsrc(add ? add : dx, add ? sz.x_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rdx = Act<T>::rsrc(dx, sz.x_bytes);
+  const __amdgpu_buffer_rsrc_t radd = Act<T>::rsrc(add ? add : dx, add ? sz.x_bytes : 0u);
   const unsigned x0 = tile0 % (unsigned)g.wo;
   unsigned rowpix[16];
 #pragma unroll
@@ -1643,18 +1646,19 @@ __global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_b
       o[i] = (jv[t] && rowpix[i] != 0xFFFFFFFFu) ? ((rowpix[i] + coff) * (unsigned)g.x_ld + (unsigned)ci) * 4u : kOOB;
     float av[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) av[i] = bload(radd, o[i]);
+    for (int i = 0; i < 16; ++i) av[i] = Act<T>::ld(radd, o[i]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) bstore(rdx, o[i], acc[t][i] + bv + av[i]);
+    for (int i = 0; i < 16; ++i) Act<T>::st(rdx, o[i], acc[t][i] + bv + av[i]);
   }
 }
 
-static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w, const float* add, const float* bias,
-                                   float* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr) {
+template <typename T>
+static ssmi_status launch_bwd_data(const Geo& g, const T* dy, const float* w, const T* add, const float* bias,
+                                   T* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
-  ProfileScope prof(st, conv_bytes(g, add != nullptr), conv_flops(g));
+  ProfileScope prof(st, conv_bytes(g, add != nullptr, sizeof(T)), conv_flops(g));
   if (g.kh == 2 && g.kw == 2 && g.stride == 2 && g.dil == 1 && g.pad_t == 0 && g.pad_l == 0 && g.h == 2 * g.ho &&
       g.w == 2 * g.wo && g.cout % 8 == 0 && g.y_ld % 4 == 0 && bb.x == nullptr && part_rows == nullptr &&
       ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(w)) & 15) == 0 && conv_kernel_override() == 0) {
@@ -1663,13 +1667,13 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
     const int64_t M = (int64_t)g.n * g.ho * g.wo;
     dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((N + 32 * nt - 1) / (32 * nt)), 1);
     set_last_kernel("conv_bwd_data_2x2s2_kernel<%d>", nt);
-#define L(NT) hipLaunchKernelGGL((conv_bwd_data_2x2s2_kernel<NT>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx)
+#define L(NT) hipLaunchKernelGGL((conv_bwd_data_2x2s2_kernel<T, NT>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx)
     if (nt == 1) L(1); else if (nt == 2) L(2); else if (nt == 3) L(3); else L(4);
 #undef L
     SSMI_LAUNCH_CHECK();
     return SSMI_OK;
   }
-  if (launch_gemm_lds(g, sz, 1, dy, w, bias, add, dx, st, &e, nullptr, part_rows, bb)) return e;
+  if (launch_gemm_lds<T>(g, sz, 1, dy, w, bias, add, dx, st, &e, nullptr, part_rows, bb)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.h * g.w, 128);
   const int s = g.stride;
   const int qh = (g.h + s - 1) / s, qw = (g.w + s - 1) / s;
@@ -1679,7 +1683,7 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
   const bool vec = (g.cout % 8 == 0) && (g.y_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
   set_last_kernel("conv_bwd_data_kernel<%d, %s>", nt, vec ? "true" : "false");
-#define L(NT, V) hipLaunchKernelGGL((conv_bwd_data_kernel<NT, V>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx, bb)
+#define L(NT, V) hipLaunchKernelGGL((conv_bwd_data_kernel<T, NT, V>), grid, dim3(256), 0, st, g, sz, dy, w, add, bias, dx, bb)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
   } else {
@@ -1699,9 +1703,9 @@ static ssmi_status launch_bwd_data(const Geo& g, const float* dy, const float* w
 // once per 12 tiles.  The bias gradient (column sums of dy) is accumulated by the waves of the first k-tile.
 // Partial sums per pixel share: part[share][K_aug][cout], reduced by conv_bwd_weight_reduce.
 // ---------------------------------------------------------------------------------------------------
-template <int WK, int WC>
+template <typename T, int WK, int WC>
 __global__ __launch_bounds__(256) void conv_bwd_weight_tiled(Geo g, Sizes sz, int K, int K_aug, int chunks_per_share,
-                                                             const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const T* __restrict__ x, const T* __restrict__ dy,
                                                              float* __restrict__ part) {
   static_assert(WK * WC == 4, "four waves per workgroup");
   constexpr int TK = WK * 64, TC = WC * 64, P = 32;
@@ -1714,7 +1718,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_tiled(Geo g, Sizes sz, in
   const int r = lane & 31, hh = lane >> 5;
   const int wk = wave % WK, wc = wave / WK;
   const int k0 = blockIdx.x * TK, c0 = blockIdx.y * TC;
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, sz.x_bytes), ry = make_rsrc(dy, sz.y_bytes);
+  const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), ry = Act<T>::rsrc(dy, sz.y_bytes);
   const unsigned M = (unsigned)(g.n * g.ho * g.wo);
   const int nchunks = (int)((M + P - 1) / P);
   const int ch0 = blockIdx.z * chunks_per_share;
@@ -1746,12 +1750,12 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_tiled(Geo g, Sizes sz, in
       const int oy = (int)(t1 - n_ * (unsigned)g.ho);
       const int iy = oy * g.stride + offy, ix = ox * g.stride + offx;
       const bool ok = pv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
-      ra[j] = bload4(rx, ok ? (((n_ * (unsigned)g.h + (unsigned)iy) * (unsigned)g.w + (unsigned)ix) * (unsigned)g.x_ld + (unsigned)ci) * 4u : kOOB);
+      ra[j] = Act<T>::ld4(rx, ok ? (((n_ * (unsigned)g.h + (unsigned)iy) * (unsigned)g.w + (unsigned)ix) * (unsigned)g.x_ld + (unsigned)ci) * 4u : kOOB);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const unsigned pix = (unsigned)ch * P + (unsigned)(pb0 + j * PB);
-      rb[j] = bload4(ry, (cv && covalid && pix < M) ? (pix * (unsigned)g.y_ld + (unsigned)co) * 4u : kOOB);
+      rb[j] = Act<T>::ld4(ry, (cv && covalid && pix < M) ? (pix * (unsigned)g.y_ld + (unsigned)co) * 4u : kOOB);
     }
   };
 
@@ -1921,7 +1925,8 @@ static size_t wg_ws_bytes(const Geo& g) {
   return t.use && t.bytes > b ? t.bytes : b;      // the strip kernels remain the fallback for unaligned pointers
 }
 
-static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* dy, float* dw, float* dbias, void* ws,
+template <typename T>
+static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, float* dw, float* dbias, void* ws,
                                      size_t ws_bytes, hipStream_t st) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
@@ -1934,10 +1939,10 @@ static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* 
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((unsigned)t.ktiles, (unsigned)t.ctiles, (unsigned)t.shares);
     if (t.wk == 2)
-      hipLaunchKernelGGL((conv_bwd_weight_tiled<2, 2>), grid, dim3(256), (size_t)32 * 256 * 4, st, g, sz, t.K, t.K_aug,
+      hipLaunchKernelGGL((conv_bwd_weight_tiled<T, 2, 2>), grid, dim3(256), (size_t)32 * 256 * 4, st, g, sz, t.K, t.K_aug,
                          t.chunks_per_share, x, dy, part);
     else
-      hipLaunchKernelGGL((conv_bwd_weight_tiled<4, 1>), grid, dim3(256), (size_t)32 * 320 * 4, st, g, sz, t.K, t.K_aug,
+      hipLaunchKernelGGL((conv_bwd_weight_tiled<T, 4, 1>), grid, dim3(256), (size_t)32 * 320 * 4, st, g, sz, t.K, t.K_aug,
                          t.chunks_per_share, x, dy, part);
     SSMI_LAUNCH_CHECK();
     const int E = t.K_aug * g.cout;
@@ -1953,14 +1958,14 @@ static ssmi_status launch_bwd_weight(const Geo& g, const float* x, const float* 
   dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
   if (p.use_lds) {
     const size_t lds = (size_t)p.l.lds_words * 4;
-#define LL(TPW, V, M) hipLaunchKernelGGL((conv_bwd_weight_lds<TPW, V, M>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part)
+#define LL(TPW, V, M) hipLaunchKernelGGL((conv_bwd_weight_lds<T, TPW, V, M>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part)
 #define LT(V, M) do { if (p.tpw == 1) LL(1, V, M); else if (p.tpw == 2) LL(2, V, M); else LL(3, V, M); } while (0)
     if (p.vec) { if (p.m16) LT(true, true); else LT(true, false); }
     else { if (p.m16) LT(false, true); else LT(false, false); }
 #undef LT
 #undef LL
   } else {
-#define L(TPW) hipLaunchKernelGGL((conv_bwd_weight_kernel<TPW>), grid, dim3(256), 0, st, g, sz, p.a, x, dy, part)
+#define L(TPW) hipLaunchKernelGGL((conv_bwd_weight_kernel<T, TPW>), grid, dim3(256), 0, st, g, sz, p.a, x, dy, part)
     if (p.tpw == 1) L(1); else if (p.tpw == 2) L(2); else L(3);
 #undef L
   }
@@ -1989,17 +1994,20 @@ ssmi_status ssmi_same_pad(int32_t in, int32_t k, int32_t stride, int32_t dil, in
   return SSMI_OK;
 }
 
-ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+ssmi_status ssmi_conv2d_fwd(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                             void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(x && w && y, SSMI_E_INVALID_ARG, "conv2d_fwd: NULL tensor");
-  return launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream));
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_fwd<T>(to_geo(d), static_cast<const T*>(x), w, bias, static_cast<T*>(y), as_stream(stream));
+  });
 }
 
-ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias,
                                          const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                         int32_t act, const float* alpha, float slope, float* y, void* stream) {
+                                         int32_t act, const float* alpha, float slope, void* y, void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(x && w && y && mean && invstd && gamma && beta, SSMI_E_INVALID_ARG, "conv2d_fwd_bn_act_infer: NULL tensor");
@@ -2008,10 +2016,10 @@ ssmi_status ssmi_conv2d_fwd_bn_act_infer(const ssmi_conv_desc* d, const float* x
   return ssmi_conv2d_fwd_bn_add_act_infer(d, x, w, bias, mean, invstd, gamma, beta, nullptr, 0, act, alpha, slope, y, stream);
 }
 
-ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias,
+ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias,
                                              const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                             const float* skip, int32_t skip_ld, int32_t act, const float* alpha,
-                                             float slope, float* y, void* stream) {
+                                             const void* skip, int32_t skip_ld, int32_t act, const float* alpha,
+                                             float slope, void* y, void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(x && w && y && mean && invstd && gamma && beta, SSMI_E_INVALID_ARG, "conv2d_fwd_bn_add_act_infer: NULL tensor");
@@ -2022,7 +2030,10 @@ ssmi_status ssmi_conv2d_fwd_bn_add_act_infer(const ssmi_conv_desc* d, const floa
   BnBwdArgs bn{};
   bn.mean = mean; bn.invstd = invstd; bn.gamma = gamma; bn.beta = beta; bn.alpha = alpha;
   bn.slope = slope; bn.act = act; bn.hw = 1; bn.skip = skip; bn.skip_ld = skip ? skip_ld : 0;
-  return launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream), nullptr, nullptr, bn);
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_fwd<T>(to_geo(d), static_cast<const T*>(x), w, bias, static_cast<T*>(y), as_stream(stream), nullptr, nullptr, bn);
+  });
 }
 
 size_t ssmi_conv2d_fwd_bn_stats_workspace_bytes(const ssmi_conv_desc* d) {
@@ -2031,7 +2042,7 @@ size_t ssmi_conv2d_fwd_bn_stats_workspace_bytes(const ssmi_conv_desc* d) {
   return (size_t)rows * 2 * d->cout * sizeof(float);
 }
 
-ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                                      float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
                                      float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                                      void* stream) {
@@ -2042,18 +2053,25 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const float* x, co
                "conv2d_fwd_bn_stats: workspace too small");
   int rows = 0;
   float* part = reinterpret_cast<float*>(ws);
-  s = launch_fwd(to_geo(d), x, w, bias, y, as_stream(stream), part, &rows);
+  s = dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_fwd<T>(to_geo(d), static_cast<const T*>(x), w, bias, static_cast<T*>(y), as_stream(stream), part, &rows);
+  });
   if (s) return s;
   return launch_bn_stats_final(part, rows, d->cout, (int64_t)d->n * d->ho * d->wo, eps, momentum, unbiased_moving,
                                moving_mean, moving_var, save_mean, save_invstd, as_stream(stream));
 }
 
-ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add, float* dx,
+ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,
                                  void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(dy && w && dx, SSMI_E_INVALID_ARG, "conv2d_bwd_data: NULL tensor");
-  return launch_bwd_data(to_geo(d), dy, w, add, nullptr, dx, as_stream(stream));
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_bwd_data<T>(to_geo(d), static_cast<const T*>(dy), w, static_cast<const T*>(add), nullptr, static_cast<T*>(dx),
+                              as_stream(stream));
+  });
 }
 
 size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d) {
@@ -2064,10 +2082,42 @@ size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d) {
   return fused > plain ? fused : plain;
 }
 
-ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const float* dy, const float* w, const float* add,
-                                        float* da, const float* bn_x, int32_t ld_x, const float* mean,
+extern "C++" {
+template <typename T>
+static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T* dy, const float* w, const T* add, T* da,
+                                               const T* bn_x, int32_t ld_x, const float* mean, const float* invstd,
+                                               const float* gamma, const float* beta, int32_t act, const float* alpha,
+                                               float slope, const float* drop, int64_t hw, T* dx_bn, float* dgamma,
+                                               float* dbeta, float* dalpha, void* ws, size_t ws_bytes, void* stream) {
+  const Geo g = to_geo(d);
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const int c = d->cin;
+  hipStream_t st = as_stream(stream);
+  static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;   // A/B switch for measurements
+  if (no_fuse || d->stride != 1 || c % 4 != 0 || c > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < c ||
+      npix * ld_x * 4 >= 0x7FFFFFFFLL || (drop && (hw <= 0 || npix % hw != 0))) {
+    ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st);          // unfused: the two passes of the plain entry points
+    if (s) return s;
+    return bn_act_drop_bwd_impl<T>(da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn, dgamma,
+                                   dbeta, dalpha, npix, c, ws, ws_bytes, stream);
+  }
+  float* part = reinterpret_cast<float*>(ws);
+  BnBwdArgs bb{};
+  bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
+  bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
+  int rows = 0;
+  ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows);
+  if (s) return s;
+  float* coef = part + (size_t)rows * 3 * c;
+  return launch_bn_bwd_tail<T>(part, rows, da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn,
+                               dgamma, dbeta, dalpha, npix, c, coef, st);
+}
+}  // extern "C++"
+
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add,
+                                        void* da, const void* bn_x, int32_t ld_x, const float* mean,
                                         const float* invstd, const float* gamma, const float* beta, int32_t act,
-                                        const float* alpha, float slope, const float* drop, int64_t hw, float* dx_bn,
+                                        const float* alpha, float slope, const float* drop, int64_t hw, void* dx_bn,
                                         float* dgamma, float* dbeta, float* dalpha, void* ws, size_t ws_bytes,
                                         void* stream) {
   ssmi_status s = check_desc(d);
@@ -2078,28 +2128,12 @@ ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const float* dy
                "conv2d_bwd_data_bn_bwd: workspace too small");
   SSMI_REQUIRE(act >= SSMI_ACT_NONE && act <= SSMI_ACT_LEAKY && (act != SSMI_ACT_PRELU || alpha), SSMI_E_INVALID_ARG,
                "conv2d_bwd_data_bn_bwd: bad activation");
-  const Geo g = to_geo(d);
-  const int64_t npix = (int64_t)d->n * d->h * d->w;
-  const int c = d->cin;
-  hipStream_t st = as_stream(stream);
-  static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;   // A/B switch for measurements
-  if (no_fuse || d->stride != 1 || c % 4 != 0 || c > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < c ||
-      npix * ld_x * 4 >= 0x7FFFFFFFLL || (drop && (hw <= 0 || npix % hw != 0))) {
-    s = launch_bwd_data(g, dy, w, add, nullptr, da, st);          // unfused: the two passes of the plain entry points
-    if (s) return s;
-    return ssmi_bn_act_drop_bwd(da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn, dgamma,
-                                dbeta, dalpha, npix, c, ws, ws_bytes, stream);
-  }
-  float* part = reinterpret_cast<float*>(ws);
-  BnBwdArgs bb{};
-  bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
-  bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
-  int rows = 0;
-  s = launch_bwd_data(g, dy, w, add, nullptr, da, st, bb, &rows);
-  if (s) return s;
-  float* coef = part + (size_t)rows * 3 * c;
-  return launch_bn_bwd_tail(part, rows, da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn,
-                            dgamma, dbeta, dalpha, npix, c, coef, st);
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return conv2d_bwd_data_bn_bwd_impl<T>(d, static_cast<const T*>(dy), w, static_cast<const T*>(add), static_cast<T*>(da),
+                                          static_cast<const T*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop,
+                                          hw, static_cast<T*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream);
+  });
 }
 
 size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d) {
@@ -2107,28 +2141,39 @@ size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d) {
   return wg_ws_bytes(to_geo(d));
 }
 
-ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+ssmi_status ssmi_conv2d_bwd_weight(const ssmi_conv_desc* d, const void* x, const void* dy, float* dw, float* dbias,
                                    void* ws, size_t ws_bytes, void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(x && dy && dw, SSMI_E_INVALID_ARG, "conv2d_bwd_weight: NULL tensor");
-  return launch_bwd_weight(to_geo(d), x, dy, dw, dbias, ws, ws_bytes, as_stream(stream));
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_bwd_weight<T>(to_geo(d), static_cast<const T*>(x), static_cast<const T*>(dy), dw, dbias, ws, ws_bytes,
+                                as_stream(stream));
+  });
 }
 
-ssmi_status ssmi_conv2d_transpose_fwd(const ssmi_conv_desc* d, const float* xt, const float* w, const float* bias,
-                                      float* yt, void* stream) {
+ssmi_status ssmi_conv2d_transpose_fwd(const ssmi_conv_desc* d, const void* xt, const float* w, const float* bias,
+                                      void* yt, void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(xt && w && yt, SSMI_E_INVALID_ARG, "conv2d_transpose_fwd: NULL tensor");
-  return launch_bwd_data(to_geo(d), xt, w, nullptr, bias, yt, as_stream(stream));
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_bwd_data<T>(to_geo(d), static_cast<const T*>(xt), w, (const T*)nullptr, bias, static_cast<T*>(yt),
+                              as_stream(stream));
+  });
 }
 
-ssmi_status ssmi_conv2d_transpose_bwd_data(const ssmi_conv_desc* d, const float* dyt, const float* w, float* dxt,
+ssmi_status ssmi_conv2d_transpose_bwd_data(const ssmi_conv_desc* d, const void* dyt, const float* w, void* dxt,
                                            void* stream) {
   ssmi_status s = check_desc(d);
   if (s) return s;
   SSMI_REQUIRE(dyt && w && dxt, SSMI_E_INVALID_ARG, "conv2d_transpose_bwd_data: NULL tensor");
-  return launch_fwd(to_geo(d), dyt, w, nullptr, dxt, as_stream(stream));
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_fwd<T>(to_geo(d), static_cast<const T*>(dyt), w, nullptr, static_cast<T*>(dxt), as_stream(stream));
+  });
 }
 
 static int colsum_blocks(int64_t npix, int c) {
@@ -2145,16 +2190,13 @@ size_t ssmi_conv2d_transpose_bwd_weight_workspace_bytes(const ssmi_conv_desc* d)
   return a + (size_t)512 * d->cin * sizeof(float);
 }
 
-ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const float* xt, const float* dyt, float* dw,
-                                             float* dbias, void* ws, size_t ws_bytes, void* stream) {
-  ssmi_status s = check_desc(d);
-  if (s) return s;
-  SSMI_REQUIRE(xt && dyt && dw, SSMI_E_INVALID_ARG, "conv2d_transpose_bwd_weight: NULL tensor");
-  SSMI_REQUIRE(ws_bytes >= ssmi_conv2d_transpose_bwd_weight_workspace_bytes(d), SSMI_E_WORKSPACE,
-               "conv2d_transpose_bwd_weight: workspace too small");
+extern "C++" {
+template <typename T>
+static ssmi_status conv2d_transpose_bwd_weight_impl(const ssmi_conv_desc* d, const T* xt, const T* dyt, float* dw,
+                                                    float* dbias, void* ws, void* stream) {
   Geo g = to_geo(d);
   const size_t a = wg_ws_bytes(g);
-  s = launch_bwd_weight(g, dyt, xt, dw, nullptr, ws, a, as_stream(stream));
+  ssmi_status s = launch_bwd_weight<T>(g, dyt, xt, dw, nullptr, ws, a, as_stream(stream));
   if (s) return s;
   if (dbias) {
     SSMI_REQUIRE(g.cin <= 256, SSMI_E_UNSUPPORTED, "conv2d_transpose_bwd_weight: bias gradient supports <= 256 channels");
@@ -2162,14 +2204,28 @@ ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const floa
     const int64_t npix = (int64_t)g.n * g.h * g.w;
     const int nb = colsum_blocks(npix, g.cin);
     if (g.cin % 4 == 0 && g.x_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dyt) & 15) == 0)
-      hipLaunchKernelGGL(colsum_partial<true>, dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
+      hipLaunchKernelGGL((colsum_partial<T, true>), dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
     else
-      hipLaunchKernelGGL(colsum_partial<false>, dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
+      hipLaunchKernelGGL((colsum_partial<T, false>), dim3(nb), dim3(256), 0, as_stream(stream), dyt, npix, g.cin, g.x_ld, part);
     SSMI_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_final, dim3((g.cin + 7) / 8), dim3(256), 0, as_stream(stream), part, nb, g.cin, dbias);
     SSMI_LAUNCH_CHECK();
   }
   return SSMI_OK;
+}
+}  // extern "C++"
+
+ssmi_status ssmi_conv2d_transpose_bwd_weight(const ssmi_conv_desc* d, const void* xt, const void* dyt, float* dw,
+                                             float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(xt && dyt && dw, SSMI_E_INVALID_ARG, "conv2d_transpose_bwd_weight: NULL tensor");
+  SSMI_REQUIRE(ws_bytes >= ssmi_conv2d_transpose_bwd_weight_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_transpose_bwd_weight: workspace too small");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return conv2d_transpose_bwd_weight_impl<T>(d, static_cast<const T*>(xt), static_cast<const T*>(dyt), dw, dbias, ws, stream);
+  });
 }
 
 }  // extern "C"

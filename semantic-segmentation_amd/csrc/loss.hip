@@ -32,10 +32,10 @@ __device__ __forceinline__ void loss_block_finish(float local_loss, int bad, int
   if (bad_labels && bad) atomicAdd(bad_labels, bad);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+template <typename T, int C>
+__global__ __launch_bounds__(256) void xent_kernel(const T* __restrict__ logits, const int32_t* __restrict__ labels,
                                                    const float* __restrict__ weights, int64_t npix, float inv_npix,
-                                                   float grad_scale, float* __restrict__ dlogits, double* __restrict__ part,
+                                                   float grad_scale, T* __restrict__ dlogits, double* __restrict__ part,
                                                    int64_t* __restrict__ cm, int64_t npix_metrics, uint64_t ignore_mask,
                                                    int32_t* __restrict__ pred_out, int32_t* __restrict__ bad_labels) {
   extern __shared__ int cm_lds[];
@@ -48,17 +48,17 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
   const int64_t nloop = npix_metrics > npix ? npix_metrics : npix;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nloop; p += (int64_t)gridDim.x * 256) {
     const bool in_loss = p < npix;   // rows past npix feed the confusion matrix only
-    const float* zp = logits + p * C;
+    const T* zp = logits + p * C;
     float z[C];
     if (C % 4 == 0) {
 #pragma unroll
       for (int j = 0; j < C / 4; ++j) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(zp + 4 * j);
+        const f32x4 t = Act<T>::gld4(zp + 4 * j);
         z[4 * j] = t[0]; z[4 * j + 1] = t[1]; z[4 * j + 2] = t[2]; z[4 * j + 3] = t[3];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < C; ++j) z[j] = zp[j];
+      for (int j = 0; j < C; ++j) z[j] = Act<T>::gld(zp + j);
     }
     float mx = z[0];
     int am = 0;
@@ -81,18 +81,18 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
     if (dlogits && in_loss) {
       const float k = grad_scale * wgt * inv_npix;
       const float inv = 1.f / se;
-      float* dp = dlogits + p * C;
+      T* dp = dlogits + p * C;
       if (C % 4 == 0) {
 #pragma unroll
         for (int j = 0; j < C / 4; ++j) {
           f32x4 t;
 #pragma unroll
           for (int q = 0; q < 4; ++q) t[q] = k * (e[4 * j + q] * inv - ((4 * j + q) == lab ? 1.f : 0.f));
-          *reinterpret_cast<f32x4*>(dp + 4 * j) = t;
+          Act<T>::gst4(dp + 4 * j, t);
         }
       } else {
 #pragma unroll
-        for (int j = 0; j < C; ++j) dp[j] = k * (e[j] * inv - (j == lab ? 1.f : 0.f));
+        for (int j = 0; j < C; ++j) Act<T>::gst(dp + j, k * (e[j] * inv - (j == lab ? 1.f : 0.f)));
       }
     }
     if (pred_out) pred_out[p] = am;
@@ -103,9 +103,10 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
 }
 
 // any class count up to 64: logits re-read three times (served by L1/L2)
-__global__ __launch_bounds__(256) void xent_kernel_generic(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+template <typename T>
+__global__ __launch_bounds__(256) void xent_kernel_generic(const T* __restrict__ logits, const int32_t* __restrict__ labels,
                                                            const float* __restrict__ weights, int64_t npix, int C,
-                                                           float inv_npix, float grad_scale, float* __restrict__ dlogits,
+                                                           float inv_npix, float grad_scale, T* __restrict__ dlogits,
                                                            double* __restrict__ part, int64_t* __restrict__ cm,
                                                            int64_t npix_metrics, uint64_t ignore_mask,
                                                            int32_t* __restrict__ pred_out, int32_t* __restrict__ bad_labels) {
@@ -119,26 +120,26 @@ __global__ __launch_bounds__(256) void xent_kernel_generic(const float* __restri
   const int64_t nloop = npix_metrics > npix ? npix_metrics : npix;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nloop; p += (int64_t)gridDim.x * 256) {
     const bool in_loss = p < npix;
-    const float* zp = logits + p * C;
-    float mx = zp[0];
+    const T* zp = logits + p * C;
+    float mx = Act<T>::gld(zp);
     int am = 0;
     for (int j = 1; j < C; ++j) {
-      const float v = zp[j];
+      const float v = Act<T>::gld(zp + j);
       if (v > mx) { mx = v; am = j; }
     }
     float se = 0.f;
-    for (int j = 0; j < C; ++j) se += __expf(zp[j] - mx);
+    for (int j = 0; j < C; ++j) se += __expf(Act<T>::gld(zp + j) - mx);
     const int lab = labels[p];
     const bool lv = (unsigned)lab < (unsigned)C;
     const float wgt = (lv && in_loss) ? weights[p] : 0.f;
     if (!lv) ++bad;
-    const float zl = lv ? zp[lab] : 0.f;
+    const float zl = lv ? Act<T>::gld(zp + lab) : 0.f;
     local += wgt * (mx + __logf(se) - zl);
     if (dlogits && in_loss) {
       const float k = grad_scale * wgt * inv_npix;
       const float inv = 1.f / se;
-      float* dp = dlogits + p * C;
-      for (int j = 0; j < C; ++j) dp[j] = k * (__expf(zp[j] - mx) * inv - (j == lab ? 1.f : 0.f));
+      T* dp = dlogits + p * C;
+      for (int j = 0; j < C; ++j) Act<T>::gst(dp + j, k * (__expf(Act<T>::gld(zp + j) - mx) * inv - (j == lab ? 1.f : 0.f)));
     }
     if (pred_out) pred_out[p] = am;
     if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
@@ -455,10 +456,13 @@ size_t ssmi_softmax_xent_workspace_bytes(int64_t npix) {
   return (size_t)kLossBlocks * sizeof(double);
 }
 
-ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
-                                      int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
-                                      int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
-                                      int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream) {
+}  // extern "C"
+
+template <typename T>
+static ssmi_status softmax_xent_impl(const T* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                     int32_t num_classes, float grad_scale, T* dlogits, float* loss_out, int64_t* cm,
+                                     int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out, int32_t* bad_labels, void* ws,
+                                     size_t ws_bytes, void* stream) {
   SSMI_REQUIRE(logits && labels && weights && loss_out && npix > 0, SSMI_E_INVALID_ARG, "softmax_xent: bad argument");
   SSMI_REQUIRE(num_classes >= 2 && num_classes <= 64, SSMI_E_UNSUPPORTED, "softmax_xent: num_classes %d outside [2,64]", num_classes);
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_softmax_xent_workspace_bytes(npix), SSMI_E_WORKSPACE, "softmax_xent: workspace too small");
@@ -472,16 +476,35 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
   const size_t lds = cm ? (size_t)num_classes * num_classes * sizeof(int) : 0;
   const bool aligned = ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15) == 0;
   if (num_classes == 24 && aligned) {
-    hipLaunchKernelGGL((xent_kernel<24>), dim3(nb), dim3(256), lds, st, logits, labels, weights, npix, inv, grad_scale,
+    hipLaunchKernelGGL((xent_kernel<T, 24>), dim3(nb), dim3(256), lds, st, logits, labels, weights, npix, inv, grad_scale,
                        dlogits, part, cm, npix_metrics, ignore_mask, pred_out, bad_labels);
   } else {
-    hipLaunchKernelGGL(xent_kernel_generic, dim3(nb), dim3(256), lds, st, logits, labels, weights, npix, num_classes, inv,
+    hipLaunchKernelGGL(xent_kernel_generic<T>, dim3(nb), dim3(256), lds, st, logits, labels, weights, npix, num_classes, inv,
                        grad_scale, dlogits, part, cm, npix_metrics, ignore_mask, pred_out, bad_labels);
   }
   SSMI_LAUNCH_CHECK();
   hipLaunchKernelGGL(xent_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, loss_out);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
+}
+
+extern "C" {
+
+ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                      int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
+                                      int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                      int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream) {
+  return softmax_xent_impl<float>(logits, labels, weights, npix, num_classes, grad_scale, dlogits, loss_out, cm, npix_metrics,
+                                  ignore_mask, pred_out, bad_labels, ws, ws_bytes, stream);
+}
+
+ssmi_status ssmi_softmax_xent_fwd_bwd_bf16(const uint16_t* logits, const int32_t* labels, const float* weights, int64_t npix,
+                                           int32_t num_classes, float grad_scale, uint16_t* dlogits, float* loss_out,
+                                           int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                           int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream) {
+  return softmax_xent_impl<bf16>(reinterpret_cast<const bf16*>(logits), labels, weights, npix, num_classes, grad_scale,
+                                 reinterpret_cast<bf16*>(dlogits), loss_out, cm, npix_metrics, ignore_mask, pred_out, bad_labels,
+                                 ws, ws_bytes, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

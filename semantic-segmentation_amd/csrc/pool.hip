@@ -7,8 +7,9 @@ namespace ssmi {
 __device__ __forceinline__ f32x4 ld4p(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // generic scalar version (any c): one thread per output element
-__global__ __launch_bounds__(256) void maxpool_argmax_fwd_scalar(const float* __restrict__ x, int n, int h, int w, int c,
-                                                                 int ho, int wo, float* __restrict__ y, int y_ld,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_argmax_fwd_scalar(const T* __restrict__ x, int n, int h, int w, int c,
+                                                                 int ho, int wo, T* __restrict__ y, int y_ld,
                                                                  int32_t* __restrict__ idx_i, float* __restrict__ idx_f,
                                                                  int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -18,7 +19,7 @@ __global__ __launch_bounds__(256) void maxpool_argmax_fwd_scalar(const float* __
     q /= wo;
     const int oy = (int)(q % ho);
     const int n_ = (int)(q / ho);
-    const float* base = x + (int64_t)n_ * h * w * c;
+    const T* base = x + (int64_t)n_ * h * w * c;
     float best = 0.f;
     int bi = 0;
     bool first = true;
@@ -31,19 +32,20 @@ __global__ __launch_bounds__(256) void maxpool_argmax_fwd_scalar(const float* __
         const int ix = ox * 2 + dw;
         if (ix >= w) continue;
         const int flat = (iy * w + ix) * c + ch;
-        const float v = base[flat];
+        const float v = Act<T>::gld(base + flat);
         if (first || v > best) { best = v; bi = flat; first = false; }
       }
     }
-    y[((int64_t)(n_ * ho + oy) * wo + ox) * y_ld + ch] = best;
+    Act<T>::gst(y + ((int64_t)(n_ * ho + oy) * wo + ox) * y_ld + ch, best);
     if (idx_i) idx_i[i] = bi;
     if (idx_f) idx_f[i] = (float)bi;
   }
 }
 
 // vector version: c % 4 == 0, y_ld % 4 == 0, even h and w
-__global__ __launch_bounds__(256) void maxpool_argmax_fwd_vec(const float* __restrict__ x, int n, int h, int w, int c4n,
-                                                              float* __restrict__ y, int y_ld, int32_t* __restrict__ idx_i,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_argmax_fwd_vec(const T* __restrict__ x, int n, int h, int w, int c4n,
+                                                              T* __restrict__ y, int y_ld, int32_t* __restrict__ idx_i,
                                                               float* __restrict__ idx_f, int64_t total4) {
   const int c = c4n * 4;
   const int ho = h >> 1, wo = w >> 1;
@@ -55,9 +57,9 @@ __global__ __launch_bounds__(256) void maxpool_argmax_fwd_vec(const float* __res
     const int oy = (int)(q2 % ho);
     const int n_ = (int)(q2 / ho);
     const int f00 = ((2 * oy) * w + 2 * ox) * c + ch;
-    const float* base = x + (int64_t)n_ * h * w * c;
-    const f32x4 v00 = ld4p(base + f00), v01 = ld4p(base + f00 + c), v10 = ld4p(base + f00 + w * c),
-                v11 = ld4p(base + f00 + w * c + c);
+    const T* base = x + (int64_t)n_ * h * w * c;
+    const f32x4 v00 = Act<T>::gld4(base + f00), v01 = Act<T>::gld4(base + f00 + c), v10 = Act<T>::gld4(base + f00 + w * c),
+                v11 = Act<T>::gld4(base + f00 + w * c + c);
     f32x4 best = v00;
     int bi[4] = {f00, f00 + 1, f00 + 2, f00 + 3};
 #pragma unroll
@@ -66,15 +68,16 @@ __global__ __launch_bounds__(256) void maxpool_argmax_fwd_vec(const float* __res
       if (v10[j] > best[j]) { best[j] = v10[j]; bi[j] = f00 + w * c + j; }
       if (v11[j] > best[j]) { best[j] = v11[j]; bi[j] = f00 + w * c + c + j; }
     }
-    *reinterpret_cast<f32x4*>(y + q * y_ld + ch) = best;
+    Act<T>::gst4(y + q * y_ld + ch, best);
     if (idx_i) *reinterpret_cast<int4*>(idx_i + i * 4) = make_int4(bi[0], bi[1], bi[2], bi[3]);
     if (idx_f) *reinterpret_cast<f32x4*>(idx_f + i * 4) = f32x4{(float)bi[0], (float)bi[1], (float)bi[2], (float)bi[3]};
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_argmax_bwd_kernel(const float* __restrict__ dy, int dy_ld,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_argmax_bwd_kernel(const T* __restrict__ dy, int dy_ld,
                                                                  const int32_t* __restrict__ idx, int n, int h, int w, int c,
-                                                                 int ho, int wo, float* __restrict__ dx, int accumulate,
+                                                                 int ho, int wo, T* __restrict__ dx, int accumulate,
                                                                  int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
@@ -85,8 +88,8 @@ __global__ __launch_bounds__(256) void maxpool_argmax_bwd_kernel(const float* __
     const int n_ = (int)(q / h);
     const int64_t o = ((int64_t)n_ * ho + (iy >> 1)) * wo + (ix >> 1);
     const int flat = (iy * w + ix) * c + ch;
-    const float g = (idx[o * c + ch] == flat) ? dy[o * dy_ld + ch] : 0.f;
-    dx[i] = accumulate ? dx[i] + g : g;
+    const float g = (idx[o * c + ch] == flat) ? Act<T>::gld(dy + o * dy_ld + ch) : 0.f;
+    Act<T>::gst(dx + i, accumulate ? Act<T>::gld(dx + i) + g : g);
   }
 }
 
@@ -133,8 +136,9 @@ __global__ __launch_bounds__(256) void idx_f32_to_i32_kernel(const float* __rest
 }
 
 // nearest 2x upsampling; y (forward) / dy (backward) may be a channel slice of a wider tensor (pixel stride ld)
-__global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restrict__ x, int n, int h, int w, int c,
-                                                           float* __restrict__ y, int y_ld, int64_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_kernel(const T* __restrict__ x, int n, int h, int w, int c,
+                                                           T* __restrict__ y, int y_ld, int64_t total) {
   const int H = 2 * h, W = 2 * w;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
@@ -144,12 +148,13 @@ __global__ __launch_bounds__(256) void upsample_fwd_kernel(const float* __restri
     q /= W;
     const int oy = (int)(q % H);
     const int n_ = (int)(q / H);
-    y[pix * y_ld + ch] = x[(((int64_t)n_ * h + (oy >> 1)) * w + (ox >> 1)) * c + ch];
+    y[pix * y_ld + ch] = x[(((int64_t)n_ * h + (oy >> 1)) * w + (ox >> 1)) * c + ch];      // a copy: no conversion
   }
 }
 
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, int dy_ld, int n, int h, int w,
-                                                           int c, float* __restrict__ dx, int64_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ dy, int dy_ld, int n, int h, int w,
+                                                           int c, T* __restrict__ dx, int64_t total) {
   const int W = 2 * w;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
@@ -158,31 +163,48 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     q /= w;
     const int y_ = (int)(q % h);
     const int n_ = (int)(q / h);
-    const float* b = dy + ((((int64_t)n_ * 2 * h + 2 * y_) * W) + 2 * x_) * dy_ld + ch;
-    dx[i] = b[0] + b[dy_ld] + b[(int64_t)W * dy_ld] + b[(int64_t)W * dy_ld + dy_ld];
+    const T* b = dy + ((((int64_t)n_ * 2 * h + 2 * y_) * W) + 2 * x_) * dy_ld + ch;
+    Act<T>::gst(dx + i, Act<T>::gld(b) + Act<T>::gld(b + dy_ld) + Act<T>::gld(b + (int64_t)W * dy_ld) +
+                            Act<T>::gld(b + (int64_t)W * dy_ld + dy_ld));
   }
 }
 
 // dst[p, 0:c] (=|+=) src[p, 0:c] with independent pixel strides: concat slices and their gradients
-__global__ __launch_bounds__(256) void copy_ld_kernel(const float* __restrict__ src, int src_ld, float* __restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void copy_ld_kernel(const T* __restrict__ src, int src_ld, T* __restrict__ dst,
                                                       int dst_ld, int c, int accumulate, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
     const int64_t p = i / c;
-    const float v = src[p * src_ld + ch];
-    float* d = dst + p * dst_ld + ch;
-    *d = accumulate ? *d + v : v;
+    const float v = Act<T>::gld(src + p * src_ld + ch);
+    T* d = dst + p * dst_ld + ch;
+    Act<T>::gst(d, accumulate ? Act<T>::gld(d) + v : v);
   }
 }
 
 // y[n, p, c] = x[n, p, c] * table[n, c]   (SpatialDropout2D keep/scale table; its own gradient too)
-__global__ __launch_bounds__(256) void scale_nc_kernel(const float* __restrict__ x, const float* __restrict__ table,
-                                                       float* __restrict__ y, int64_t hw, int c, int64_t total) {
+template <typename T>
+__global__ __launch_bounds__(256) void scale_nc_kernel(const T* __restrict__ x, const float* __restrict__ table,
+                                                       T* __restrict__ y, int64_t hw, int c, int64_t total) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int ch = (int)(i % c);
     const int64_t n_ = i / ((int64_t)c * hw);
-    y[i] = x[i] * table[n_ * c + ch];
+    Act<T>::gst(y + i, Act<T>::gld(x + i) * table[n_ * c + ch]);
   }
+}
+
+// float32 <-> bfloat16 (round to nearest even), 4 elements per thread where the count allows
+__global__ __launch_bounds__(256) void cast_f32_to_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    Act<bf16>::gst4(d + i * 4, Act<float>::gld4(s + i * 4));
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = (bf16)s[i];
+}
+__global__ __launch_bounds__(256) void cast_bf16_to_f32_kernel(const bf16* __restrict__ s, float* __restrict__ d, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+    Act<float>::gst4(d + i * 4, Act<bf16>::gld4(s + i * 4));
+  for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = (float)s[i];
 }
 
 __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ d, float v, int64_t n) {
@@ -237,8 +259,11 @@ using namespace ssmi;
 
 extern "C" {
 
-ssmi_status ssmi_maxpool_argmax_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
-                                    int32_t* idx_i32, float* idx_f32, void* stream) {
+}  // extern "C"
+
+template <typename T>
+static ssmi_status maxpool_argmax_fwd_impl(const T* x, int32_t n, int32_t h, int32_t w, int32_t c, T* y, int32_t y_ld,
+                                           int32_t* idx_i32, float* idx_f32, void* stream) {
   SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && y_ld >= c, SSMI_E_INVALID_ARG, "maxpool_argmax_fwd: bad argument");
   SSMI_REQUIRE((int64_t)h * w * c < (int64_t)1 << 31, SSMI_E_UNSUPPORTED, "maxpool_argmax_fwd: per-image index exceeds int32");
   const int ho = (h + 1) / 2, wo = (w + 1) / 2;
@@ -246,24 +271,116 @@ ssmi_status ssmi_maxpool_argmax_fwd(const float* x, int32_t n, int32_t h, int32_
                    ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
   if (vec) {
     const int64_t total4 = (int64_t)n * ho * wo * (c / 4);
-    hipLaunchKernelGGL(maxpool_argmax_fwd_vec, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, n, h, w, c / 4, y,
+    hipLaunchKernelGGL(maxpool_argmax_fwd_vec<T>, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, n, h, w, c / 4, y,
                        y_ld, idx_i32, idx_f32, total4);
   } else {
     const int64_t total = (int64_t)n * ho * wo * c;
-    hipLaunchKernelGGL(maxpool_argmax_fwd_scalar, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, ho,
+    hipLaunchKernelGGL(maxpool_argmax_fwd_scalar<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, ho,
                        wo, y, y_ld, idx_i32, idx_f32, total);
   }
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
 
-ssmi_status ssmi_maxpool_argmax_bwd(const float* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
-                                    int32_t c, float* dx, int32_t accumulate, void* stream) {
+template <typename T>
+static ssmi_status maxpool_argmax_bwd_impl(const T* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
+                                           int32_t c, T* dx, int32_t accumulate, void* stream) {
   SSMI_REQUIRE(dy && idx && dx && n > 0 && h > 0 && w > 0 && c > 0 && dy_ld >= c, SSMI_E_INVALID_ARG, "maxpool_argmax_bwd: bad argument");
   const int ho = (h + 1) / 2, wo = (w + 1) / 2;
   const int64_t total = (int64_t)n * h * w * c;
-  hipLaunchKernelGGL(maxpool_argmax_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, idx, n, h,
+  hipLaunchKernelGGL(maxpool_argmax_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, idx, n, h,
                      w, c, ho, wo, dx, accumulate, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+template <typename T>
+static ssmi_status upsample_fwd_impl(const T* x, int32_t n, int32_t h, int32_t w, int32_t c, T* y, int32_t y_ld, void* stream) {
+  SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && y_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_fwd: bad argument");
+  const int64_t total = (int64_t)n * h * w * c * 4;
+  hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, y_ld, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+template <typename T>
+static ssmi_status upsample_bwd_impl(const T* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c, T* dx, void* stream) {
+  SSMI_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && dy_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_bwd: bad argument");
+  const int64_t total = (int64_t)n * h * w * c;
+  hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, n, h, w, c, dx, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+template <typename T>
+static ssmi_status copy_ld_impl(const T* src, int32_t src_ld, T* dst, int32_t dst_ld, int64_t npix, int32_t c, int32_t accumulate,
+                                void* stream) {
+  SSMI_REQUIRE(src && dst && npix > 0 && c > 0 && src_ld >= c && dst_ld >= c, SSMI_E_INVALID_ARG, "copy_ld: bad argument");
+  const int64_t total = npix * c;
+  hipLaunchKernelGGL(copy_ld_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld, c,
+                     accumulate, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+template <typename T>
+static ssmi_status scale_nc_impl(const T* x, const float* table, T* y, int32_t n, int64_t hw, int32_t c, void* stream) {
+  SSMI_REQUIRE(x && table && y && n > 0 && hw > 0 && c > 0, SSMI_E_INVALID_ARG, "scale_nc: bad argument");
+  const int64_t total = (int64_t)n * hw * c;
+  hipLaunchKernelGGL(scale_nc_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, table, y, hw, c, total);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+#define BF(p) reinterpret_cast<bf16*>(p)
+#define CBF(p) reinterpret_cast<const bf16*>(p)
+
+extern "C" {
+
+ssmi_status ssmi_maxpool_argmax_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
+                                    int32_t* idx_i32, float* idx_f32, void* stream) {
+  return maxpool_argmax_fwd_impl<float>(x, n, h, w, c, y, y_ld, idx_i32, idx_f32, stream);
+}
+ssmi_status ssmi_maxpool_argmax_fwd_bf16(const uint16_t* x, int32_t n, int32_t h, int32_t w, int32_t c, uint16_t* y,
+                                         int32_t y_ld, int32_t* idx_i32, float* idx_f32, void* stream) {
+  return maxpool_argmax_fwd_impl<bf16>(CBF(x), n, h, w, c, BF(y), y_ld, idx_i32, idx_f32, stream);
+}
+ssmi_status ssmi_maxpool_argmax_bwd(const float* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
+                                    int32_t c, float* dx, int32_t accumulate, void* stream) {
+  return maxpool_argmax_bwd_impl<float>(dy, dy_ld, idx, n, h, w, c, dx, accumulate, stream);
+}
+ssmi_status ssmi_maxpool_argmax_bwd_bf16(const uint16_t* dy, int32_t dy_ld, const int32_t* idx, int32_t n, int32_t h, int32_t w,
+                                         int32_t c, uint16_t* dx, int32_t accumulate, void* stream) {
+  return maxpool_argmax_bwd_impl<bf16>(CBF(dy), dy_ld, idx, n, h, w, c, BF(dx), accumulate, stream);
+}
+ssmi_status ssmi_upsample_nn2x_fwd_bf16(const uint16_t* x, int32_t n, int32_t h, int32_t w, int32_t c, uint16_t* y, int32_t y_ld,
+                                        void* stream) {
+  return upsample_fwd_impl<bf16>(CBF(x), n, h, w, c, BF(y), y_ld, stream);
+}
+ssmi_status ssmi_upsample_nn2x_bwd_bf16(const uint16_t* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c,
+                                        uint16_t* dx, void* stream) {
+  return upsample_bwd_impl<bf16>(CBF(dy), dy_ld, n, h, w, c, BF(dx), stream);
+}
+ssmi_status ssmi_copy_ld_bf16(const uint16_t* src, int32_t src_ld, uint16_t* dst, int32_t dst_ld, int64_t npix, int32_t c,
+                              int32_t accumulate, void* stream) {
+  return copy_ld_impl<bf16>(CBF(src), src_ld, BF(dst), dst_ld, npix, c, accumulate, stream);
+}
+ssmi_status ssmi_scale_nc_bf16(const uint16_t* x, const float* table, uint16_t* y, int32_t n, int64_t hw, int32_t c, void* stream) {
+  return scale_nc_impl<bf16>(CBF(x), table, BF(y), n, hw, c, stream);
+}
+ssmi_status ssmi_cast_f32_to_bf16(const float* src, uint16_t* dst, int64_t count, void* stream) {
+  SSMI_REQUIRE(src && dst && count > 0, SSMI_E_INVALID_ARG, "cast_f32_to_bf16: bad argument");
+  SSMI_REQUIRE(((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 7)) == 0, SSMI_E_INVALID_ARG,
+               "cast_f32_to_bf16: pointers must be 16 / 8 byte aligned");
+  hipLaunchKernelGGL(cast_f32_to_bf16_kernel, dim3(grid_for(count / 4 + 1)), dim3(256), 0, as_stream(stream), src, BF(dst), count);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+ssmi_status ssmi_cast_bf16_to_f32(const uint16_t* src, float* dst, int64_t count, void* stream) {
+  SSMI_REQUIRE(src && dst && count > 0, SSMI_E_INVALID_ARG, "cast_bf16_to_f32: bad argument");
+  SSMI_REQUIRE(((reinterpret_cast<uintptr_t>(dst) & 15) | (reinterpret_cast<uintptr_t>(src) & 7)) == 0, SSMI_E_INVALID_ARG,
+               "cast_bf16_to_f32: pointers must be 16 / 8 byte aligned");
+  hipLaunchKernelGGL(cast_bf16_to_f32_kernel, dim3(grid_for(count / 4 + 1)), dim3(256), 0, as_stream(stream), CBF(src), dst, count);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
@@ -310,38 +427,21 @@ ssmi_status ssmi_idx_f32_to_i32(const float* src, int32_t* dst, int64_t count, v
 
 ssmi_status ssmi_upsample_nn2x_fwd(const float* x, int32_t n, int32_t h, int32_t w, int32_t c, float* y, int32_t y_ld,
                                    void* stream) {
-  SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && y_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_fwd: bad argument");
-  const int64_t total = (int64_t)n * h * w * c * 4;
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, y_ld, total);
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return upsample_fwd_impl<float>(x, n, h, w, c, y, y_ld, stream);
 }
 
 ssmi_status ssmi_upsample_nn2x_bwd(const float* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c, float* dx,
                                    void* stream) {
-  SSMI_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && dy_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_bwd: bad argument");
-  const int64_t total = (int64_t)n * h * w * c;
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, n, h, w, c, dx, total);
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return upsample_bwd_impl<float>(dy, dy_ld, n, h, w, c, dx, stream);
 }
 
 ssmi_status ssmi_copy_ld(const float* src, int32_t src_ld, float* dst, int32_t dst_ld, int64_t npix, int32_t c,
                          int32_t accumulate, void* stream) {
-  SSMI_REQUIRE(src && dst && npix > 0 && c > 0 && src_ld >= c && dst_ld >= c, SSMI_E_INVALID_ARG, "copy_ld: bad argument");
-  const int64_t total = npix * c;
-  hipLaunchKernelGGL(copy_ld_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld, c,
-                     accumulate, total);
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return copy_ld_impl<float>(src, src_ld, dst, dst_ld, npix, c, accumulate, stream);
 }
 
 ssmi_status ssmi_scale_nc(const float* x, const float* table, float* y, int32_t n, int64_t hw, int32_t c, void* stream) {
-  SSMI_REQUIRE(x && table && y && n > 0 && hw > 0 && c > 0, SSMI_E_INVALID_ARG, "scale_nc: bad argument");
-  const int64_t total = (int64_t)n * hw * c;
-  hipLaunchKernelGGL(scale_nc_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, table, y, hw, c, total);
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return scale_nc_impl<float>(x, table, y, n, hw, c, stream);
 }
 
 ssmi_status ssmi_fill_f32(float* dst, float value, int64_t count, void* stream) {

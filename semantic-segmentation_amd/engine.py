@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from ._lib import BnParams, ConvDesc, MergeDesc, lib
+from ._lib import BF16, F32, BnParams, ConvDesc, MergeDesc, lib, lib_for
 
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.1   # src/models.py:1064 (weight of the OLD moving value)
@@ -58,13 +58,28 @@ class ParamStore:
     """Flat arenas + named views.  Order of registration = Keras layer-creation order (weight order of
     model.get_weights(): per layer kernel, bias / gamma, beta, moving_mean, moving_variance / alpha)."""
 
-    def __init__(self):
+    def __init__(self, act_dtype=torch.float32):
+        # element type of the ACTIVATION tensors of the network built on this store (float32 or bfloat16); parameters,
+        # gradients of parameters, statistics and optimizer state are float32 either way
+        if act_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("activation dtype must be torch.float32 or torch.bfloat16, got {}".format(act_dtype))
+        self.act_dtype = act_dtype
+        self.dtype_code = BF16 if act_dtype == torch.bfloat16 else F32
+        self.esize = 2 if act_dtype == torch.bfloat16 else 4      # bytes per activation element
+        self._L = None
         self.specs: "OrderedDict[str, ParamSpec]" = OrderedDict()
         self.n_train = 0
         self.n_state = 0
         self.theta = self.grad = self.state = None
         self.views: Dict[str, torch.Tensor] = {}
         self.gviews: Dict[str, torch.Tensor] = {}
+
+    @property
+    def L(self):
+        """The C-ABI library as this network's activation type sees it (bfloat16 twins where they exist)."""
+        if self._L is None:
+            self._L = lib_for(self.dtype_code)
+        return self._L
 
     def add(self, key, shape, trainable=True, init="zeros", fan_in=0):
         if key in self.specs:
@@ -149,8 +164,9 @@ class Conv:
 
     def plan(self, n, h, w, x_ld=None, y_ld=None):
         """(h, w) is the spatial size of this layer's INPUT.  Returns the output (h, w)."""
-        L = lib()
+        L = self.store.L
         d = ConvDesc()
+        d.dtype = self.store.dtype_code
         if not self.transpose:
             if self.padding == "same":
                 ho, pt = same_pad(h, self.kh, self.stride, self.dil)
@@ -188,7 +204,7 @@ class Conv:
         return out_hw
 
     def fwd(self, x, y, st):
-        L = lib()
+        L = self.store.L
         if self.transpose:
             L.conv2d_transpose_fwd(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), st)
         else:
@@ -201,7 +217,7 @@ class Conv:
             self.fwd(x, y, st)
             bn.stats(y, npix, self.cout, training, update_moving, unbiased, ws, st)
             return
-        lib().conv2d_fwd_bn_stats(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), BN_EPS, BN_MOMENTUM,
+        self.store.L.conv2d_fwd_bn_stats(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(y), BN_EPS, BN_MOMENTUM,
                                   1 if unbiased else 0, _ptr(bn.mm) if update_moving else None,
                                   _ptr(bn.mv) if update_moving else None, _ptr(bn.mean), _ptr(bn.invstd), _ptr(ws),
                                   ws.numel() * 4, st)
@@ -212,18 +228,18 @@ class Conv:
         assert not self.transpose
         if act is None:
             act = ACT_PRELU if bn.alpha is not None else ACT_NONE
-        lib().conv2d_fwd_bn_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
+        self.store.L.conv2d_fwd_bn_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
                                       _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(y), st)
 
     def fwd_bn_add_act_infer(self, x, y, bn: "BatchNorm", skip, skip_ld, alpha, st):
         """Inference phase: y = PReLU_alpha(BN(conv(x)) + skip) in one launch (the tail of a regular bottleneck)."""
         assert not self.transpose
-        lib().conv2d_fwd_bn_add_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
+        self.store.L.conv2d_fwd_bn_add_act_infer(self._dref, _ptr(x), _ptr(self.w), _ptr(self.b), _ptr(bn.mean), _ptr(bn.invstd),
                                           _ptr(bn.gamma), _ptr(bn.beta), _ptr(skip), skip_ld, ACT_PRELU, _ptr(alpha), 0.0,
                                           _ptr(y), st)
 
     def bwd_data(self, dy, dx, st, add=None):
-        L = lib()
+        L = self.store.L
         if self.transpose:
             assert add is None
             L.conv2d_transpose_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(dx), st)
@@ -238,17 +254,17 @@ class Conv:
             act = ACT_PRELU if bn.alpha is not None else ACT_NONE
         if self.transpose:
             self.bwd_data(dy, da, st)
-            lib().bn_act_drop_bwd(_ptr(da), self.cin, _ptr(bn_x), ld_x, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma),
+            self.store.L.bn_act_drop_bwd(_ptr(da), self.cin, _ptr(bn_x), ld_x, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma),
                                   _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(drop), hw, _ptr(dx_bn), _ptr(bn.dgamma),
                                   _ptr(bn.dbeta), _ptr(bn.dalpha), npix, self.cin, _ptr(ws), ws.numel() * 4, st)
             return
-        lib().conv2d_bwd_data_bn_bwd(self._dref, _ptr(dy), _ptr(self.w), None, _ptr(da), _ptr(bn_x), ld_x, _ptr(bn.mean),
+        self.store.L.conv2d_bwd_data_bn_bwd(self._dref, _ptr(dy), _ptr(self.w), None, _ptr(da), _ptr(bn_x), ld_x, _ptr(bn.mean),
                                      _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(drop),
                                      hw, _ptr(dx_bn), _ptr(bn.dgamma), _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(ws),
                                      ws.numel() * 4, st)
 
     def bwd_weight(self, x, dy, ws, st):
-        L = lib()
+        L = self.store.L
         if self.transpose:
             L.conv2d_transpose_bwd_weight(self._dref, _ptr(x), _ptr(dy), _ptr(self.dw), _ptr(self.db), _ptr(ws),
                                           ws.numel() * 4, st)
@@ -287,7 +303,7 @@ class BatchNorm:
         self._pref = C.byref(self.params)
 
     def stats(self, x, npix, ld, training, update_moving, unbiased, ws, st):
-        L = lib()
+        L = self.store.L
         if training:
             L.bn_train_stats(_ptr(x), npix, self.c, ld, BN_EPS, BN_MOMENTUM, 1 if unbiased else 0,
                              _ptr(self.mm) if update_moving else None, _ptr(self.mv) if update_moving else None,
@@ -297,12 +313,12 @@ class BatchNorm:
 
     def act_fwd(self, x, ld, y, npix, st):
         act = ACT_PRELU if self.alpha is not None else ACT_NONE
-        lib().bn_act_fwd(_ptr(x), ld, _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), act,
+        self.store.L.bn_act_fwd(_ptr(x), ld, _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), act,
                          _ptr(self.alpha), 0.0, _ptr(y), npix, self.c, st)
 
     def act_bwd(self, dy, x, ld, dx, npix, ws, st):
         act = ACT_PRELU if self.alpha is not None else ACT_NONE
-        lib().bn_act_bwd(_ptr(dy), _ptr(x), ld, _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), act,
+        self.store.L.bn_act_bwd(_ptr(dy), _ptr(x), ld, _ptr(self.mean), _ptr(self.invstd), _ptr(self.gamma), _ptr(self.beta), act,
                          _ptr(self.alpha), 0.0, _ptr(dx), _ptr(self.dgamma), _ptr(self.dbeta), _ptr(self.dalpha), npix,
                          self.c, _ptr(ws), ws.numel() * 4, st)
 
@@ -394,6 +410,7 @@ class InitialBlock(Block):
 
     def __init__(self, store, variant):
         self.name = "initial_block"
+        self.store = store
         self.variant = variant
         self.conv = Conv(store, "initial_block_conv2d", 3, 3, 3, 13, stride=2, padding="same", bias=True,
                          init="glorot_uniform")
@@ -410,7 +427,7 @@ class InitialBlock(Block):
         self.ho, self.wo = self.conv.plan(n, h, w, x_ld=3, y_ld=16)
         assert h % 2 == 0 and w % 2 == 0, "input height/width must be even"
         self.npix = n * self.ho * self.wo
-        self.cat = torch.empty(n, self.ho, self.wo, 16, dtype=torch.float32, device=dev)
+        self.cat = torch.empty(n, self.ho, self.wo, 16, dtype=self.store.act_dtype, device=dev)
         self.pool_slice = self.cat.view(-1)[13:]
         self.idx = torch.empty(n, self.ho, self.wo, 3, dtype=torch.int32, device=dev) if self.variant == "unpool" else None
         if self.bn:
@@ -422,7 +439,7 @@ class InitialBlock(Block):
         return (self.ho, self.wo, 16)
 
     def fwd(self, x, cfg: RunCfg):
-        L = lib()
+        L = self.store.L
         self.x = x
         self.conv.fwd(x, self.cat, cfg.st)
         L.maxpool_argmax_fwd(_ptr(x), self.n, self.h, self.w, 3, _ptr(self.pool_slice), 16, _ptr(self.idx), None, cfg.st)
@@ -456,6 +473,7 @@ class Bottleneck(Block):
     def __init__(self, store, prefix, cin, cout, kind, variant, downsample=False, upsample=False, asymmetric=0, dilated=0,
                  dropout_rate=None):
         self.name = prefix
+        self.store = store
         self.cin, self.cout, self.kind, self.variant = cin, cout, kind, variant
         self.downsample, self.upsample = downsample, upsample
         internal = cout // 4
@@ -520,7 +538,7 @@ class Bottleneck(Block):
     def plan(self, n, h, w, dev, unpool_idx=None):
         """(h, w): input spatial size.  unpool_idx: int32 indices for mode 3."""
         self.n = n
-        f32 = dict(dtype=torch.float32, device=dev)
+        f32 = dict(dtype=self.store.act_dtype, device=dev)
         h1, w1 = self.conv1.plan(n, h, w)
         h2, w2 = h1, w1
         if self.conv2a is not None:
@@ -570,6 +588,7 @@ class Bottleneck(Block):
                         None if unpool_idx is None else tuple(unpool_idx.shape), (n, h, w, c))
         md = MergeDesc()
         md.n, md.h, md.w, md.c, md.other_mode, md.c_other = n, h2, w2, c, self.mode, (self.cin if self.mode == 1 else c)
+        md.dtype = self.store.dtype_code
         self.md = md
         self._mref = C.byref(md)
         return (h2, w2, c)
@@ -582,7 +601,7 @@ class Bottleneck(Block):
         return self.yo, self.bn_o._pref, (self.unpool_idx if self.mode == 3 else None)
 
     def fwd(self, x, cfg: RunCfg):
-        L = lib()
+        L = self.store.L
         st, ws = cfg.st, cfg.ws
         tr, um, ub = cfg.training, cfg.update_moving, cfg.unbiased_moving
         self.x = x
@@ -627,7 +646,7 @@ class Bottleneck(Block):
         return self.out
 
     def bwd(self, dout, cfg: RunCfg):
-        L = lib()
+        L = self.store.L
         st, ws = cfg.st, cfg.ws
         wsb = ws.numel() * 4
         i = self.internal
@@ -674,6 +693,7 @@ class EnhancedHead(Block):
 
     def __init__(self, store, cin, num_classes, final_layer_name="logits"):
         self.name = final_layer_name
+        self.store = store
         self.cin, self.num_classes = cin, num_classes
         self.conv_a = Conv(store, "final_nn_rs_conv_conv2d", 3, 3, cin, num_classes, bias=True)
         self.bn = BatchNorm(store, "final_nn_rs_conv_bnorm", num_classes)
@@ -684,7 +704,7 @@ class EnhancedHead(Block):
         return [self.conv_a, self.conv]
 
     def plan(self, n, h, w, dev):
-        f32 = dict(dtype=torch.float32, device=dev)
+        f32 = dict(dtype=self.store.act_dtype, device=dev)
         self.n, self.h, self.w = n, h, w
         H, W, C_ = 2 * h, 2 * w, self.num_classes
         self.conv_a.plan(n, H, W)
@@ -703,7 +723,7 @@ class EnhancedHead(Block):
         return (H, W, C_)
 
     def fwd(self, x, cfg):
-        L = lib()
+        L = self.store.L
         C_ = self.num_classes
         L.upsample_nn2x_fwd(_ptr(x), self.n, self.h, self.w, self.cin, _ptr(self.xu), self.cin, cfg.st)
         self.conv_a.fwd_bn(self.xu, self.ya, self.bn, self.npix, cfg.training, cfg.update_moving, cfg.unbiased_moving, cfg.ws,
@@ -713,7 +733,7 @@ class EnhancedHead(Block):
         return self.out
 
     def bwd(self, dout, cfg):
-        L = lib()
+        L = self.store.L
         C_ = self.num_classes
         cfg.wgrad(self.conv, self.aa, dout)
         self.conv.bwd_data(dout, self.daa, cfg.st)
@@ -730,6 +750,9 @@ class ClassifierHead(Block):
 
     def __init__(self, store, cin, num_classes):
         self.name = "logits"
+        self.store = store
+        if store.dtype_code != F32:
+            raise NotImplementedError("the encoder-only classification heads run in float32 only")
         self.cin, self.num_classes = cin, num_classes
         self.dense = Conv(store, "logits", 1, 1, cin, num_classes, padding="valid", bias=True, init="glorot_uniform",
                           kernel_shape=(cin, num_classes))
@@ -738,7 +761,7 @@ class ClassifierHead(Block):
         return [self.dense]
 
     def plan(self, n, h, w, dev):
-        f32 = dict(dtype=torch.float32, device=dev)
+        f32 = dict(dtype=self.store.act_dtype, device=dev)
         self.n, self.hw = n, h * w
         self.dense.plan(n, 1, 1)
         self.pooled = torch.empty(n, 1, 1, self.cin, **f32)
@@ -765,6 +788,7 @@ class LogitsHead(Block):
 
     def __init__(self, store, cin, num_classes):
         self.name = "logits"
+        self.store = store
         self.conv = Conv(store, "logits", 2, 2, cin, num_classes, stride=2, bias=True, transpose=True)
         self.num_classes = num_classes
 
@@ -773,9 +797,9 @@ class LogitsHead(Block):
 
     def plan(self, n, h, w, dev):
         self.ho, self.wo = self.conv.plan(n, h, w)
-        self.out = torch.empty(n, self.ho, self.wo, self.num_classes, dtype=torch.float32, device=dev)
+        self.out = torch.empty(n, self.ho, self.wo, self.num_classes, dtype=self.store.act_dtype, device=dev)
         self.dout = torch.empty_like(self.out)
-        self.dx = torch.empty(n, h, w, self.conv.cin, dtype=torch.float32, device=dev)
+        self.dx = torch.empty(n, h, w, self.conv.cin, dtype=self.store.act_dtype, device=dev)
         return (self.ho, self.wo, self.num_classes)
 
     def fwd(self, x, cfg):
@@ -879,6 +903,13 @@ class GraphBase:
         n, h, w, c = images.shape
         assert c == 3 and images.dtype == torch.float32 and images.is_contiguous()
         self.plan(n, h, w)
+        if self.store.dtype_code == BF16:
+            # the batch arrives as float32 (src/generators.py:732-768); a bfloat16 network rounds it once, here
+            if getattr(self, "_images_act", None) is None or self._images_act.shape != images.shape:
+                self._images_act = torch.empty(images.shape, dtype=torch.bfloat16, device=images.device)
+            stq = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+            lib().cast_f32_to_bf16(_ptr(images), _ptr(self._images_act), images.numel(), stq)
+            images = self._images_act
         main = torch.cuda.current_stream()
         st = stream if stream is not None else main.cuda_stream
         side = self.side_stream if (self.overlap_weight_gradients and training and st == main.cuda_stream and st != 0) else None
@@ -923,11 +954,11 @@ class ENetGraph(GraphBase):
     """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling` /
     `enet-naive-upsampling-enhanced`."""
 
-    def __init__(self, variant: str, num_classes: int, device="cuda", encoder_only: bool = False):
+    def __init__(self, variant: str, num_classes: int, device="cuda", encoder_only: bool = False, act_dtype=torch.float32):
         assert variant in ("naive", "unpool", "enhanced")
         self.variant, self.num_classes, self.encoder_only = variant, num_classes, encoder_only
         self.device = torch.device(device)
-        st = self.store = ParamStore()
+        st = self.store = ParamStore(act_dtype)
         B = Bottleneck
         blocks: List[Block] = [InitialBlock(st, variant)]
         blocks.append(B(st, "en_bn_1.0", 16, 64, "enc", variant, downsample=True, dropout_rate=0.01))

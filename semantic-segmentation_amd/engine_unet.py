@@ -28,6 +28,7 @@ class ConvUnit:
 
     def __init__(self, store: ParamStore, name, cin, cout, use_bias, use_activation):
         self.name, self.cin, self.cout = name, cin, cout
+        self.store = store
         self.conv = Conv(store, name, 3, 3, cin, cout, padding="same", bias=use_bias)   # pad 1 + valid == SAME for 3x3/s1
         self.bn = BatchNorm(store, name + "_normalization", cout)
         self.act = ACT_LEAKY if use_activation else ACT_NONE
@@ -36,7 +37,7 @@ class ConvUnit:
         self.needs_dx = True
 
     def plan(self, n, h, w, dev, x_ld=None):
-        f32 = dict(dtype=torch.float32, device=dev)
+        f32 = dict(dtype=self.store.act_dtype, device=dev)      # activation type
         self.n, self.h, self.w, self.npix = n, h, w, n * h * w
         self.conv.plan(n, h, w, x_ld=x_ld)
         self.bn.plan(dev)
@@ -46,7 +47,7 @@ class ConvUnit:
         self.dx = torch.empty(n, h, w, self.cin, **f32) if self.needs_dx else None
 
     def fwd(self, x, cfg: RunCfg):
-        L = lib()
+        L = self.store.L
         bn = self.bn
         self.x = x
         if not cfg.training and not cfg.use_dropout:      # inference phase: BN + activation in the convolution's epilogue
@@ -62,7 +63,7 @@ class ConvUnit:
     def bn_bwd(self, dout_ptr, dout_ld, cfg: RunCfg):
         """dout: gradient w.r.t. `out` (raw pointer + pixel stride, it may be a channel slice) -> self.dy (gradient of
         the raw convolution output) and the BN parameter gradients."""
-        L = lib()
+        L = self.store.L
         bn = self.bn
         drop = self.drop_mask if cfg.use_dropout else None
         L.bn_act_drop_bwd(dout_ptr, dout_ld, _ptr(self.y), self.cout, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma),
@@ -120,6 +121,7 @@ class EncoderBlock(UnitBlock):
 
     def __init__(self, store, prefix, n_conv, cin, cout, first=False):
         self.name = prefix
+        self.store = store
         self.units = []
         c = cin
         for i in range(n_conv):
@@ -135,9 +137,9 @@ class EncoderBlock(UnitBlock):
             u.plan(n, h, w, dev)
         self.n, self.h, self.w = n, h, w
         c = self.cout
-        self.pooled = torch.empty(n, h // 2, w // 2, c, dtype=torch.float32, device=dev)
+        self.pooled = torch.empty(n, h // 2, w // 2, c, dtype=self.store.act_dtype, device=dev)
         self.idx = torch.empty(n, h // 2, w // 2, c, dtype=torch.int32, device=dev)
-        self.dskip = torch.empty(n, h, w, c, dtype=torch.float32, device=dev)
+        self.dskip = torch.empty(n, h, w, c, dtype=self.store.act_dtype, device=dev)
         return (h // 2, w // 2, c)
 
     @property
@@ -146,18 +148,18 @@ class EncoderBlock(UnitBlock):
 
     def fwd(self, x, cfg):
         s = self._fwd_units(x, cfg)
-        lib().maxpool_argmax_fwd(_ptr(s), self.n, self.h, self.w, self.cout, _ptr(self.pooled), self.cout, _ptr(self.idx),
+        self.store.L.maxpool_argmax_fwd(_ptr(s), self.n, self.h, self.w, self.cout, _ptr(self.pooled), self.cout, _ptr(self.idx),
                                  None, cfg.st)
         return self.pooled
 
     def bwd(self, dpooled, cfg):
-        L = lib()
+        L = self.store.L
         c = self.cout
         L.maxpool_argmax_bwd(_ptr(dpooled), c, _ptr(self.idx), self.n, self.h, self.w, c, _ptr(self.dskip), 0, cfg.st)
         if self.consumer is not None:
             # gradient of the concatenated copy: channel slice [c_up, c_up + c) of the decoder's input gradient
             dc = self.consumer
-            L.copy_ld(_ptr(dc.dcat) + 4 * dc.c_up, dc.c_cat, _ptr(self.dskip), c, self.n * self.h * self.w, c, 1, cfg.st)
+            L.copy_ld(_ptr(dc.dcat) + self.store.esize * dc.c_up, dc.c_cat, _ptr(self.dskip), c, self.n * self.h * self.w, c, 1, cfg.st)
         return self._bwd_units(self.dskip, cfg)
 
 
@@ -166,6 +168,7 @@ class ConnectingBlock(UnitBlock):
 
     def __init__(self, store, names_widths, cin):
         self.name = "connecting_block"
+        self.store = store
         self.units = []
         c = cin
         for name, f in names_widths:
@@ -191,6 +194,7 @@ class DecoderBlock(UnitBlock):
 
     def __init__(self, store, prefix, n_conv, c_up, skip_block: EncoderBlock, cout):
         self.name = prefix
+        self.store = store
         self.c_up, self.c_skip = c_up, skip_block.cout
         self.c_cat = c_up + skip_block.cout
         self.skip_block = skip_block
@@ -206,23 +210,23 @@ class DecoderBlock(UnitBlock):
         self.n, self.h, self.w = n, h, w
         H, W = 2 * h, 2 * w
         assert (self.skip_block.h, self.skip_block.w) == (H, W)
-        self.cat = torch.empty(n, H, W, self.c_cat, dtype=torch.float32, device=dev)
+        self.cat = torch.empty(n, H, W, self.c_cat, dtype=self.store.act_dtype, device=dev)
         for u in self.units:
             u.plan(n, H, W, dev)
         self.dcat = self.units[0].dx
-        self.dx = torch.empty(n, h, w, self.c_up, dtype=torch.float32, device=dev)
+        self.dx = torch.empty(n, h, w, self.c_up, dtype=self.store.act_dtype, device=dev)
         return (H, W, self.cout)
 
     def fwd(self, x, cfg):
-        L = lib()
+        L = self.store.L
         L.upsample_nn2x_fwd(_ptr(x), self.n, self.h, self.w, self.c_up, _ptr(self.cat), self.c_cat, cfg.st)
-        L.copy_ld(_ptr(self.skip_block.skip), self.c_skip, _ptr(self.cat) + 4 * self.c_up, self.c_cat,
+        L.copy_ld(_ptr(self.skip_block.skip), self.c_skip, _ptr(self.cat) + self.store.esize * self.c_up, self.c_cat,
                   self.n * 4 * self.h * self.w, self.c_skip, 0, cfg.st)
         return self._fwd_units(self.cat, cfg)
 
     def bwd(self, d, cfg):
         self._bwd_units(d, cfg)
-        lib().upsample_nn2x_bwd(_ptr(self.dcat), self.c_cat, self.n, self.h, self.w, self.c_up, _ptr(self.dx), cfg.st)
+        self.store.L.upsample_nn2x_bwd(_ptr(self.dcat), self.c_cat, self.n, self.h, self.w, self.c_up, _ptr(self.dx), cfg.st)
         return self.dx
 
 
@@ -231,6 +235,7 @@ class PointwiseHead(Block):
 
     def __init__(self, store, cin, num_classes):
         self.name = "logits"
+        self.store = store
         self.conv = Conv(store, "logits", 1, 1, cin, num_classes, padding="valid", bias=True)
         self.cin, self.num_classes = cin, num_classes
 
@@ -239,9 +244,9 @@ class PointwiseHead(Block):
 
     def plan(self, n, h, w, dev):
         self.conv.plan(n, h, w)
-        self.out = torch.empty(n, h, w, self.num_classes, dtype=torch.float32, device=dev)
+        self.out = torch.empty(n, h, w, self.num_classes, dtype=self.store.act_dtype, device=dev)
         self.dout = torch.empty_like(self.out)
-        self.dx = torch.empty(n, h, w, self.cin, dtype=torch.float32, device=dev)
+        self.dx = torch.empty(n, h, w, self.cin, dtype=self.store.act_dtype, device=dev)
         return (h, w, self.num_classes)
 
     def fwd(self, x, cfg):
@@ -270,13 +275,13 @@ SEGNET = dict(
 class UNetSegNetGraph(GraphBase):
     """`unet` / `segnet`: four encoder blocks, (U-Net) the connecting block, four decoder blocks, 1x1 logits."""
 
-    def __init__(self, kind: str, num_classes: int, device="cuda", encoder_only: bool = False):
+    def __init__(self, kind: str, num_classes: int, device="cuda", encoder_only: bool = False, act_dtype=torch.float32):
         assert kind in ("unet", "segnet")
         assert not (encoder_only and kind == "unet")      # the reference has no unet-encoder-only
         topo = UNET if kind == "unet" else SEGNET
         self.variant, self.num_classes, self.encoder_only = kind, num_classes, encoder_only
         self.device = torch.device(device)
-        st = self.store = ParamStore()
+        st = self.store = ParamStore(act_dtype)
         blocks: List[Block] = []
         encs: List[EncoderBlock] = []
         c = 3

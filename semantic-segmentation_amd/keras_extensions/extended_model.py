@@ -54,6 +54,9 @@ class ExtendedModel(object):
         # encoder-only model with the classification lambda loss (src/models.py:197-199, 706-729): labels and class weights
         # are [batch, classes] float tensors, the logits have rank 2
         self.classification = bool(classification and lambda_loss)
+        self.act_dtype = graph.store.act_dtype
+        if self.act_dtype != torch.float32 and (self.mean_teacher or self.superpixel or self.classification):
+            raise NotImplementedError("bfloat16 activations are implemented for the supervised segmentation loss only")
         if self.mean_teacher:
             self.input_names += ["mt_predictions", "consistency_cost"]
         if self.superpixel:
@@ -372,7 +375,7 @@ class ExtendedModel(object):
     # ------------------------------------------------------------------------------------------------
     def _segments(self, training: bool) -> List[Callable[[int], None]]:
         g = self.graph
-        L = lib()
+        L = g.store.L
         n, h, w = self._bufs_shape
         npix = n * h * w
         C_ = self.num_classes
@@ -574,7 +577,7 @@ class ExtendedModel(object):
         if use_training_phase_layers and self.graph.drop_groups:
             self._refresh_prediction_noise(st)
         self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
-        return self.graph.logits.detach().cpu().numpy()
+        return self.graph.logits.detach().float().cpu().numpy()
 
     def _refresh_prediction_noise(self, st):
         """Fresh SpatialDropout2D tables for a training-phase prediction: the Philox step is a device counter of this
@@ -596,7 +599,8 @@ class ExtendedModel(object):
         if use_training_phase_layers and self.graph.drop_groups:
             self._refresh_prediction_noise(st)
         self.graph.forward(self.images_buf, training=bool(use_training_phase_layers), update_moving=False, stream=st)
-        return self.graph.logits
+        lg = self.graph.logits
+        return lg if lg.dtype == torch.float32 else lg.float()      # consumers of predictions take float32
 
     def ema_update_from(self, student: "ExtendedModel", a: float):
         """Teacher update of the mean-teacher method (src/trainers.py:1692-1706) over EVERY weight get_weights()

@@ -60,7 +60,16 @@ def _norm_index(idx, n):
 class ModelBase(object):
     """src/models.py:157-205."""
 
-    def __init__(self, name, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, device="cuda"):
+    def __init__(self, name, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, device="cuda",
+                 dtype="f32"):
+        """`dtype` (no counterpart in the reference, which is float32 only): element type of the activation tensors in
+        device memory, "f32" or "bf16".  Parameters, statistics, optimizer state and arithmetic are float32 either way."""
+        import torch
+        try:
+            self.act_dtype = {"f32": torch.float32, "float32": torch.float32, torch.float32: torch.float32,
+                              "bf16": torch.bfloat16, "bfloat16": torch.bfloat16, torch.bfloat16: torch.bfloat16}[dtype]
+        except KeyError:
+            raise ValueError('Unknown activation dtype: {} (expected "f32" or "bf16")'.format(dtype))
         self.name = name
         self.input_shape = tuple(input_shape)
         self.num_classes = num_classes
@@ -204,7 +213,7 @@ class ENetNaiveUpsampling(ModelBase):
                          model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return ENetGraph("naive", self.num_classes, self.device, encoder_only=self.encoder_only)
+        return ENetGraph("naive", self.num_classes, self.device, encoder_only=self.encoder_only, act_dtype=self.act_dtype)
 
 
 class ENetMaxUnpooling(ModelBase):
@@ -216,7 +225,7 @@ class ENetMaxUnpooling(ModelBase):
                          model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return ENetGraph("unpool", self.num_classes, self.device, encoder_only=self.encoder_only)
+        return ENetGraph("unpool", self.num_classes, self.device, encoder_only=self.encoder_only, act_dtype=self.act_dtype)
 
 
 class ENetNaiveUpsamplingEnhanced(ModelBase):
@@ -228,7 +237,7 @@ class ENetNaiveUpsamplingEnhanced(ModelBase):
                          model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return ENetGraph("enhanced", self.num_classes, self.device, encoder_only=self.encoder_only)
+        return ENetGraph("enhanced", self.num_classes, self.device, encoder_only=self.encoder_only, act_dtype=self.act_dtype)
 
 
 class UNetModel(ModelBase):
@@ -238,7 +247,7 @@ class UNetModel(ModelBase):
         super().__init__("UNet", input_shape, num_classes, model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return UNetSegNetGraph("unet", self.num_classes, self.device)
+        return UNetSegNetGraph("unet", self.num_classes, self.device, act_dtype=self.act_dtype)
 
 
 class SegNetBasicModel(ModelBase):
@@ -250,7 +259,7 @@ class SegNetBasicModel(ModelBase):
                          model_lambda_loss_type, **kw)
 
     def _build_model(self):
-        return UNetSegNetGraph("segnet", self.num_classes, self.device, encoder_only=self.encoder_only)
+        return UNetSegNetGraph("segnet", self.num_classes, self.device, encoder_only=self.encoder_only, act_dtype=self.act_dtype)
 
 
 def get_model(model_name, input_shape, num_classes, model_lambda_loss_type=ModelLambdaLossType.NONE, **kw):

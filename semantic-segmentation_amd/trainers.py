@@ -180,7 +180,9 @@ class SegmentationTrainer(object):
                  (False, True): T.SEGMENTATION_SEMI_SUPERVISED_SUPERPIXEL,
                  (True, True): T.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER_SUPERPIXEL}[(self.using_mean_teacher_method,
                                                                                           self.using_superpixel_method)]
-        mb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes, ltype, device=self.device)
+        # "activation_dtype": "f32" (default) | "bf16": storage format of activations and their gradients in HBM
+        mb = models.get_model(model_name, tuple(config.get("input_shape", [None, None, 3])), num_classes, ltype, device=self.device,
+                              dtype=config.get("activation_dtype", "f32"))
         self.model_wrapper = mb
         self.model = mb.model
         self.model.seed = self.random_seed + self.rank   # independent dropout draws per replica

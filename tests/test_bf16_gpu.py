@@ -1,0 +1,391 @@
+"""bfloat16 activation storage (BASELINE configuration "ENet 512x512 batch 16, fp32 and bf16 training").
+
+Activations and their gradients live in HBM as bfloat16; kernels, statistics, optimizer state and every multiply-add are
+float32.  Three layers of checks:
+
+  * operator level, bit-exact: a bfloat16 kernel must return round-to-nearest-even(float32 kernel result) when both read
+    the same bfloat16-representable inputs - the arithmetic between load and store is the same code.  Weight gradients
+    (float32 outputs) must be identical.  That ties every bfloat16 kernel to its float32 twin, which tests/test_ops_gpu.py
+    ties to the fp64 oracle at rtol 1e-3;
+  * step level against the fp64 CPU oracle, BLOCK BY BLOCK on the kernels' own tensors: every block's output, input
+    gradient and parameter gradients within 2e-2 (relative L2 norm, the north star's bf16 tolerance) of the oracle's
+    evaluation of that block on the block input / output gradient the device stored, the oracle rounding to bfloat16 where
+    the kernels store (oracle/enet_oracle.py block_step, storage="bf16") and following the PReLU / pooling branches the
+    kernels took.  Whole-network tensors cannot carry that tolerance with this storage format, whoever computes them: a
+    rounding that falls the other way (one bfloat16 ulp = 2^-8 relative) is a fresh perturbation at every one of the ~100
+    stored tensors on the path, and the randomly initialised network amplifies perturbations about 40-fold from input to
+    logits - the fp64 oracle with bfloat16 storage sits 14 % (relative L2) from the oracle with exact storage, and two
+    evaluations with bfloat16 storage that differ in the last float32 bit sit as far from each other.  So the whole-network
+    checks are: the loss (a mean over all pixels) within 2e-2 of the exact oracle; the kernels' logits no farther from the
+    exact oracle than 1.5x the bfloat16-storage oracle's; pooling indices bit-exact against the oracle's pooling of the
+    kernel's own (rounded) input, confusion matrix bit-exact against the argmax of the kernel's own logits;
+  * training: the loss falls over 30 steps, HIP-graph replay equals eager launches bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import enet_oracle as E
+from oracle import tf_keras_ops as K
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+NC = 24
+
+
+def _bf(a):
+    """float64/32 numpy -> values representable in bfloat16 (as float32 numpy)."""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def _dev(a, dtype):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV).to(dtype)
+
+
+CONV_CASES = [
+    # kh kw cin cout stride dil padding bias  N  H  W
+    (3, 3, 3, 13, 2, 1, "same", True, 2, 16, 20),      # initial block (scalar path, 2-byte loads)
+    (2, 2, 16, 16, 2, 1, "valid", False, 2, 12, 8),    # downsampling projection / pixel-shuffle data gradient
+    (2, 2, 64, 32, 2, 1, "valid", False, 1, 8, 8),
+    (1, 1, 64, 16, 1, 1, "valid", False, 2, 9, 7),     # LDS-weight kernel, 16x16 tiles, ragged pixels
+    (1, 1, 16, 64, 1, 1, "valid", False, 1, 8, 8),
+    (1, 1, 32, 128, 1, 1, "valid", False, 1, 8, 8),
+    (1, 1, 128, 32, 1, 1, "valid", False, 1, 6, 6),
+    (3, 3, 16, 16, 1, 1, "same", True, 2, 8, 10),
+    (3, 3, 32, 32, 1, 1, "same", True, 1, 9, 9),
+    (3, 3, 32, 32, 1, 16, "same", True, 1, 8, 8),
+    (1, 5, 32, 32, 1, 1, "same", False, 1, 6, 11),
+    (5, 1, 32, 32, 1, 1, "same", True, 1, 11, 6),
+    (3, 3, 4, 4, 1, 1, "same", True, 2, 8, 8),
+    (1, 1, 64, 4, 1, 1, "valid", False, 1, 8, 8),
+    (3, 3, 5, 7, 2, 1, "same", True, 1, 7, 9),         # odd everything
+    (3, 3, 64, 64, 1, 1, "same", True, 2, 9, 11),      # wide layers: tiled weight gradient
+    (3, 3, 32, 128, 1, 1, "same", False, 1, 8, 8),
+]
+
+
+def _conv_pair(case, transpose=False):
+    kh, kw, cin, cout, s, d, pad, bias, N, H, W = case
+    eng = pkg("engine")
+    rng = np.random.RandomState(sum((i + 1) * int(v) for i, v in enumerate(case) if not isinstance(v, str)))
+    w = rng.standard_normal((kh, kw, cout, cin) if transpose else (kh, kw, cin, cout)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32) if bias else None
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        store = eng.ParamStore(dt)
+        cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=s, dil=d, padding=pad, bias=bias, transpose=transpose)
+        store.materialise(torch.device(DEV))
+        store.views["c/kernel"].copy_(torch.from_numpy(w))
+        if bias:
+            store.views["c/bias"].copy_(torch.from_numpy(b))
+        ho, wo = cv.plan(N, H, W)
+        out[dt] = (store, cv, ho, wo)
+    return out, rng
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}".format(*c[:7]))
+def test_conv2d_bf16_equals_rounded_float32_kernel(case):
+    kh, kw, cin, cout, s, d, pad, bias, N, H, W = case
+    pair, rng = _conv_pair(case)
+    ho, wo = pair[torch.float32][2:]
+    x = _bf(rng.standard_normal((N, H, W, cin)))
+    dy = _bf(rng.standard_normal((N, ho, wo, cout)))
+    add = _bf(rng.standard_normal((N, H, W, cin)))
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for dt, (store, cv, _, _) in pair.items():
+        xd, dyd, addd = _dev(x, dt), _dev(dy, dt), _dev(add, dt)
+        y = torch.full((N, ho, wo, cout), 7.0, device=DEV, dtype=dt)
+        cv.fwd(xd, y, st)
+        dx = torch.full((N, H, W, cin), 7.0, device=DEV, dtype=dt)
+        cv.bwd_data(dyd, dx, st)
+        dx2 = torch.full((N, H, W, cin), 7.0, device=DEV, dtype=dt)
+        cv.bwd_data(dyd, dx2, st, add=addd)
+        ws = torch.empty(cv.ws_bytes // 4 + 8, device=DEV)
+        cv.bwd_weight(xd, dyd, ws, st)
+        torch.cuda.synchronize()
+        res[dt] = dict(y=y, dx=dx, dx2=dx2, dw=store.gviews["c/kernel"].clone(),
+                       db=store.gviews["c/bias"].clone() if bias else None)
+    a, b = res[torch.float32], res[torch.bfloat16]
+    for k in ("y", "dx", "dx2"):
+        assert torch.equal(a[k].to(torch.bfloat16), b[k]), "{}: bf16 kernel != rounded float32 kernel".format(k)
+    assert torch.equal(a["dw"], b["dw"]), "weight gradient differs between the storage types"
+    if bias:
+        assert torch.equal(a["db"], b["db"])
+
+
+@pytest.mark.parametrize("k,cin,cout,N,H,W", [(3, 16, 16, 2, 6, 5), (3, 4, 4, 1, 8, 8), (2, 16, 24, 2, 5, 7), (2, 16, 24, 1, 3, 40)])
+def test_conv2d_transpose_bf16_equals_rounded_float32_kernel(k, cin, cout, N, H, W):
+    case = (k, k, cin, cout, 2, 1, "same", True, N, H, W)
+    pair, rng = _conv_pair(case, transpose=True)
+    ho, wo = pair[torch.float32][2:]
+    x = _bf(rng.standard_normal((N, H, W, cin)))
+    dy = _bf(rng.standard_normal((N, ho, wo, cout)))
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for dt, (store, cv, _, _) in pair.items():
+        y = torch.empty(N, ho, wo, cout, device=DEV, dtype=dt)
+        cv.fwd(_dev(x, dt), y, st)
+        dx = torch.empty(N, H, W, cin, device=DEV, dtype=dt)
+        cv.bwd_data(_dev(dy, dt), dx, st)
+        ws = torch.empty(cv.ws_bytes // 4 + 8, device=DEV)
+        cv.bwd_weight(_dev(x, dt), _dev(dy, dt), ws, st)
+        torch.cuda.synchronize()
+        res[dt] = (y, dx, store.gviews["c/kernel"].clone(), store.gviews["c/bias"].clone())
+    a, b = res[torch.float32], res[torch.bfloat16]
+    assert torch.equal(a[0].to(torch.bfloat16), b[0]) and torch.equal(a[1].to(torch.bfloat16), b[1])
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("c,npix,act", [(16, 1000, 1), (4, 333, 1), (128, 260, 1), (64, 77, 0), (24, 50, 2)])
+def test_bn_act_bf16_equals_rounded_float32_kernel(c, npix, act):
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(c + npix)
+    x = _bf(rng.standard_normal((npix, c)) * 2 + 0.5)
+    dy = _bf(rng.standard_normal((npix, c)))
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    gamma, beta, alpha = f(rng.uniform(0.5, 1.5, c)), f(rng.uniform(-0.5, 0.5, c)), f(rng.uniform(0.05, 0.4, c))
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for dt, sfx in ((torch.float32, ""), (torch.bfloat16, "_bf16")):
+        xd, dyd = _dev(x, dt), _dev(dy, dt)
+        mean, invstd = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        ws = torch.empty(L.bn_workspace_bytes(npix, c) // 4 + 8, device=DEV)
+        getattr(L, "bn_train_stats" + sfx)(xd.data_ptr(), npix, c, c, 1e-3, 0.1, 0, None, None, mean.data_ptr(), invstd.data_ptr(),
+                                           ws.data_ptr(), ws.numel() * 4, st)
+        y = torch.empty(npix, c, device=DEV, dtype=dt)
+        getattr(L, "bn_act_fwd" + sfx)(xd.data_ptr(), c, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), act,
+                                       alpha.data_ptr(), 0.1, y.data_ptr(), npix, c, st)
+        dx = torch.empty(npix, c, device=DEV, dtype=dt)
+        dg, db, da = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        getattr(L, "bn_act_bwd" + sfx)(dyd.data_ptr(), xd.data_ptr(), c, mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(),
+                                       beta.data_ptr(), act, alpha.data_ptr(), 0.1, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                       da.data_ptr(), npix, c, ws.data_ptr(), ws.numel() * 4, st)
+        torch.cuda.synchronize()
+        res[dt] = (mean, invstd, y, dx, dg, db, da)
+    a, b = res[torch.float32], res[torch.bfloat16]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[2].to(torch.bfloat16), b[2]) and torch.equal(a[3].to(torch.bfloat16), b[3])
+    assert torch.equal(a[4], b[4]) and torch.equal(a[5], b[5]) and torch.equal(a[6], b[6])
+
+
+@pytest.mark.parametrize("mode,c,c_other,h,w", [(0, 64, 64, 6, 10), (1, 64, 16, 8, 6), (2, 16, 16, 8, 12), (3, 64, 64, 4, 6)])
+def test_merge_bf16_equals_rounded_float32_kernel(mode, c, c_other, h, w):
+    lib_mod = pkg("_lib")
+    L = lib_mod.lib()
+    import ctypes as C
+    n = 2
+    rng = np.random.RandomState(mode * 31 + c)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(DEV)
+    main = _bf(rng.standard_normal((n, h, w, c)))
+    dout = _bf(rng.standard_normal((n, h, w, c)))
+    oshape = (n, h, w, c) if mode == 0 else ((n, h, w, c_other) if mode == 1 else (n, h // 2, w // 2, c))
+    other = _bf(rng.standard_normal(oshape))
+    p3 = [f(rng.standard_normal(c) * 0.1), f(rng.uniform(0.5, 2, c)), f(rng.uniform(0.5, 1.5, c)), f(rng.uniform(-0.5, 0.5, c))]
+    po = [f(rng.standard_normal(c) * 0.1), f(rng.uniform(0.5, 2, c)), f(rng.uniform(0.5, 1.5, c)), f(rng.uniform(-0.5, 0.5, c))]
+    alpha = f(rng.uniform(-0.2, 0.5, c))
+    drop = f((rng.uniform(size=(n, c)) > 0.2) / 0.8)
+    idx = None
+    if mode == 3:      # indices a 2x2 pooling of random data would produce
+        _, idx_np = K.max_pool_with_argmax_np(rng.standard_normal((n, h, w, c)))
+        idx = torch.from_numpy(idx_np.astype(np.int32)).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for dt, code in ((torch.float32, lib_mod.F32), (torch.bfloat16, lib_mod.BF16)):
+        md = lib_mod.MergeDesc()
+        md.n, md.h, md.w, md.c, md.other_mode, md.c_other, md.dtype = n, h, w, c, mode, c_other, code
+        bn3 = lib_mod.BnParams(*[t.data_ptr() for t in p3])
+        bno = lib_mod.BnParams(*[t.data_ptr() for t in po])
+        mainD, otherD, doutD = _dev(main, dt), _dev(other, dt), _dev(dout, dt)
+        out = torch.empty(n, h, w, c, device=DEV, dtype=dt)
+        L.merge_fwd(C.byref(md), mainD.data_ptr(), C.byref(bn3), drop.data_ptr(), otherD.data_ptr(), C.byref(bno),
+                    None if idx is None else idx.data_ptr(), alpha.data_ptr(), out.data_ptr(), st)
+        dmain, dsum = torch.empty_like(out), torch.empty_like(out)
+        doth = torch.empty(oshape, device=DEV, dtype=dt) if mode >= 2 else None
+        dg, db, da = torch.zeros(c, device=DEV), torch.zeros(c, device=DEV), torch.zeros(c, device=DEV)
+        ws = torch.empty(L.merge_workspace_bytes(C.byref(md)) // 4 + 8, device=DEV)
+        L.merge_bwd(C.byref(md), doutD.data_ptr(), mainD.data_ptr(), C.byref(bn3), drop.data_ptr(), otherD.data_ptr(), C.byref(bno),
+                    None if idx is None else idx.data_ptr(), alpha.data_ptr(), dmain.data_ptr(), dsum.data_ptr(),
+                    None if doth is None else doth.data_ptr(), dg.data_ptr(), db.data_ptr(), da.data_ptr(), ws.data_ptr(),
+                    ws.numel() * 4, st)
+        torch.cuda.synchronize()
+        res[dt] = (out, dsum, dg, db, da, dmain, doth)
+    a, b = res[torch.float32], res[torch.bfloat16]
+    assert torch.equal(a[0].to(torch.bfloat16), b[0]), "merge output"
+    assert torch.equal(a[1].to(torch.bfloat16), b[1]), "dsum"
+    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]), "parameter gradients"
+    # dmain / dother re-read the ROUNDED dsum in the bfloat16 build: one rounding apart, not bit-equal
+    for k in (5, 6):
+        if a[k] is not None:
+            ref, got = a[k].double(), b[k].double()
+            assert float((ref - got).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()), "dmain / dother"
+
+
+def test_pool_and_loss_bf16():
+    L = pkg("_lib").lib()
+    rng = np.random.RandomState(5)
+    st = torch.cuda.current_stream().cuda_stream
+    for (n, h, w, c) in ((2, 8, 12, 16), (1, 7, 9, 3), (2, 6, 6, 64)):
+        x = _bf(rng.standard_normal((n, h, w, c)))
+        x[0, :2, :2, 0] = 0.5      # a tie: the first element of the window wins
+        ho, wo = (h + 1) // 2, (w + 1) // 2
+        xd = _dev(x, torch.bfloat16)
+        y = torch.empty(n, ho, wo, c, device=DEV, dtype=torch.bfloat16)
+        idx = torch.empty(n, ho, wo, c, device=DEV, dtype=torch.int32)
+        L.maxpool_argmax_fwd_bf16(xd.data_ptr(), n, h, w, c, y.data_ptr(), c, idx.data_ptr(), None, st)
+        ref_y, ref_i = K.max_pool_with_argmax_np(x)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), ref_i) and np.array_equal(y.float().cpu().numpy(), ref_y)
+        dy = _bf(rng.standard_normal((n, ho, wo, c)))
+        dx = torch.empty(n, h, w, c, device=DEV, dtype=torch.bfloat16)
+        L.maxpool_argmax_bwd_bf16(_dev(dy, torch.bfloat16).data_ptr(), c, idx.data_ptr(), n, h, w, c, dx.data_ptr(), 0, st)
+        ref_dx = np.zeros((n, h * w * c), np.float32)
+        np.add.at(ref_dx, (np.arange(n)[:, None], ref_i.reshape(n, -1)), dy.reshape(n, -1))
+        assert np.array_equal(dx.float().cpu().numpy(), ref_dx.reshape(n, h, w, c))
+    # loss: bfloat16 logits in, float32 arithmetic, rounded gradient out; confusion matrix exact
+    for C_, npix in ((24, 5000), (7, 333)):
+        logits = _bf(rng.standard_normal((npix, C_)) * 3)
+        labels = rng.randint(0, C_, size=npix).astype(np.int32)
+        wts = rng.uniform(0.2, 2.0, size=npix).astype(np.float32)
+        out = {}
+        lab_d, wts_d = torch.from_numpy(labels).to(DEV), torch.from_numpy(wts).to(DEV)
+        for dt, sfx in ((torch.float32, ""), (torch.bfloat16, "_bf16")):
+            lg = _dev(logits, dt)
+            dl = torch.empty(npix, C_, device=DEV, dtype=dt)
+            loss = torch.zeros(1, device=DEV)
+            cm = torch.zeros(C_, C_, dtype=torch.int64, device=DEV)
+            ws = torch.empty(L.softmax_xent_workspace_bytes(npix) // 4 + 8, device=DEV)
+            getattr(L, "softmax_xent_fwd_bwd" + sfx)(lg.data_ptr(), lab_d.data_ptr(), wts_d.data_ptr(), npix, C_, 1.0, dl.data_ptr(),
+                                                     loss.data_ptr(), cm.data_ptr(), npix, 1, None, None, ws.data_ptr(),
+                                                     ws.numel() * 4, st)
+            torch.cuda.synchronize()
+            out[dt] = (loss.clone(), dl, cm)
+        a, b = out[torch.float32], out[torch.bfloat16]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1].to(torch.bfloat16), b[1]) and torch.equal(a[2], b[2])
+        assert np.array_equal(b[2].cpu().numpy(), K.confusion_matrix_np(labels, logits, C_, [0]))
+
+
+def _compiled(name, w0, lr=5e-4, dtype="bf16"):
+    models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
+    m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY,
+                         dtype=dtype).model
+    m.set_weights([w0[k] for k in m.weight_names()])
+    m.compile(optimizer=xo.Adam(lr=lr), metrics={'logits': [metrics.segmentation_accuracy(0, [0]),
+                                                            metrics.segmentation_confusion_matrix(NC, 0, [0])]})
+    return m
+
+
+def _np(t):
+    return t.float().cpu().numpy().astype(np.float64)
+
+
+def _rel_l2(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.linalg.norm(np.asarray(got, np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+@pytest.mark.parametrize("name,B,H,W,seed", [("enet-naive-upsampling", 2, 64, 64, 3), ("enet-max-unpooling", 2, 64, 96, 5),
+                                             ("enet-naive-upsampling-enhanced", 2, 48, 80, 9)])
+def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed):
+    from test_parity_step_gpu import _hip_branches
+    w0 = E.init_weights(name, NC, seed=seed, perturb=True)
+    m = _compiled(name, w0)
+    cw = np.ones(NC, dtype=np.float32)
+    cw[0] = 0
+    cw[1:] = 0.5 + np.arange(1, NC) / 23.0
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=seed + 100, block=8, class_weights=cw)
+    masks = E.make_dropout_masks(name, B, seed)
+    m._ensure_buffers(B, H, W)
+    g = m.graph
+    assert g.store.act_dtype == torch.bfloat16
+    g.drop_groups = []
+    for k, mk in masks.items():
+        g.drop_views[k].copy_(torch.from_numpy(mk.astype(np.float32)))
+    m.use_hip_graph = False
+    with torch.cuda.stream(torch.cuda.Stream()):
+        outs = m.train_on_batch([images, labels, pw, np.zeros((B, 1), np.int32)])
+    torch.cuda.synchronize()
+    assert g.logits.dtype == torch.bfloat16 and g.by_name["en_bn_1.0"].y1.dtype == torch.bfloat16
+    forced = _hip_branches(m, w0)
+    hip_logits = g.logits.float().cpu().numpy()
+    # --- whole network, quantities that survive compounding --------------------------------------------------------------
+    ref = E.train_step(name, w0, images, labels, pw, masks)                       # exact storage, the oracle's own branches
+    refq = E.train_step(name, w0, images, labels, pw, masks, storage="bf16")      # same arithmetic, bfloat16 storage
+    # the loss is a mean over all pixels: storage rounding averages out of it even where single logits moved
+    assert abs(outs[0] - ref["loss"]) <= 2e-2 * abs(ref["loss"]), (outs[0], ref["loss"])
+    # the kernels' distance to exact storage is the distance ANY evaluation with bfloat16 storage has (here: the fp64
+    # oracle with the storage roundings inserted), not more
+    e_hip, e_emul = _rel_l2(hip_logits, ref["logits"]), _rel_l2(refq["logits"], ref["logits"])
+    assert e_hip <= 1.5 * e_emul + 1e-3, (e_hip, e_emul)
+    # bit-exact integer artefacts: pooling indices for the kernel's own (rounded) input, matrix for the kernel's own logits
+    for bname in ("en_bn_1.0", "en_bn_2.0"):
+        blk = g.by_name[bname]
+        pooled, idx = K.max_pool_with_argmax_np(blk.x.float().cpu().numpy())
+        assert np.array_equal(blk.idx.cpu().numpy().astype(np.int64), idx), "argmax indices of " + bname
+        assert np.array_equal(blk.pooled.float().cpu().numpy(), pooled)
+    assert np.array_equal(outs[4], K.confusion_matrix_np(labels, hip_logits, NC, [0]))
+    # --- block by block on the kernels' own tensors, rtol 2e-2 -----------------------------------------------------------
+    blocks = g.blocks
+    worst = {"out": (0.0, ""), "dx": (0.0, ""), "grad": (0.0, "")}
+
+    def note(kind, e, what):
+        if e > worst[kind][0]:
+            worst[kind] = (e, what)
+        assert e <= 2e-2, "{} of {}: relative L2 error {:.3e}".format(kind, what, e)
+
+    for i, blk in enumerate(blocks):
+        last = i == len(blocks) - 1
+        bname = "initial_block" if i == 0 else ("head" if last else blk.name)
+        x_in = g._images_act if i == 0 else blocks[i - 1].out
+        dout = g.dlogits if last else blocks[i + 1].dx
+        ui = getattr(blk, "unpool_idx", None)
+        r = E.block_step(name, w0, bname, _np(x_in), _np(dout), masks, forced, "bf16",
+                         None if ui is None else ui.cpu().numpy().astype(np.int64))
+        note("out", _rel_l2(_np(blk.out), r["out"]), bname)
+        if r["dx"] is not None:
+            note("dx", _rel_l2(_np(blk.dx), r["dx"]), bname)
+        for k, gr in r["grads"].items():
+            got = g.store.gviews[k].cpu().numpy().astype(np.float64)
+            if k.endswith("/bias") and k not in ("logits/bias",) + (("initial_block_conv2d/bias",) * (name == "enet-max-unpooling")):
+                # every other bias sits in front of a BatchNormalization: its gradient is the sum of a tensor that sums to
+                # zero in exact arithmetic, what is left is the rounding residue of that tensor's storage on both sides
+                lim = 2e-2 * np.abs(r["grads"][k[:-5] + "/kernel"]).max()
+                assert np.abs(got).max() <= lim and np.abs(gr).max() <= lim, k
+                continue
+            note("grad", _rel_l2(got, gr), k)
+    print("{} bf16, block by block against the fp64 oracle with bf16 storage: worst block output {:.2e} ({}), input gradient "
+          "{:.2e} ({}), parameter gradient {:.2e} ({}); whole network against exact storage: logits {:.3f} (the oracle with "
+          "bf16 storage: {:.3f}), loss {:.5f} vs {:.5f}".format(name, worst["out"][0], worst["out"][1], worst["dx"][0],
+                                                               worst["dx"][1], worst["grad"][0], worst["grad"][1], e_hip, e_emul,
+                                                               outs[0], ref["loss"]))
+
+
+def test_bf16_training_loss_falls_and_graph_replay_is_exact():
+    name, B, H, W, lr = "enet-naive-upsampling", 2, 64, 64, 2e-3
+    w0 = E.init_weights(name, NC, seed=21, perturb=True)
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=33, block=16)
+    x = [images, labels, pw, np.zeros((B, 1), np.int32)]
+    runs = {}
+    for mode in ("graph", "eager"):
+        m = _compiled(name, w0, lr=lr)
+        m.use_hip_graph = mode == "graph"
+        losses_ = []
+        with torch.cuda.stream(torch.cuda.Stream()):
+            for step in range(30 if mode == "graph" else 4):
+                losses_.append(m.train_on_batch(x)[0])
+                if step == 3:
+                    torch.cuda.synchronize()
+                    runs[mode] = (list(losses_), m.graph.store.theta.clone())
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert losses_[-1] < 0.9 * losses_[0] and np.mean(losses_[-5:]) < np.mean(losses_[:5]), losses_
+        m.close()
+    assert runs["graph"][0] == runs["eager"][0] and torch.equal(runs["graph"][1], runs["eager"][1])
+
+
+def test_bf16_rejects_what_it_does_not_implement():
+    models, losses = pkg("models"), pkg("losses")
+    with pytest.raises(ValueError):
+        models.get_model("enet-naive-upsampling", (None, None, 3), NC, dtype="fp8")
+    with pytest.raises(NotImplementedError):
+        models.get_model("enet-naive-upsampling", (None, None, 3), NC,
+                         losses.ModelLambdaLossType.SEGMENTATION_SEMI_SUPERVISED_MEAN_TEACHER, dtype="bf16")

@@ -40,7 +40,7 @@ def _close(a, b, rtol, atol, what):
 
 
 def _f32(t):
-    return t.detach().cpu().numpy().astype(np.float32)
+    return t.detach().float().cpu().numpy()
 
 
 def _hip_branches(model, w_before):
