@@ -185,6 +185,33 @@ def main():
     ms = elapsed / args.steps * 1e3
     value = args.batch * world * args.steps / elapsed
 
+    # Data-parallel runs: where a step's time goes, from HIP events on the step's stream over a few extra (untimed) steps -
+    # each backward segment, the time the stream then waits for each gradient bucket, the optimizer - maximum over ranks.
+    dp = None
+    if tr.reducer is not None and args.mode == "train":
+        red = tr.reducer
+        b0, n0 = red.bytes_reduced, red.buckets_started
+        k = min(args.steps, 10)
+        with torch.cuda.stream(stream):
+            model.segment_timing(True)
+            for _ in range(k):
+                model.train_step_async()
+            times = model.segment_times_ms()
+            model.segment_timing(False)
+        if times is not None:       # eager launches (--eager) carry no marks
+            flat = torch.tensor(times["segments"] + times["bucket_waits"] + [times["optimizer"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(flat, op=dist.ReduceOp.MAX)
+            flat = [round(v, 3) for v in flat.tolist()]
+            ns = len(times["segments"])
+            times = {"segments_ms": flat[:ns], "bucket_wait_ms": flat[ns:-1], "optimizer_ms": flat[-1]}
+        dp = dict({"backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                   "buckets_per_step": (red.buckets_started - n0) // k, "bytes_reduced_per_step": (red.bytes_reduced - b0) // k,
+                   "bucket_bytes": [(hi - lo) * 4 for lo, hi in model.bucket_ranges()],
+                   "note": "segments_ms[0] = dropout tables + forward + loss + backward of the blocks behind the first cut; "
+                           "bucket_wait_ms[j] = time the stream waited for bucket j after the last backward segment "
+                           "(0 when the all-reduce was hidden behind backward work); maximum over ranks, {} steps".format(k)},
+                  **(times or {}))
+
     if args.mode == "eval":
         if rank == 0:
             cm = ev["confusion_matrix"]
@@ -236,7 +263,7 @@ def main():
                    "inputs": {None: "resident in HBM", "f32": "float32 host arrays staged every step (PCIe-inclusive)",
                               "u8": "uint8 host arrays through pinned double buffers + device pre-pass every step "
                                     "(PCIe-inclusive, overlapped)"}[args.host_inputs]},
-               "roofline": roof, "cpu_baseline": cpu, "bf16": bf16}
+               "roofline": roof, "cpu_baseline": cpu, "bf16": bf16, "data_parallel": dp}
         print(json.dumps(out), flush=True)
     if world > 1:
         # rank 0 measured the roofline alone; the others wait here so that no rank tears the group down under it

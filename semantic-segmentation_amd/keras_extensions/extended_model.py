@@ -36,6 +36,16 @@ class LayerInfo:
         self.name, self.weight_keys, self.trainable = name, list(weight_keys), True
 
 
+class _Marks:
+    """Collects one timing event per call of append() (handed to the reducer, which calls it after each bucket wait)."""
+
+    def __init__(self, mark):
+        self._mark, self.events = mark, []
+
+    def append(self, _=None):
+        self.events.append(self._mark())
+
+
 class ExtendedModel(object):
 
     def __init__(self, name: str, graph: ENetGraph, input_shape, num_classes: int, lambda_loss: bool,
@@ -79,6 +89,8 @@ class ExtendedModel(object):
         self._unbiased_moving_variance = False
         self.use_hip_graph = True
         self.grad_sync = None          # trainers.GradientBucketReducer when data-parallel
+        self._timed_steps = None       # list of per-step event records while segment_timing(True)
+        self._step_marks = None
         self._bufs_shape = None
         self._noise_counter = None     # device int64: Philox step of predict_on_batch(use_training_phase_layers=True)
         self._cm = None
@@ -424,31 +436,32 @@ class ExtendedModel(object):
                 loss_call(st, False)
             return [seg_eval]
 
-        split = self._split_index()
         blocks = g.blocks
+        cuts = self._cut_indices() if self.grad_sync is not None else []
+        bounds = [len(blocks)] + cuts + [0]        # backward segment j covers blocks[bounds[j+1]:bounds[j]]
+        carry = {}
 
-        def seg_a(st):
+        def seg_first(st):
             if g.drop_groups:
                 g.refresh_dropout(self.seed, self.optimizer.step_block, stream=st)
             g.forward(self.images_buf, training=True, update_moving=True, unbiased_moving=self.unbiased_moving_variance,
                       stream=st)
             loss_call(st, True)
-            d = g.dlogits
-            for b in reversed(blocks[split:]):
-                d = b.bwd(d, g._cfg)
-                g._cfg.flush()
-            if self.grad_sync is not None:      # bucket 1 must be complete before its all-reduce starts
-                g._cfg.join()
-            self._d_mid = d
+            carry["d"] = g.dlogits
+            seg_bwd(0)(st)
 
-        def seg_b(st):
-            d = self._d_mid
-            for b in reversed(blocks[:split]):
-                d = b.bwd(d, g._cfg)
-                g._cfg.flush()
-            g._cfg.join()
+        def seg_bwd(j):
+            def run(st):
+                d = carry["d"]
+                for b in reversed(blocks[bounds[j + 1]:bounds[j]]):
+                    d = b.bwd(d, g._cfg)
+                    g._cfg.flush()
+                if self.grad_sync is not None or j == len(bounds) - 2:
+                    g._cfg.join()       # a bucket must be complete before its all-reduce starts
+                carry["d"] = d
+            return run
 
-        def seg_c(st):
+        def seg_opt(st):
             # the hyper-parameter block is flushed by _run before the launch (a copy cannot be part of a captured graph)
             self.optimizer.apply(grad_scale=self._grad_scale(), stream=st, capturing=True)
 
@@ -456,27 +469,54 @@ class ExtendedModel(object):
             # no collective between the segments: one graph for the whole step (also lets the weight gradients of the late
             # blocks keep running beside the early blocks' data-gradient chain instead of being joined in between)
             def seg_all(st):
-                seg_a(st)
-                seg_b(st)
-                seg_c(st)
+                seg_first(st)
+                seg_opt(st)
             return [seg_all]
-        return [seg_a, seg_b, seg_c]
+        return [seg_first] + [seg_bwd(j) for j in range(1, len(bounds) - 1)] + [seg_opt]
 
-    def _split_index(self) -> int:
-        """Backward is cut in front of en_bn_2.0: the late blocks hold ~95 % of the parameters, the early blocks the
-        high-resolution (slow) backward work that hides the first bucket's all-reduce."""
-        for i, b in enumerate(self.graph.blocks):
-            if b.name == "en_bn_2.0":
-                return i
-        return len(self.graph.blocks) // 2
+    BUCKET_BYTES = 25 << 20      # gradient bytes per all-reduce for the wide models (SegNet 83 MB, U-Net 124 MB)
+    MAX_BUCKETS = 8
+
+    def _block_offsets(self):
+        """Arena offset of every block's first parameter (None for parameter-free blocks), or None when the arena does not
+        follow the block order (then the whole arena is one bucket)."""
+        st = self.graph.store
+        offs, last = [], -1
+        for b in self.graph.blocks:
+            o = [st.specs[c.name + "/kernel"].offset for c in b.convs() if c.name + "/kernel" in st.specs]
+            o = min(o) if o else None
+            if o is not None:
+                if o <= last:
+                    return None
+                last = o
+            offs.append(o)
+        return offs
+
+    def _cut_indices(self) -> List[int]:
+        """Block indices (descending) in front of which the backward pass is cut so that the gradients behind the cut can be
+        all-reduced while the rest of the backward pass runs.  ENets (1.46 MB of gradients): one cut in front of en_bn_2.0 -
+        the late blocks hold ~95 % of the parameters, the early blocks the high-resolution (slow) backward work that hides
+        the first bucket's all-reduce.  Wide models: a cut whenever ~BUCKET_BYTES of gradients have become final, in the
+        order the backward pass produces them (last layers first)."""
+        blocks = self.graph.blocks
+        offs = self._block_offsets()
+        if offs is None:
+            return []
+        for i, b in enumerate(blocks):
+            if b.name == "en_bn_2.0" and offs[i] is not None:
+                return [i]
+        cuts, hi = [], self.graph.store.theta.numel()
+        for i in range(len(blocks) - 1, 0, -1):
+            if offs[i] is not None and (hi - offs[i]) * 4 >= self.BUCKET_BYTES and len(cuts) < self.MAX_BUCKETS - 1:
+                cuts.append(i)
+                hi = offs[i]
+        return cuts
 
     def bucket_ranges(self):
         """[(lo, hi)] element ranges of the gradient arena, in the order they become final during backward."""
-        st = self.graph.store
-        split_block = self.graph.blocks[self._split_index()]
-        first_key = split_block.convs()[0].name + "/kernel"
-        cut = st.specs[first_key].offset
-        return [(cut, st.theta.numel()), (0, cut)]
+        offs = self._block_offsets()
+        edges = [self.graph.store.theta.numel()] + [offs[i] for i in self._cut_indices()] + [0]
+        return [(edges[j + 1], edges[j]) for j in range(len(edges) - 1)]
 
     def _grad_scale(self) -> float:
         return 1.0 / self.grad_sync.world_size if self.grad_sync is not None else 1.0
@@ -509,19 +549,66 @@ class ExtendedModel(object):
                     L.graph_end_capture(st, C.byref(h))
                 glist.append(h)
             self._graphs[key] = glist
+        timed = training and self.grad_sync is not None and self._timed_steps is not None
+        if timed:
+            def mark():
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                return e
+            self._step_marks = _Marks(mark)
+            seg_events = [mark()]
         for h, hk in zip(self._graphs[key], hooks):
             L.graph_launch(h, st)
+            if timed:
+                seg_events.append(mark())
             hk()
+        if timed:
+            self._timed_steps.append({"seg": seg_events, "waits": self._step_marks.events})
+            self._step_marks = None
 
     def _hooks(self, training):
-        if not training:
-            return [lambda: None]
-        if self.grad_sync is None:
+        """What the host does after each segment's launch: start that segment's bucket; after the last backward segment also
+        make the stream wait for every bucket; nothing after the optimizer."""
+        if not training or self.grad_sync is None:
             return [lambda: None]
         rs = self.bucket_ranges()
         gs = self.grad_sync
         grad = self.graph.store.grad
-        return [lambda: gs.start(grad, rs[0]), lambda: (gs.start(grad, rs[1]), gs.finish()), lambda: None]
+        hooks = [(lambda r=r: gs.start(grad, r)) for r in rs[:-1]]
+        hooks.append(lambda: (gs.start(grad, rs[-1]), gs.finish(self._wait_marks())))
+        hooks.append(lambda: None)
+        return hooks
+
+    # -- per-segment timing of data-parallel steps (HIP events on the step's stream) ---------------------------------------
+    def _wait_marks(self):
+        return self._step_marks.append if self._step_marks is not None else None
+
+    def segment_timing(self, on: bool):
+        """While on, every data-parallel training step records an event after each segment launch and after each bucket
+        wait; segment_times_ms() turns them into per-step means."""
+        self._timed_steps = [] if on else None
+
+    def segment_times_ms(self):
+        """{"segments": [ms per backward segment...], "bucket_waits": [ms the stream waited for each bucket after the last
+        segment...], "optimizer": ms} averaged over the timed steps (synchronises)."""
+        torch.cuda.synchronize()
+        steps = self._timed_steps or []
+        if not steps:
+            return None
+        nseg = len(steps[0]["seg"]) - 2
+        out = {"segments": [0.0] * nseg, "bucket_waits": [0.0] * len(steps[0]["waits"]), "optimizer": 0.0}
+        for rec in steps:
+            ev = rec["seg"]
+            for j in range(nseg):
+                out["segments"][j] += ev[j].elapsed_time(ev[j + 1])
+            prev = ev[nseg]
+            for j, w in enumerate(rec["waits"]):
+                out["bucket_waits"][j] += prev.elapsed_time(w)
+                prev = w
+            out["optimizer"] += prev.elapsed_time(ev[nseg + 1])
+        k = float(len(steps))
+        return {"segments": [v / k for v in out["segments"]], "bucket_waits": [v / k for v in out["bucket_waits"]],
+                "optimizer": out["optimizer"] / k, "steps": len(steps)}
 
     # ------------------------------------------------------------------------------------------------
     # Keras-shaped batch API

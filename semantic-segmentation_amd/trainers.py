@@ -36,6 +36,7 @@ class GradientBucketReducer:
         self.rank = dist.get_rank(group)
         self._pending = []
         self.bytes_reduced = 0
+        self.buckets_started = 0
 
     def start(self, grad: torch.Tensor, rng: Tuple[int, int]):
         lo, hi = rng
@@ -43,14 +44,32 @@ class GradientBucketReducer:
             return
         view = grad[lo:hi]
         self.bytes_reduced += view.numel() * view.element_size()
+        self.buckets_started += 1
+        if self._host_staged(view):
+            # gloo with device tensors (rehearsals of several ranks on one GPU only): the bucket travels through host
+            # memory under this class's control - wait for the stream, copy out, reduce on the host, copy back.  gloo's own
+            # device hand-off stalls for minutes when the all-reduce is queued behind device work of two processes that
+            # share a GPU (reproduced with plain matrix products, scripts/gloo_speed_probe.py)
+            torch.cuda.current_stream().synchronize()
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            view.copy_(host)
+            return
         if os.environ.get("SSMI_SYNC_ALLREDUCE"):       # debugging aid: blocking collectives
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             return
         self._pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def finish(self, after_each=None):
+        """Makes the current stream wait for every pending bucket, in the order they were started.  after_each: called once
+        per bucket after its wait has been queued (timing marks)."""
         for w in self._pending:
             w.wait()
+            if after_each is not None:
+                after_each(w)
         self._pending = []
 
     def broadcast_(self, tensors: Sequence[torch.Tensor], src: int = 0):

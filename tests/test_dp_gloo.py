@@ -118,3 +118,30 @@ def test_one_rank_rccl_group_runs_the_data_parallel_step():
         outs.append(json.loads(lines[0]))
     assert outs[0]["config"]["final_loss"] == outs[1]["config"]["final_loss"]
     assert outs[1]["n_gpus"] == 1 and outs[1]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_two_gloo_ranks_share_the_gpu_and_finish_the_data_parallel_step():
+    """Two ranks (gloo, both on GPU 0) run bench.py's data-parallel step: graph segments, a gradient bucket after each, the
+    optimizer behind the last one.  The buckets travel through host memory here (GradientBucketReducer's gloo path), so this
+    checks the segment / bucket logic with two real ranks, not RCCL.  Both ranks start from rank 0's weights and see
+    all-reduced gradients, so the step must finish, report two ranks and two buckets covering the whole gradient arena."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSMI_DIST_BACKEND="gloo", SSMI_BENCH_WATCHDOG="100")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+           "--batch", "2", "--size", "64"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=140, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    dp = d["data_parallel"]
+    assert d["n_gpus"] == 2 and dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["buckets_per_step"] == 2
+    assert dp["bytes_reduced_per_step"] == sum(dp["bucket_bytes"]) and len(dp["segments_ms"]) == 2
+    assert np.isfinite(d["config"]["final_loss"]) and d["value"] > 0

@@ -178,6 +178,32 @@ def test_bucket_ranges_cover_the_arena_in_backward_order():
     assert (hi1 - lo1) > 0.9 * n
 
 
+@pytest.mark.parametrize("name", ["segnet", "unet", "enet-max-unpooling"])
+def test_bucket_ranges_of_every_model_tile_the_arena(name):
+    """Buckets are contiguous, ordered from the end of the arena (the gradients the backward pass finishes first) to its
+    start, and ~25 MB each for the wide models; every cut is the first parameter of a block."""
+    models, losses = pkg("models"), pkg("losses")
+    m = models.get_model(name, (None, None, 3), 24, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY,
+                         device="cpu").model
+    rs = m.bucket_ranges()
+    n = m.graph.store.theta.numel()
+    assert rs[0][1] == n and rs[-1][0] == 0
+    for (lo, hi), (lo2, hi2) in zip(rs, rs[1:]):
+        assert hi2 == lo and lo2 < hi2
+    cuts = m._cut_indices()
+    assert len(rs) == len(cuts) + 1 and cuts == sorted(cuts, reverse=True) and len(rs) <= m.MAX_BUCKETS
+    offs = m._block_offsets()
+    assert [lo for lo, _ in rs[:-1]] == [offs[i] for i in cuts]
+    if name in ("segnet", "unet"):
+        assert len(rs) >= 3
+        for lo, hi in rs[:-1]:
+            assert (hi - lo) * 4 >= m.BUCKET_BYTES
+        # a cut adds the smallest block that reaches the target, so no bucket is larger than target + one block
+        biggest_block = max(b - a for a, b in zip([o for o in offs if o is not None], [o for o in offs if o is not None][1:] + [n]))
+        for lo, hi in rs:
+            assert (hi - lo) * 4 <= m.BUCKET_BYTES + biggest_block * 4
+
+
 def test_ops_refuse_cpu_tensors():
     pooling = pkg("layers.pooling")
     losses = pkg("losses")
