@@ -391,11 +391,7 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __
   f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (active) {
     const f32x4 al = ld4(a.alpha + c);
-    for (unsigned p = blockIdx.x * (unsigned)ppi + (unsigned)pl; p < (unsigned)npix; p += gridDim.x * (unsigned)ppi) {
-      f32x4 xh3, dv;
-      const f32x4 s = merge_sum<T, MODE>(a, p, c, xh3, dv);
-      const f32x4 d = Act<T>::gld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
-      f32x4 ds;
+    auto accumulate = [&](const f32x4& s, const f32x4& xh3, const f32x4& dv, const f32x4& d, f32x4& ds) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ds[j] = d[j] * (s[j] > 0.f ? 1.f : (s[j] < 0.f ? al[j] : 0.f));
@@ -404,7 +400,30 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __
         v[1][j] += dz * xh3[j];
         v[2][j] += d[j] * (s[j] < 0.f ? s[j] : 0.f);
       }
-      Act<T>::gst4(dsum + (p * c4n + c4) * 4, ds);
+    };
+    const unsigned stride = gridDim.x * (unsigned)ppi;
+    unsigned p = blockIdx.x * (unsigned)ppi + (unsigned)pl;
+    // four pixels per round: all their loads are issued before the first result is stored (a one-pixel loop costs one
+    // memory round trip per pixel and leaves the launch far below the bandwidth its 512 workgroups could draw)
+    for (; (uint64_t)p + 3ull * stride < (uint64_t)npix; p += 4u * stride) {
+      f32x4 s[4], xh3[4], dv[4], d[4], ds[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const unsigned q = p + (unsigned)u * stride;
+        s[u] = merge_sum<T, MODE>(a, q, c, xh3[u], dv[u]);
+        d[u] = Act<T>::gld4(dout + (q * (unsigned)c4n + (unsigned)c4) * 4u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(s[u], xh3[u], dv[u], d[u], ds[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) Act<T>::gst4(dsum + ((p + (unsigned)u * stride) * (unsigned)c4n + (unsigned)c4) * 4u, ds[u]);
+    }
+    for (; p < (unsigned)npix; p += stride) {
+      f32x4 xh3, dv, ds;
+      const f32x4 s = merge_sum<T, MODE>(a, p, c, xh3, dv);
+      const f32x4 d = Act<T>::gld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
+      accumulate(s, xh3, dv, d, ds);
+      Act<T>::gst4(dsum + (p * (unsigned)c4n + (unsigned)c4) * 4u, ds);
     }
   }
   block_reduce_groups<3>(v, sm, c4n, ppi, active);
