@@ -946,6 +946,195 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Register-weight implicit GEMM for narrow outputs (<= 16 output channels, stride 1, short reductions: K = NTAP * CR <=
+// 144): the same GEMM as conv_gemm_lds with 16 x 16 x 4 MFMA tiles, but the wave's share of the kernel matrix -
+// K / 4 words per lane - is loaded ONCE into registers straight from global memory (the matrix is a few KB and sits in
+// L2), so there is no LDS staging, no barrier in front of the first multiply and no LDS read per MFMA.  The reduction is
+// unrolled completely (taps and channel blocks are compile-time constants, tap offsets wave-uniform scalars).  A wave
+// walks over several pixel groups; the operand loads of the next group are issued before the current group is
+// multiplied, so one memory round trip is hidden behind a whole group's MFMAs and stores.
+//   forward (mode 0): in = x, CR = cin;  data gradient (mode 1, stride 1): in = dy, CR = cout, flipped taps.
+// Epilogue as conv_gemm_lds: bias, addend, fused BatchNormalization statistics (part) or BN backward sums (bb).
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int NTAP, int CR, int MT>
+__global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, const T* __restrict__ in,
+                                                 const float* __restrict__ w, const float* __restrict__ bias,
+                                                 const T* __restrict__ add, T* __restrict__ out,
+                                                 float* __restrict__ part, BnBwdArgs bb) {
+  __shared__ float red[4 * 3 * 16];
+  constexpr int CB = CR / 16;              // 16-channel k-blocks per tap
+  constexpr int NB = NTAP * CB;            // k-blocks in all
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, kq = lane >> 4;
+  const bool bwd = a.mode == 1;
+  const int qh = bwd ? g.h : g.ho, qw = bwd ? g.w : g.wo;      // stride 1: the output grid
+  const int64_t M = (int64_t)g.n * qh * qw;
+  const bool cv = c < a.C_o;
+
+  // tap offsets (uniform) and the lane's kernel words: B[(t * CB + cb) * 4 + j] = Wl[t][cb * 16 + 4 * kq + j][c]
+  int tdy[NTAP], tdx[NTAP];
+  unsigned toff[NTAP];
+  float B[NB * 4];
+  {
+    const __amdgpu_buffer_rsrc_t rwt = make_rsrc(w, sz.w_bytes);
+    const unsigned cmask = cv ? 0u : kOOB;         // kernel matrices are far below 2 GiB: OR-ing the marker in is exact
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+      const int ky = NTAP == 1 ? 0 : t / g.kw, kx = NTAP == 1 ? 0 : t - (t / g.kw) * g.kw;
+      tdy[t] = bwd ? g.pad_t - ky * g.dil : ky * g.dil - g.pad_t;
+      tdx[t] = bwd ? g.pad_l - kx * g.dil : kx * g.dil - g.pad_l;
+      toff[t] = (unsigned)((tdy[t] * a.in_w + tdx[t]) * a.in_ld * 4);
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int r0 = cb * 16 + 4 * kq;
+        if (bwd) {
+          // data gradient: w[t][ci = c][co = r0 .. r0 + 3] is one 16-byte load (cout = CR is a multiple of 16)
+          const f32x4 v = bload4(rwt, ((unsigned)((t * g.cin + c) * g.cout + r0) * 4u) | cmask);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) B[(t * CB + cb) * 4 + j] = v[j];
+        } else {
+          // forward: w[t][ci = r0 + j][co = c], the 16 lanes of a row read 64 consecutive bytes
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            B[(t * CB + cb) * 4 + j] = bload(rwt, ((unsigned)((t * g.cin + r0 + j) * g.cout + c) * 4u) | cmask);
+        }
+      }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rin = Act<T>::rsrc(in, bwd ? sz.y_bytes : sz.x_bytes);
+  const unsigned out_bytes = bwd ? sz.x_bytes : sz.y_bytes;
+  const __amdgpu_buffer_rsrc_t rout = Act<T>::rsrc(out, out_bytes);
+  const __amdgpu_buffer_rsrc_t radd = Act<T>::rsrc(add ? add : out, add ? out_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rbx = Act<T>::rsrc(bb.x ? bb.x : (const void*)out, bb.x ? (unsigned)((int64_t)g.n * g.h * g.w * bb.ld * 4) : 0u);
+  const float bvv = (bias && cv) ? bias[c] : 0.f;
+  const int64_t ngroups = (M + MT * 16 - 1) / (MT * 16);
+  float st1 = 0.f, st2 = 0.f, st3 = 0.f;
+
+  f32x4 An[MT][NB];                 // operands of the group fetched ahead
+  auto fetch = [&](int64_t grp) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const unsigned p = (unsigned)(grp * (MT * 16)) + (unsigned)(m * 16 + c);
+      const bool pv = grp < ngroups && p < (unsigned)M;
+      const unsigned pp = pv ? p : 0u;
+      const unsigned t1 = pp / (unsigned)qw;
+      const int qx = (int)(pp - t1 * (unsigned)qw);
+      const unsigned n_ = t1 / (unsigned)qh;
+      const int qy = (int)(t1 - n_ * (unsigned)qh);
+      const unsigned pbase = ((n_ * (unsigned)a.in_h + (unsigned)qy) * (unsigned)a.in_w + (unsigned)qx) * (unsigned)a.in_ld * 4u +
+                             (unsigned)(kq * 16);
+#pragma unroll
+      for (int t = 0; t < NTAP; ++t) {
+        bool ok = pv;
+        if (NTAP > 1) ok = ok & ((unsigned)(qy + tdy[t]) < (unsigned)a.in_h) & ((unsigned)(qx + tdx[t]) < (unsigned)a.in_w);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) An[m][t * CB + cb] = Act<T>::ld4(rin, ok ? pbase + toff[t] + (unsigned)(cb * 64) : kOOB);
+      }
+    }
+  };
+
+  int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t gstep = (int64_t)gridDim.x * 4;
+  fetch(grp);
+  for (; grp < ngroups; grp += gstep) {
+    f32x4 A[MT][NB];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) A[m][b] = An[m][b];
+    fetch(grp + gstep);             // past the end every lane reads zeros
+    typedef float accv __attribute__((ext_vector_type(4)));
+    accv acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = accv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][b][j], B[b * 4 + j], acc[m], 0, 0, 0);
+
+    // ---- epilogue: accumulator element i of tile m is output pixel tile0 + m * 16 + 4 * kq + i, column c ----
+    const unsigned tile0 = (unsigned)(grp * (MT * 16));
+    unsigned po[MT][4], rowoff[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        po[m][i] = tile0 + (unsigned)(m * 16 + kq * 4 + i);
+        rowoff[m][i] = (po[m][i] < (unsigned)M && cv) ? (po[m][i] * (unsigned)a.out_ld + (unsigned)c) * 4u : kOOB;
+      }
+    // branch-free: without an addend / a fused BN backward the descriptors have size zero and the loads return 0
+    float av[MT][4], xr[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        av[m][i] = Act<T>::ld(radd, rowoff[m][i]);
+        xr[m][i] = Act<T>::ld(rbx, rowoff[m][i] != kOOB ? (po[m][i] * (unsigned)bb.ld + (unsigned)c) * 4u : kOOB);
+      }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Act<T>::st(rout, rowoff[m][i], acc[m][i] + bvv + av[m][i]);
+    if (part) {          // uniform: BatchNormalization statistics of the forward output
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = rowoff[m][i] != kOOB ? acc[m][i] + bvv : 0.f;
+          st1 += v;
+          st2 += v * v;
+        }
+    }
+    if (bb.x) {          // uniform: BatchNormalization backward sums of the data gradient
+      const int cc = cv ? c : 0;
+      const float mu = bb.mean[cc], is = bb.invstd[cc], ga = bb.gamma[cc], be = bb.beta[cc];
+      const float al = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bool ok = rowoff[m][i] != kOOB;
+          float d = acc[m][i] + bvv + av[m][i];
+          if (bb.drop) d *= bb.drop[(ok ? po[m][i] / bb.hw : 0u) * (unsigned)a.C_o + (unsigned)cc];
+          const float xh = (xr[m][i] - mu) * is;
+          const float z = ga * xh + be;
+          const float gr = bb.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al : 0.f));
+          const float dz = ok ? d * gr : 0.f;
+          st1 += dz;
+          st2 += dz * xh;
+          st3 += ok ? d * (z < 0.f ? z : 0.f) : 0.f;
+        }
+    }
+  }
+  if (part || bb.x) {   // uniform: combine the four lane groups that share a column, then the four waves through LDS
+    const int ns = bb.x ? 3 : 2;
+    float* dst = bb.x ? bb.part : part;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      st1 += __shfl_xor(st1, o, 64);
+      st2 += __shfl_xor(st2, o, 64);
+      st3 += __shfl_xor(st3, o, 64);
+    }
+    if (kq == 0) {
+      red[(wave * 3 + 0) * 16 + c] = st1;
+      red[(wave * 3 + 1) * 16 + c] = st2;
+      red[(wave * 3 + 2) * 16 + c] = st3;
+    }
+    __syncthreads();
+    if (tid < 16 && tid < a.C_o) {
+      for (int k = 0; k < ns; ++k) {
+        float sk = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) sk += red[(wv * 3 + k) * 16 + tid];
+        dst[((int64_t)blockIdx.x * ns + k) * a.C_o + tid] = sk;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // weight gradient: dw[(tap,ci), co] = sum_p x[pix(p,tap), ci] * dy[p, co]; optional extra row K = sum_p dy[p, co].
 // The [K_aug x cout] result is cut into 32x32 output tiles (kt, ct).  A workgroup owns one strip of output rows and
 // up to 4*TPW tiles: its waves split the tiles (wave w takes tiles w, w+wps, ...), so the 4 waves stream the same
@@ -1450,6 +1639,39 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
   size_t lds = (size_t)(4 + 5 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
   if (lds > 64 * 1024) return false;
   if ((part || bb.x) && lds < (size_t)12 * nt * ts * 4) lds = (size_t)12 * nt * ts * 4;   // room for the column-sum combine
+
+  // Register-weight kernel: narrow outputs, stride 1, the two reductions that dominate the 16-channel stages of ENet
+  // (1x1 over 64 channels, 3x3 over 16 channels).  SSMI_NO_REGW=1 keeps the LDS kernel (A/B measurements).
+  static const bool no_regw = getenv("SSMI_NO_REGW") != nullptr;
+  if (!no_regw && force == 0 && m16 && vec && s == 1 && ((ntaps == 1 && a.C_r == 64) || (ntaps == 9 && g.kh == 3 && a.C_r == 16)) &&
+      (mode == 0 || (g.ho == g.h && g.wo == g.w)) && !(mode == 0 && bb.mean != nullptr)) {
+    const int64_t M = (int64_t)g.n * qh * qw;
+    // Measured on MI355X (batch 16, 128x128): 3x3 16->16 forward 28.3 -> 23.3 us and data gradient 28.4 -> 22.9 us with two
+    // tiles per wave and 512 workgroups (four groups per wave, no remainder); 1x1 64->16 19.0 -> 16.7 us and the data
+    // gradient of 1x1 16->64 19.9 -> 16.5 us with one tile per wave and 1024 workgroups.  More workgroups re-read the
+    // kernel matrix more often, four tiles per wave (1x1) lose occupancy: both measured slower.
+    static const int regw_wgs_env = getenv("SSMI_REGW_WGS") ? atoi(getenv("SSMI_REGW_WGS")) : 0;
+    const int regw_wgs = regw_wgs_env > 0 ? regw_wgs_env : (ntaps == 1 ? 1024 : 512);
+    static const int regw_mt = getenv("SSMI_REGW_MT") ? atoi(getenv("SSMI_REGW_MT")) : 0;
+    const int mt_ = (regw_mt == 1 || regw_mt == 2 || regw_mt == 4) ? regw_mt : (ntaps == 1 ? 1 : 2);
+    const int64_t ngroups = ceil_div64(M, mt_ * 16);
+    int64_t bx = ceil_div64(ngroups, 4);
+    if (bx > regw_wgs) bx = regw_wgs;
+    if (part_rows) *part_rows = (int)bx;
+    set_last_kernel("conv_regw<%d, %d, %d>", ntaps, a.C_r, mt_);
+#define LR(NTAP_, CR_, MT_) hipLaunchKernelGGL((conv_regw<T, NTAP_, CR_, MT_>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb)
+    if (ntaps == 1) { if (mt_ == 1) LR(1, 64, 1); else if (mt_ == 2) LR(1, 64, 2); else LR(1, 64, 4); }
+    else { if (mt_ == 1) LR(9, 16, 1); else LR(9, 16, 2); }
+#undef LR
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("conv_regw launch: %s", hipGetErrorString(e));
+      *status = SSMI_E_HIP;
+    } else {
+      *status = SSMI_OK;
+    }
+    return true;
+  }
 
   // Tile variant (opt-in, SSMI_CONV_KERNEL=tile): multi-tap stride-1 convolutions into <= 32 channels read every input
   // pixel once per tap; staging the 8 x 32 tile's halo patch in LDS makes that one pass over global memory and removes
