@@ -175,25 +175,42 @@ __device__ __forceinline__ float act_grad(float z, float a) {
   return z > 0.f ? 1.f : (z < 0.f ? a : 0.f);
 }
 
+// Elementwise kernels: thread (c4 = tid % c4n, pl = tid / c4n) owns channel group c4 of the pixels pl, pl + stride, ...
+// so its per-channel parameters are loaded ONCE (re-loading five or more 16-byte parameter vectors for every 16-byte
+// payload load made the address unit, not HBM, the limit), and it handles four pixels per round with all payload loads
+// issued before the first store.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, int ld, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ alpha,
                                                          float slope, const float* __restrict__ drop, int64_t hw,
-                                                         T* __restrict__ y, int y_ld, int64_t total4, int c4n) {
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
-    const unsigned p = i / (unsigned)c4n;
-    const int c = (int)(i - p * (unsigned)c4n) * 4;
-    const f32x4 xv = Act<T>::gld4(x + p * ld + c);
-    const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
-    f32x4 a = {slope, slope, slope, slope};
-    if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+                                                         T* __restrict__ y, int y_ld, int64_t npix, int c4n) {
+  const unsigned ppi = 256u / (unsigned)c4n;
+  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+  if (pl >= ppi) return;
+  const int c = (int)c4 * 4;
+  const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+  f32x4 a = {slope, slope, slope, slope};
+  if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+  auto one = [&](const f32x4& xv, unsigned p) {
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
     if (drop) o = o * ld4(drop + (p / (unsigned)hw) * (unsigned)(c4n * 4) + c);
-    Act<T>::gst4(y + p * y_ld + c, o);
+    return o;
+  };
+  const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;      // npix * ld < 2^29
+  unsigned p = blockIdx.x * ppi + pl;
+  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
+    f32x4 xv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = Act<T>::gld4(x + (p + (unsigned)u * stride) * (unsigned)ld + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) xv[u] = one(xv[u], p + (unsigned)u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Act<T>::gst4(y + (p + (unsigned)u * stride) * (unsigned)y_ld + c, xv[u]);
   }
+  for (; p < n; p += stride) Act<T>::gst4(y + p * (unsigned)y_ld + c, one(Act<T>::gld4(x + p * (unsigned)ld + c), p));
 }
 
 // backward pass 1: per-channel sums of dz, dz*xhat and (PReLU) dy*min(z,0)
@@ -280,19 +297,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const T* __restrict__ dy
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ alpha, float slope,
                                                         const float* __restrict__ drop, int64_t hw, int dy_ld,
-                                                        const float* __restrict__ coef, T* __restrict__ dx,
-                                                        int64_t total4, int c4n) {
+                                                        const float* __restrict__ coef, T* dx,
+                                                        int64_t npix, int c4n) {
   const int cc = c4n * 4;
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
-    const unsigned p = i / (unsigned)c4n;
-    const int c = (int)(i - p * (unsigned)c4n) * 4;
-    const f32x4 xv = Act<T>::gld4(x + p * ld + c);
-    f32x4 d = Act<T>::gld4(dy + p * dy_ld + c);
+  const unsigned ppi = 256u / (unsigned)c4n;
+  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+  if (pl >= ppi) return;
+  const int c = (int)c4 * 4;
+  const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
+  const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
+  f32x4 a = {slope, slope, slope, slope};
+  if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+  auto one = [&](const f32x4& xv, f32x4 d, unsigned p) {
     if (drop) d = d * ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
-    const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
-    const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
-    f32x4 a = {slope, slope, slope, slope};
-    if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -301,8 +318,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const T* __restrict__ dy
       const float dz = d[j] * act_grad<ACT>(z, a[j]);
       o[j] = k1[j] * (dz - m1[j] - xh * m2[j]);
     }
-    Act<T>::gst4(dx + p * ld + c, o);
+    return o;
+  };
+  const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;
+  unsigned p = blockIdx.x * ppi + pl;
+  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
+    f32x4 xv[4], d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned q = p + (unsigned)u * stride;
+      xv[u] = Act<T>::gld4(x + q * (unsigned)ld + c);
+      d[u] = Act<T>::gld4(dy + q * (unsigned)dy_ld + c);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = one(xv[u], d[u], p + (unsigned)u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Act<T>::gst4(dx + (p + (unsigned)u * stride) * (unsigned)ld + c, d[u]);   // dx may alias dy: all loads are done
   }
+  for (; p < n; p += stride)
+    Act<T>::gst4(dx + p * (unsigned)ld + c, one(Act<T>::gld4(x + p * (unsigned)ld + c), Act<T>::gld4(dy + p * (unsigned)dy_ld + c), p));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,44 +353,81 @@ struct MergeArgs {
   const float* alpha;
 };
 
-// pre-activation sum s and (optionally) the BN3 intermediates for element group (p, c..c+3)
+// per-channel parameters of a thread's channel group, loaded once
+struct MergeParams {
+  f32x4 m, is, g, b;         // BN3
+  f32x4 mo, iso, go, bo;     // BN of the skip branch (modes 2, 3)
+};
+template <int MODE>
+__device__ __forceinline__ MergeParams merge_params(const MergeArgs& a, int c) {
+  MergeParams q;
+  q.m = ld4(a.mean3 + c); q.is = ld4(a.invstd3 + c); q.g = ld4(a.gamma3 + c); q.b = ld4(a.beta3 + c);
+  q.mo = q.iso = q.go = q.bo = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (MODE >= 2) { q.mo = ld4(a.mean_o + c); q.iso = ld4(a.invstd_o + c); q.go = ld4(a.gamma_o + c); q.bo = ld4(a.beta_o + c); }
+  return q;
+}
+
+// Raw operands of element group (p, c..c+3): the main-branch value, the skip-branch value and (mode 3) the argmax indices.
+// Loads only, so that a caller can issue several pixels' loads back to back.
 template <typename T, int MODE>
-__device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, unsigned p, int c, f32x4& xh3, f32x4& dropv) {
+struct MergeRaw {
+  f32x4 mv, ov, dropv;
+  int4 iv;
+  int flat;
+  bool has_other;
+};
+template <typename T, int MODE>
+__device__ __forceinline__ MergeRaw<T, MODE> merge_load(const MergeArgs& a, unsigned p, int c) {
+  MergeRaw<T, MODE> r;
   const unsigned hw = (unsigned)(a.h * a.w);     // every tensor is below 2 GiB: 32-bit element arithmetic
   const unsigned n_ = p / hw;
   const T* main_ = static_cast<const T*>(a.main);
   const T* other_ = static_cast<const T*>(a.other);
-  const f32x4 mv = Act<T>::gld4(main_ + p * a.c + c);
-  const f32x4 m = ld4(a.mean3 + c), is = ld4(a.invstd3 + c), g = ld4(a.gamma3 + c), b = ld4(a.beta3 + c);
-  dropv = f32x4{1.f, 1.f, 1.f, 1.f};
-  if (a.drop) dropv = ld4(a.drop + n_ * (unsigned)a.c + c);
-  f32x4 s;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    xh3[j] = (mv[j] - m[j]) * is[j];
-    s[j] = (g[j] * xh3[j] + b[j]) * dropv[j];
-  }
+  r.mv = Act<T>::gld4(main_ + p * a.c + c);
+  r.dropv = f32x4{1.f, 1.f, 1.f, 1.f};
+  if (a.drop) r.dropv = ld4(a.drop + n_ * (unsigned)a.c + c);
+  r.ov = f32x4{0.f, 0.f, 0.f, 0.f};
+  r.iv = int4{0, 0, 0, 0};
+  r.flat = 0;
+  r.has_other = true;
   if (MODE == 0) {
-    s += Act<T>::gld4(other_ + p * a.c + c);
+    r.ov = Act<T>::gld4(other_ + p * a.c + c);
   } else if (MODE == 1) {
-    if (c < a.c_other) s += Act<T>::gld4(other_ + p * a.c_other + c);
+    r.has_other = c < a.c_other;
+    if (r.has_other) r.ov = Act<T>::gld4(other_ + p * a.c_other + c);
   } else {
     const unsigned rem = p - n_ * hw;
     const int y = (int)(rem / (unsigned)a.w), x = (int)(rem - (unsigned)y * (unsigned)a.w);
     const int h2 = a.h >> 1, w2 = a.w >> 1;
     const unsigned q = (n_ * (unsigned)h2 + (unsigned)(y >> 1)) * (unsigned)w2 + (unsigned)(x >> 1);
-    const f32x4 ov = Act<T>::gld4(other_ + q * a.c + c);
-    const f32x4 mo = ld4(a.mean_o + c), iso = ld4(a.invstd_o + c), go = ld4(a.gamma_o + c), bo = ld4(a.beta_o + c);
+    r.ov = Act<T>::gld4(other_ + q * a.c + c);
+    if (MODE == 3) {
+      r.iv = *reinterpret_cast<const int4*>(a.idx + q * a.c + c);
+      r.flat = (y * a.w + x) * a.c + c;
+    }
+  }
+  return r;
+}
+// pre-activation sum s and the BN3 intermediate xhat3 from the raw operands
+template <typename T, int MODE>
+__device__ __forceinline__ f32x4 merge_sum(const MergeParams& q, const MergeRaw<T, MODE>& r, f32x4& xh3) {
+  f32x4 s;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xh3[j] = (r.mv[j] - q.m[j]) * q.is[j];
+    s[j] = (q.g[j] * xh3[j] + q.b[j]) * r.dropv[j];
+  }
+  if (MODE <= 1) {
+    s += r.ov;            // zeros where the pooled skip tensor has no such channel
+  } else {
     f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = go[j] * ((ov[j] - mo[j]) * iso[j]) + bo[j];
+    for (int j = 0; j < 4; ++j) o[j] = q.go[j] * ((r.ov[j] - q.mo[j]) * q.iso[j]) + q.bo[j];
     if (MODE == 3) {
-      const int4 iv = *reinterpret_cast<const int4*>(a.idx + q * a.c + c);
-      const int flat = (y * a.w + x) * a.c + c;
-      o[0] = (iv.x == flat) ? o[0] : 0.f;
-      o[1] = (iv.y == flat + 1) ? o[1] : 0.f;
-      o[2] = (iv.z == flat + 2) ? o[2] : 0.f;
-      o[3] = (iv.w == flat + 3) ? o[3] : 0.f;
+      o[0] = (r.iv.x == r.flat) ? o[0] : 0.f;
+      o[1] = (r.iv.y == r.flat + 1) ? o[1] : 0.f;
+      o[2] = (r.iv.z == r.flat + 2) ? o[2] : 0.f;
+      o[3] = (r.iv.w == r.flat + 3) ? o[3] : 0.f;
     }
     s += o;
   }
@@ -364,18 +435,34 @@ __device__ __forceinline__ f32x4 merge_sum(const MergeArgs& a, unsigned p, int c
 }
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, T* __restrict__ out, int64_t total4, int c4n) {
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
-    const unsigned p = i / (unsigned)c4n;
-    const int c = (int)(i - p * (unsigned)c4n) * 4;
-    f32x4 xh3, dv;
-    const f32x4 s = merge_sum<T, MODE>(a, p, c, xh3, dv);
-    const f32x4 al = ld4(a.alpha + c);
+__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, T* __restrict__ out, int64_t npix, int c4n) {
+  const unsigned ppi = 256u / (unsigned)c4n;
+  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+  if (pl >= ppi) return;
+  const int c = (int)c4 * 4;
+  const MergeParams q = merge_params<MODE>(a, c);
+  const f32x4 al = ld4(a.alpha + c);
+  auto finish = [&](const MergeRaw<T, MODE>& r) {
+    f32x4 xh3;
+    const f32x4 s = merge_sum<T, MODE>(q, r, xh3);
     f32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = s[j] > 0.f ? s[j] : al[j] * s[j];
-    Act<T>::gst4(out + (size_t)i * 4, o);
+    return o;
+  };
+  const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;
+  unsigned p = blockIdx.x * ppi + pl;
+  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
+    MergeRaw<T, MODE> r[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r[u] = merge_load<T, MODE>(a, p + (unsigned)u * stride, c);
+    f32x4 o[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) o[u] = finish(r[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Act<T>::gst4(out + ((p + (unsigned)u * stride) * (unsigned)c4n + c4) * 4u, o[u]);
   }
+  for (; p < n; p += stride) Act<T>::gst4(out + (p * (unsigned)c4n + c4) * 4u, finish(merge_load<T, MODE>(a, p, c)));
 }
 
 // backward pass 1: dsum = dout * prelu'(s); partial sums of dz = dsum*drop, dz*xhat3 and dout*min(s,0)
@@ -391,11 +478,14 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __
   f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (active) {
     const f32x4 al = ld4(a.alpha + c);
-    auto accumulate = [&](const f32x4& s, const f32x4& xh3, const f32x4& dv, const f32x4& d, f32x4& ds) {
+    const MergeParams q = merge_params<MODE>(a, c);
+    auto accumulate = [&](const MergeRaw<T, MODE>& r, const f32x4& d, f32x4& ds) {
+      f32x4 xh3;
+      const f32x4 s = merge_sum<T, MODE>(q, r, xh3);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         ds[j] = d[j] * (s[j] > 0.f ? 1.f : (s[j] < 0.f ? al[j] : 0.f));
-        const float dz = ds[j] * dv[j];
+        const float dz = ds[j] * r.dropv[j];
         v[0][j] += dz;
         v[1][j] += dz * xh3[j];
         v[2][j] += d[j] * (s[j] < 0.f ? s[j] : 0.f);
@@ -406,23 +496,24 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __
     // four pixels per round: all their loads are issued before the first result is stored (a one-pixel loop costs one
     // memory round trip per pixel and leaves the launch far below the bandwidth its 512 workgroups could draw)
     for (; (uint64_t)p + 3ull * stride < (uint64_t)npix; p += 4u * stride) {
-      f32x4 s[4], xh3[4], dv[4], d[4], ds[4];
+      MergeRaw<T, MODE> r[4];
+      f32x4 d[4], ds[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const unsigned q = p + (unsigned)u * stride;
-        s[u] = merge_sum<T, MODE>(a, q, c, xh3[u], dv[u]);
-        d[u] = Act<T>::gld4(dout + (q * (unsigned)c4n + (unsigned)c4) * 4u);
+        const unsigned pu = p + (unsigned)u * stride;
+        r[u] = merge_load<T, MODE>(a, pu, c);
+        d[u] = Act<T>::gld4(dout + (pu * (unsigned)c4n + (unsigned)c4) * 4u);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) accumulate(s[u], xh3[u], dv[u], d[u], ds[u]);
+      for (int u = 0; u < 4; ++u) accumulate(r[u], d[u], ds[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u) Act<T>::gst4(dsum + ((p + (unsigned)u * stride) * (unsigned)c4n + (unsigned)c4) * 4u, ds[u]);
     }
     for (; p < (unsigned)npix; p += stride) {
-      f32x4 xh3, dv, ds;
-      const f32x4 s = merge_sum<T, MODE>(a, p, c, xh3, dv);
+      f32x4 ds;
+      const MergeRaw<T, MODE> r = merge_load<T, MODE>(a, p, c);
       const f32x4 d = Act<T>::gld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
-      accumulate(s, xh3, dv, d, ds);
+      accumulate(r, d, ds);
       Act<T>::gst4(dsum + (p * (unsigned)c4n + (unsigned)c4) * 4u, ds);
     }
   }
@@ -439,14 +530,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void merge_bwd_apply(const T* __restrict__ dsum, const T* __restrict__ main,
                                                        const float* __restrict__ mean3, const float* __restrict__ invstd3,
                                                        const float* __restrict__ drop, const float* __restrict__ coef,
-                                                       T* __restrict__ dmain, int64_t total4, int c4n, int64_t hw) {
+                                                       T* __restrict__ dmain, int64_t npix, int c4n, int64_t hw) {
   const int cc = c4n * 4;
-  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < (unsigned)total4; i += gridDim.x * 256u) {   // total4 < 2^31
-    const unsigned p = i / (unsigned)c4n;
-    const int c = (int)(i - p * (unsigned)c4n) * 4;
-    const f32x4 ds = Act<T>::gld4(dsum + (size_t)i * 4), mv = Act<T>::gld4(main + (size_t)i * 4);
-    const f32x4 m = ld4(mean3 + c), is = ld4(invstd3 + c);
-    const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
+  const unsigned ppi = 256u / (unsigned)c4n;
+  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+  if (pl >= ppi) return;
+  const int c = (int)c4 * 4;
+  const f32x4 m = ld4(mean3 + c), is = ld4(invstd3 + c);
+  const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
+  auto one = [&](const f32x4& ds, const f32x4& mv, unsigned p) {
     f32x4 dv = {1.f, 1.f, 1.f, 1.f};
     if (drop) dv = ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
     f32x4 o;
@@ -455,7 +547,26 @@ __global__ __launch_bounds__(256) void merge_bwd_apply(const T* __restrict__ dsu
       const float xh = (mv[j] - m[j]) * is[j];
       o[j] = k1[j] * (ds[j] * dv[j] - m1[j] - xh * m2[j]);
     }
-    Act<T>::gst4(dmain + (size_t)i * 4, o);
+    return o;
+  };
+  const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;
+  unsigned p = blockIdx.x * ppi + pl;
+  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
+    f32x4 ds[4], mv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const unsigned e = ((p + (unsigned)u * stride) * (unsigned)c4n + c4) * 4u;
+      ds[u] = Act<T>::gld4(dsum + e);
+      mv[u] = Act<T>::gld4(main + e);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ds[u] = one(ds[u], mv[u], p + (unsigned)u * stride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Act<T>::gst4(dmain + ((p + (unsigned)u * stride) * (unsigned)c4n + c4) * 4u, ds[u]);
+  }
+  for (; p < n; p += stride) {
+    const unsigned e = (p * (unsigned)c4n + c4) * 4u;
+    Act<T>::gst4(dmain + e, one(Act<T>::gld4(dsum + e), Act<T>::gld4(main + e), p));
   }
 }
 
@@ -501,6 +612,15 @@ static ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64
   return SSMI_OK;
 }
 
+// grid of the pixel-strided elementwise kernels: one round of four pixels per thread, at most 4096 workgroups
+static inline int ew_blocks_px(int64_t npix, int c4n) {
+  const int ppi = 256 / c4n;
+  int64_t b = ceil_div64(npix, (int64_t)ppi * 4);
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 static inline int ew_blocks(int64_t total4) {
   int64_t b = ceil_div64(total4, 256 * 4);
   if (b > 4096) b = 4096;
@@ -522,9 +642,8 @@ ssmi_status launch_bn_bwd_tail(const float* part, int rows, const T* dy, int ld_
                                       act == SSMI_ACT_PRELU ? dalpha : nullptr, coef, st);
   if (e) return e;
   const int c4n = c / 4;
-  const int64_t total4 = npix * c4n;
-  const int nb2 = ew_blocks(total4);
-#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<T, A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, total4, c4n)
+  const int nb2 = ew_blocks_px(npix, c4n);
+#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<T, A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, npix, c4n)
   if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
 #undef L2
   SSMI_LAUNCH_CHECK();
@@ -627,9 +746,8 @@ static ssmi_status bn_act_drop_fwd_impl(const T* x, int32_t ld_x, const float* m
   SSMI_REQUIRE(npix * ld_x * 4 < 0x7FFFFFFFLL && npix * ld_y * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
                "bn_act_fwd: tensors of 2^29 elements or more are not supported");
   const int c4n = c / 4;
-  const int64_t total4 = npix * c4n;
-  const int nb = ew_blocks(total4);
-#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, total4, c4n)
+  const int nb = ew_blocks_px(npix, c4n);
+#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, npix, c4n)
   if (act == SSMI_ACT_NONE) L(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L(SSMI_ACT_LEAKY);
   else { set_error("bn_act_fwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L
@@ -702,9 +820,9 @@ static ssmi_status fill_merge(const ssmi_merge_desc* d, const void* main, const 
 template <typename T>
 static ssmi_status merge_fwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, T* out, void* stream) {
   const int c4n = d->c / 4;
-  const int64_t total4 = (int64_t)d->n * d->h * d->w * c4n;
-  const int nb = ew_blocks(total4);
-#define L(M) hipLaunchKernelGGL((merge_fwd_kernel<T, M>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, total4, c4n)
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  const int nb = ew_blocks_px(npix, c4n);
+#define L(M) hipLaunchKernelGGL((merge_fwd_kernel<T, M>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, npix, c4n)
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
   SSMI_LAUNCH_CHECK();
@@ -727,9 +845,8 @@ static ssmi_status merge_bwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, 
   SSMI_LAUNCH_CHECK();
   ssmi_status s = launch_bn_bwd_final(part, nb, c, npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
   if (s) return s;
-  const int64_t total4 = npix * c4n;
-  hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks(total4)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main), bn3->mean,
-                     bn3->invstd, drop, coef, dmain, total4, c4n, (int64_t)d->h * d->w);
+  hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main), bn3->mean,
+                     bn3->invstd, drop, coef, dmain, npix, c4n, (int64_t)d->h * d->w);
   SSMI_LAUNCH_CHECK();
   if (d->other_mode >= 2) {
     const int64_t t4 = (int64_t)d->n * (d->h / 2) * (d->w / 2) * c4n;
