@@ -123,6 +123,14 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, con
  * carries the gradient of the block's skip branch (src/models.py:1171). */
 ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,
                                  void* stream);
+
+/* Data gradient with a workspace: wide stride-1 layers (both channel counts >= 64) run as a forward convolution over dy
+ * with the rotated, transposed kernel matrix, which is built in `ws` by a small launch in front (src/models.py:828-879, the
+ * 3x3 Conv2D stacks of U-Net / SegNet, whose gradients Keras derives).  ssmi_conv2d_bwd_data_workspace_bytes() may be 0:
+ * then ws is not touched and the call equals ssmi_conv2d_bwd_data. */
+size_t ssmi_conv2d_bwd_data_workspace_bytes(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv2d_bwd_data_ws(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,
+                                    void* ws, size_t ws_bytes, void* stream);
 /* Data gradient whose result is the gradient of a BatchNormalization(+activation, +SpatialDropout2D) OUTPUT, i.e. every
  * "BN -> act -> conv" chain walked backwards (src/models.py:1096-1118 and the convolution blocks :846-876).  Same `da`
  * as ssmi_conv2d_bwd_data (desc = the convolution; da has the x-like shape [n,h,w,cin], pixel stride x_ld) followed by

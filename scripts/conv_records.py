@@ -1,5 +1,6 @@
 """Per-launch records of the convolution kernels in one eager training step (variant, duration net of the event bracket,
-algorithmic MB, GFLOP, GB/s), grouped by (variant, bytes, flops):  python scripts/conv_records.py [model] [batch]"""
+algorithmic MB, GFLOP, GB/s), grouped by (variant, bytes, flops):  python scripts/conv_records.py [model] [batch] [json]
+With a third argument the per-variant sums (launches, algorithmic bytes and flops per step) are also written as JSON."""
 import ctypes as C
 import importlib
 import os
@@ -51,6 +52,16 @@ def main():
         us = t / n * 1e3
         print("%-52s n/step %3d  %7.1f us  %7.2f MB  %7.3f GFLOP  %7.1f GB/s  %6.2f TF  total %6.3f ms/step" % (
             k[:52], n // 3, us, mb, gf, mb / us * 1e3, gf / us * 1e3, t / 3))
+    if len(sys.argv) > 3:
+        import json
+        per = defaultdict(lambda: {"launches_per_step": 0, "bytes_per_step": 0.0, "flops_per_step": 0.0, "ms_per_step_eager": 0.0})
+        for (k, mb, gf), (t, n) in agg.items():
+            e = per[k]
+            e["launches_per_step"] += n // 3
+            e["bytes_per_step"] += mb * 1e6 * (n // 3)
+            e["flops_per_step"] += gf * 1e9 * (n // 3)
+            e["ms_per_step_eager"] += t / 3
+        json.dump(per, open(sys.argv[3], "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

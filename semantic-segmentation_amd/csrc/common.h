@@ -61,6 +61,9 @@ struct BnBwdArgs {
   // the identity-skip merge of a bottleneck folded into its last convolution (skip == nullptr: no addend)
   const void* skip;        // activation type
   int skip_ld;
+  // forward kernel run as a data gradient (rotated, transposed kernel matrix): x != nullptr selects the BN-backward sums
+  // above instead of the inference epilogue; add: gradient arriving over a skip connection, layout of the output
+  const void* add;
 };
 
 // Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.

@@ -10,6 +10,8 @@
 // accumulator register i of lane l is C[row = (i&3) + 8*(i>>2) + 4*(l>>5)][col = l&31].
 #include "common.h"
 
+#include <algorithm>
+
 namespace ssmi {
 
 struct Geo {
@@ -44,12 +46,12 @@ template <typename T, int NT, bool VEC>
 __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
-  __shared__ float stat_sm[4 * 2 * NT * 32];
+  __shared__ float stat_sm[4 * 3 * NT * 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  if (tile0 >= M && part == nullptr) return;   // with statistics every wave reaches the barrier (its rows are masked)
+  if (tile0 >= M && part == nullptr && bn.x == nullptr) return;   // with statistics every wave reaches the barrier (its rows are masked)
   const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
   const unsigned p = (unsigned)tile0 + (unsigned)r;       // M < 2^31: 32-bit pixel arithmetic
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
   for (int t = 0; t < NT; ++t) {
     const int c = cbase + t * 32 + r;
     const float bv = bias ? bload(make_rsrc(bias, (unsigned)g.cout * 4u), colv[t] ? (unsigned)c * 4u : kOOB) : 0.f;
-    if (bn.mean) {   // uniform; inference phase: BatchNormalization (fixed statistics) + activation applied before the store
+    if (bn.mean && bn.x == nullptr) {   // uniform; inference phase: BatchNormalization (fixed statistics) + activation applied before the store
       const int cc = colv[t] ? c : 0;
       const float mu = bn.mean[cc], is = bn.invstd[cc], ga = bn.gamma[cc], be = bn.beta[cc];
       const float al = bn.act == SSMI_ACT_PRELU ? bn.alpha[cc] : bn.slope;
@@ -197,6 +199,48 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
         if (bn.skip) z += sk[i];
         Act<T>::st(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, (bn.act == SSMI_ACT_NONE || z > 0.f) ? z : al * z);
       }
+    } else if (bn.add || bn.x) {   // uniform; data-gradient mode: skip gradient added, optional BatchNormalization backward sums
+      const __amdgpu_buffer_rsrc_t radd = Act<T>::rsrc(bn.add ? bn.add : (const void*)y, bn.add ? sz.y_bytes : 0u);
+      const __amdgpu_buffer_rsrc_t rbx = Act<T>::rsrc(bn.x ? bn.x : (const void*)y, bn.x ? (unsigned)(M * bn.ld * 4) : 0u);
+      float av[16], xr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+        av[i] = Act<T>::ld(radd, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB);
+        xr[i] = Act<T>::ld(rbx, (colv[t] && rowoff[i] != kOOB) ? (po * (unsigned)bn.ld + (unsigned)c) * 4u : kOOB);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Act<T>::st(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv + av[i]);
+      if (bn.x) {
+        const int cc = colv[t] ? c : 0;
+        const float mu = bn.mean[cc], is = bn.invstd[cc], ga = bn.gamma[cc], be = bn.beta[cc];
+        const float al = bn.act == SSMI_ACT_PRELU ? bn.alpha[cc] : bn.slope;
+        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const bool ok = colv[t] && rowoff[i] != kOOB;
+          float d = acc[t][i] + bv + av[i];
+          if (bn.drop) {
+            const unsigned po = (unsigned)tile0 + (unsigned)((i & 3) + 8 * (i >> 2) + 4 * hh);
+            d *= bn.drop[(ok ? po / bn.hw : 0u) * (unsigned)g.cout + (unsigned)cc];
+          }
+          const float xh = (xr[i] - mu) * is;
+          const float z = ga * xh + be;
+          const float gr = bn.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al : 0.f));
+          const float dz = ok ? d * gr : 0.f;
+          s1 += dz;
+          s2 += dz * xh;
+          s3 += ok ? d * (z < 0.f ? z : 0.f) : 0.f;
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        s3 += __shfl_xor(s3, 32, 64);
+        if (hh == 0) {
+          stat_sm[(wave * 3 + 0) * (NT * 32) + t * 32 + r] = s1;
+          stat_sm[(wave * 3 + 1) * (NT * 32) + t * 32 + r] = s2;
+          stat_sm[(wave * 3 + 2) * (NT * 32) + t * 32 + r] = s3;
+        }
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) Act<T>::st(ry, colv[t] ? rowoff[i] + (unsigned)c * 4u : kOOB, acc[t][i] + bv);
@@ -212,8 +256,22 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 32, 64);
       if (hh == 0) {
-        stat_sm[(wave * 2 + 0) * (NT * 32) + t * 32 + r] = s1;
-        stat_sm[(wave * 2 + 1) * (NT * 32) + t * 32 + r] = s2;
+        stat_sm[(wave * 3 + 0) * (NT * 32) + t * 32 + r] = s1;
+        stat_sm[(wave * 3 + 1) * (NT * 32) + t * 32 + r] = s2;
+      }
+    }
+  }
+  if (bn.x) {      // uniform; never together with `part`
+    __syncthreads();
+    if (threadIdx.x < NT * 32) {
+      const int c = cbase + threadIdx.x;
+      if (c < g.cout) {
+        for (int k = 0; k < 3; ++k) {
+          float sk = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < 4; ++wv) sk += stat_sm[(wv * 3 + k) * (NT * 32) + threadIdx.x];
+          bn.part[((int64_t)blockIdx.x * 3 + k) * g.cout + c] = sk;
+        }
       }
     }
   }
@@ -225,8 +283,8 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int wv = 0; wv < 4; ++wv) {
-          s1 += stat_sm[(wv * 2 + 0) * (NT * 32) + threadIdx.x];
-          s2 += stat_sm[(wv * 2 + 1) * (NT * 32) + threadIdx.x];
+          s1 += stat_sm[(wv * 3 + 0) * (NT * 32) + threadIdx.x];
+          s2 += stat_sm[(wv * 3 + 1) * (NT * 32) + threadIdx.x];
         }
         part[((int64_t)blockIdx.x * 2 + 0) * g.cout + c] = s1;
         part[((int64_t)blockIdx.x * 2 + 1) * g.cout + c] = s2;
@@ -1554,6 +1612,31 @@ __global__ __launch_bounds__(256) void colsum_final(const float* __restrict__ pa
   }
 }
 
+// Kernel matrix of the data gradient seen as a forward convolution over dy (stride 1):
+//   wt[kh-1-ky][kw-1-kx][co][ci] = w[ky][kx][ci][co]
+// so that the lanes of an MFMA column read consecutive words, as in the forward pass (in the gather-form data-gradient
+// kernel a lane's words are cout * 4 bytes apart: 16-32 cache lines per load on the 64..512-channel layers).
+__global__ __launch_bounds__(256) void conv_wt_rot_kernel(const float* __restrict__ w, float* __restrict__ wt, int kh, int kw,
+                                                          int cin, int cout) {
+  const int total = kh * kw * cin * cout;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int ci = e % cin;
+    const int t1 = e / cin;
+    const int co = t1 % cout;
+    const int tap = t1 / cout;
+    const int ky = tap / kw, kx = tap - ky * kw;
+    wt[e] = w[(((kh - 1 - ky) * kw + (kw - 1 - kx)) * cin + ci) * cout + co];
+  }
+}
+
+// Data gradient of wide stride-1 layers through the forward kernel: worth a rotation launch when both channel counts are
+// at least 64 (U-Net / SegNet: 3x3 64->64 at 512x512, batch 4: 1579 us gather form vs 793 us forward form).
+static bool dgrad_as_fwd(const Geo& g) {
+  static const bool off = getenv("SSMI_NO_DGRAD_AS_FWD") != nullptr;
+  return !off && g.stride == 1 && g.cin >= 64 && g.cout >= 64 && g.cout % 8 == 0 && g.y_ld % 4 == 0 && g.ho == g.h && g.wo == g.w;
+}
+static size_t dgrad_wt_bytes(const Geo& g) { return dgrad_as_fwd(g) ? (size_t)g.kh * g.kw * g.cin * g.cout * sizeof(float) : 0; }
+
 static ssmi_status check_desc(const ssmi_conv_desc* d) {
   SSMI_REQUIRE(d != nullptr, SSMI_E_INVALID_ARG, "conv desc is NULL");
   SSMI_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0, SSMI_E_SHAPE,
@@ -1761,12 +1844,13 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
 // bn.mean != nullptr: inference-phase BatchNormalization + activation applied in the epilogue (bn.x stays nullptr).
 template <typename T>
 static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const float* bias, T* y,
-                              hipStream_t st, float* part = nullptr, int* part_rows = nullptr, BnBwdArgs bn = BnBwdArgs{}) {
+                              hipStream_t st, float* part = nullptr, int* part_rows = nullptr, BnBwdArgs bn = BnBwdArgs{},
+                              bool direct_only = false) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
-  ProfileScope prof(st, conv_bytes(g, false, sizeof(T)), conv_flops(g));
-  if (launch_gemm_lds<T>(g, sz, 0, x, w, bias, (const T*)nullptr, y, st, &e, part, part_rows, bn)) return e;
+  ProfileScope prof(st, conv_bytes(g, bn.add != nullptr, sizeof(T)), conv_flops(g));
+  if (!direct_only && launch_gemm_lds<T>(g, sz, 0, x, w, bias, (const T*)nullptr, y, st, &e, part, part_rows, bn)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
@@ -1876,10 +1960,25 @@ __global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_b
 
 template <typename T>
 static ssmi_status launch_bwd_data(const Geo& g, const T* dy, const float* w, const T* add, const float* bias,
-                                   T* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr) {
+                                   T* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr,
+                                   float* wt = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  if (wt && dgrad_as_fwd(g)) {
+    // forward convolution over dy with the rotated, transposed kernel matrix: n, (ho, wo, cout) -> (h, w, cin)
+    const int total = g.kh * g.kw * g.cin * g.cout;
+    hipLaunchKernelGGL(conv_wt_rot_kernel, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, w, wt, g.kh, g.kw,
+                       g.cin, g.cout);
+    SSMI_LAUNCH_CHECK();
+    Geo f = g;
+    f.h = g.ho; f.w = g.wo; f.cin = g.cout; f.x_ld = g.y_ld;
+    f.ho = g.h; f.wo = g.w; f.cout = g.cin; f.y_ld = g.x_ld;
+    f.pad_t = (g.kh - 1) * g.dil - g.pad_t;
+    f.pad_l = (g.kw - 1) * g.dil - g.pad_l;
+    bb.add = add;
+    return launch_fwd<T>(f, dy, wt, bias, dx, st, nullptr, part_rows, bb, true);
+  }
   ProfileScope prof(st, conv_bytes(g, add != nullptr, sizeof(T)), conv_flops(g));
   if (g.kh == 2 && g.kw == 2 && g.stride == 2 && g.dil == 1 && g.pad_t == 0 && g.pad_l == 0 && g.h == 2 * g.ho &&
       g.w == 2 * g.wo && g.cout % 8 == 0 && g.y_ld % 4 == 0 && bb.x == nullptr && part_rows == nullptr &&
@@ -2296,12 +2395,31 @@ ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const 
   });
 }
 
+size_t ssmi_conv2d_bwd_data_workspace_bytes(const ssmi_conv_desc* d) {
+  if (check_desc(d) != SSMI_OK) return 0;
+  return dgrad_wt_bytes(to_geo(d));
+}
+
+ssmi_status ssmi_conv2d_bwd_data_ws(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(dy && w && dx, SSMI_E_INVALID_ARG, "conv2d_bwd_data_ws: NULL tensor");
+  const size_t need = ssmi_conv2d_bwd_data_workspace_bytes(d);
+  SSMI_REQUIRE(need == 0 || (ws && ws_bytes >= need), SSMI_E_WORKSPACE, "conv2d_bwd_data_ws: workspace too small");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_bwd_data<T>(to_geo(d), static_cast<const T*>(dy), w, static_cast<const T*>(add), nullptr, static_cast<T*>(dx),
+                              as_stream(stream), BnBwdArgs{}, nullptr, need ? static_cast<float*>(ws) : nullptr);
+  });
+}
+
 size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d) {
   if (check_desc(d) != SSMI_OK) return 0;
   const int64_t npix = (int64_t)d->n * d->h * d->w;
   const size_t fused = (size_t)((ceil_div64(npix, 128) + 1024) * 3 + 3) * d->cin * sizeof(float);
   const size_t plain = ssmi_bn_workspace_bytes(npix, d->cin);
-  return fused > plain ? fused : plain;
+  return (fused > plain ? fused : plain) + dgrad_wt_bytes(to_geo(d));      // the rotated kernel matrix sits behind the sums
 }
 
 extern "C++" {
@@ -2315,20 +2433,22 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
   const int64_t npix = (int64_t)d->n * d->h * d->w;
   const int c = d->cin;
   hipStream_t st = as_stream(stream);
+  float* wt = nullptr;
+  if (dgrad_wt_bytes(g)) wt = reinterpret_cast<float*>(static_cast<char*>(ws) + (ws_bytes - dgrad_wt_bytes(g)) / 16 * 16);
   static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;   // A/B switch for measurements
   if (no_fuse || d->stride != 1 || c % 4 != 0 || c > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < c ||
       npix * ld_x * 4 >= 0x7FFFFFFFLL || (drop && (hw <= 0 || npix % hw != 0))) {
-    ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st);          // unfused: the two passes of the plain entry points
+    ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, BnBwdArgs{}, nullptr, wt);   // unfused: two plain passes
     if (s) return s;
     return bn_act_drop_bwd_impl<T>(da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn, dgamma,
-                                   dbeta, dalpha, npix, c, ws, ws_bytes, stream);
+                                   dbeta, dalpha, npix, c, ws, ws_bytes - dgrad_wt_bytes(g), stream);
   }
   float* part = reinterpret_cast<float*>(ws);
   BnBwdArgs bb{};
   bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
   bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
   int rows = 0;
-  ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows);
+  ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows, wt);
   if (s) return s;
   float* coef = part + (size_t)rows * 3 * c;
   return launch_bn_bwd_tail<T>(part, rows, da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn,

@@ -182,7 +182,9 @@ class Conv:
             d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l = self.kh, self.kw, self.stride, self.dil, pt, pl
             self.ws_bytes = max(L.conv2d_bwd_weight_workspace_bytes(C.byref(d)),
                                 L.conv2d_fwd_bn_stats_workspace_bytes(C.byref(d)),
-                                L.conv2d_bwd_data_bn_bwd_workspace_bytes(C.byref(d)))
+                                L.conv2d_bwd_data_bn_bwd_workspace_bytes(C.byref(d)),
+                                L.conv2d_bwd_data_workspace_bytes(C.byref(d)))
+            self.bwd_data_ws_bytes = L.conv2d_bwd_data_workspace_bytes(C.byref(d))
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
             H, W = h * self.stride, w * self.stride
@@ -195,6 +197,7 @@ class Conv:
             out_hw = (H, W)
             d.kh, d.kw, d.stride, d.dil, d.pad_t, d.pad_l = self.kh, self.kw, self.stride, 1, pt, pl
             self.ws_bytes = L.conv2d_transpose_bwd_weight_workspace_bytes(C.byref(d))
+            self.bwd_data_ws_bytes = 0
         self.desc = d
         self._dref = C.byref(d)
         v, g = self.store.views, self.store.gviews
@@ -238,11 +241,14 @@ class Conv:
                                           _ptr(bn.gamma), _ptr(bn.beta), _ptr(skip), skip_ld, ACT_PRELU, _ptr(alpha), 0.0,
                                           _ptr(y), st)
 
-    def bwd_data(self, dy, dx, st, add=None):
+    def bwd_data(self, dy, dx, st, add=None, ws=None):
+        """ws: the main stream's workspace; wide layers build their rotated kernel matrix in it (see ssmi_conv2d_bwd_data_ws)."""
         L = self.store.L
         if self.transpose:
             assert add is None
             L.conv2d_transpose_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(dx), st)
+        elif ws is not None and self.bwd_data_ws_bytes:
+            L.conv2d_bwd_data_ws(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), _ptr(ws), ws.numel() * 4, st)
         else:
             L.conv2d_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), st)
 

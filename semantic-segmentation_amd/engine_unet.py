@@ -83,7 +83,7 @@ class ConvUnit:
                                   slope=LEAKY_ALPHA, drop=drop, hw=p.h * p.w)
             return None
         if self.needs_dx:
-            self.conv.bwd_data(self.dy, self.dx, cfg.st)
+            self.conv.bwd_data(self.dy, self.dx, cfg.st, ws=cfg.ws)
         return self.dx
 
 
@@ -256,7 +256,7 @@ class PointwiseHead(Block):
 
     def bwd(self, dout, cfg):
         cfg.wgrad(self.conv, self.x, dout)
-        self.conv.bwd_data(dout, self.dx, cfg.st)
+        self.conv.bwd_data(dout, self.dx, cfg.st, ws=cfg.ws)
         return self.dx
 
 
