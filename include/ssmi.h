@@ -128,6 +128,21 @@ ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const 
  * with the rotated, transposed kernel matrix, which is built in `ws` by a small launch in front (src/models.py:828-879, the
  * 3x3 Conv2D stacks of U-Net / SegNet, whose gradients Keras derives).  ssmi_conv2d_bwd_data_workspace_bytes() may be 0:
  * then ws is not touched and the call equals ssmi_conv2d_bwd_data. */
+/* Pre-rotated kernel matrices: ssmi_conv_rotate_weights writes, for every table entry, the data-gradient form
+ *   w_rot[kh-1-ky][kw-1-kx][co][ci] = w[ky][kx][ci][co]
+ * of the convolution kernel at theta + offset to theta_rot + offset (one launch for a whole parameter arena; `table` is
+ * DEVICE memory).  The _rot entry points take that matrix beside the original and run the data gradient of stride-1 layers
+ * as a forward convolution over dy wherever ssmi_conv2d_bwd_data_uses_rotated() says so (w_rot may be NULL: then they equal
+ * the plain entry points).  No counterpart in the reference: Keras derives these gradients (src/models.py:1069-1319). */
+typedef struct ssmi_rot_entry {
+  int64_t offset;            /* in floats, from theta / theta_rot */
+  int32_t kh, kw, cin, cout;
+} ssmi_rot_entry;
+int32_t ssmi_conv2d_bwd_data_uses_rotated(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv_rotate_weights(const ssmi_rot_entry* table, int32_t count, const float* theta, float* theta_rot,
+                                     void* stream);
+ssmi_status ssmi_conv2d_bwd_data_rot(const ssmi_conv_desc* d, const void* dy, const float* w, const float* w_rot, const void* add,
+                                     void* dx, void* stream);
 size_t ssmi_conv2d_bwd_data_workspace_bytes(const ssmi_conv_desc* d);
 ssmi_status ssmi_conv2d_bwd_data_ws(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,
                                     void* ws, size_t ws_bytes, void* stream);
@@ -139,6 +154,13 @@ ssmi_status ssmi_conv2d_bwd_data_ws(const ssmi_conv_desc* d, const void* dy, con
  * da and bn_x; other shapes run the two plain passes.  ws: ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d). */
 size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d);
 ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add,
+                                        void* da, const void* bn_x, int32_t ld_x, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                        const float* alpha, float slope, const float* drop, int64_t hw, void* dx_bn,
+                                        float* dgamma, float* dbeta, float* dalpha, void* ws, size_t ws_bytes,
+                                        void* stream);
+/* the same with a pre-rotated kernel matrix (see ssmi_conv_rotate_weights) */
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot(const ssmi_conv_desc* d, const void* dy, const float* w, const float* w_rot, const void* add,
                                         void* da, const void* bn_x, int32_t ld_x, const float* mean,
                                         const float* invstd, const float* gamma, const float* beta, int32_t act,
                                         const float* alpha, float slope, const float* drop, int64_t hw, void* dx_bn,

@@ -1631,11 +1631,36 @@ __global__ __launch_bounds__(256) void conv_wt_rot_kernel(const float* __restric
 
 // Data gradient of wide stride-1 layers through the forward kernel: worth a rotation launch when both channel counts are
 // at least 64 (U-Net / SegNet: 3x3 64->64 at 512x512, batch 4: 1579 us gather form vs 793 us forward form).
-static bool dgrad_as_fwd(const Geo& g) {
+// A matrix the caller rotated beforehand (ssmi_conv_rotate_weights, one launch for a whole parameter arena) saves the
+// per-layer rotation launch; the layers are the same.  Narrower layers were measured too (every stride-1 ENet layer with
+// more than 16 input channels, pre-rotated): the step got slower, 9.88 -> 10.22 ms - their gather-form kernels are bound
+// by instruction issue, not by the kernel-matrix loads, and the forward kernel's fused-BN-backward epilogue costs more.
+static bool dgrad_as_fwd(const Geo& g, bool prerotated = false) {
+  (void)prerotated;
   static const bool off = getenv("SSMI_NO_DGRAD_AS_FWD") != nullptr;
   return !off && g.stride == 1 && g.cin >= 64 && g.cout >= 64 && g.cout % 8 == 0 && g.y_ld % 4 == 0 && g.ho == g.h && g.wo == g.w;
 }
 static size_t dgrad_wt_bytes(const Geo& g) { return dgrad_as_fwd(g) ? (size_t)g.kh * g.kw * g.cin * g.cout * sizeof(float) : 0; }
+
+struct RotEntry {          // mirrors ssmi_rot_entry
+  int64_t offset;
+  int32_t kh, kw, cin, cout;
+};
+__global__ __launch_bounds__(256) void conv_wt_rot_batch_kernel(const RotEntry* __restrict__ table, const float* __restrict__ theta,
+                                                                float* __restrict__ theta_rot) {
+  const RotEntry en = table[blockIdx.y];
+  const float* w = theta + en.offset;
+  float* wt = theta_rot + en.offset;
+  const int total = en.kh * en.kw * en.cin * en.cout;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int ci = e % en.cin;
+    const int t1 = e / en.cin;
+    const int co = t1 % en.cout;
+    const int tap = t1 / en.cout;
+    const int ky = tap / en.kw, kx = tap - ky * en.kw;
+    wt[e] = w[(((en.kh - 1 - ky) * en.kw + (en.kw - 1 - kx)) * en.cin + ci) * en.cout + co];
+  }
+}
 
 static ssmi_status check_desc(const ssmi_conv_desc* d) {
   SSMI_REQUIRE(d != nullptr, SSMI_E_INVALID_ARG, "conv desc is NULL");
@@ -1961,16 +1986,20 @@ __global__ __launch_bounds__(256, (NT == 1 ? 6 : (NT == 2 ? 4 : 3))) void conv_b
 template <typename T>
 static ssmi_status launch_bwd_data(const Geo& g, const T* dy, const float* w, const T* add, const float* bias,
                                    T* dx, hipStream_t st, BnBwdArgs bb = BnBwdArgs{}, int* part_rows = nullptr,
-                                   float* wt = nullptr) {
+                                   float* wt = nullptr, const float* w_rot = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
-  if (wt && dgrad_as_fwd(g)) {
+  if ((w_rot && dgrad_as_fwd(g, true)) || (wt && dgrad_as_fwd(g))) {
     // forward convolution over dy with the rotated, transposed kernel matrix: n, (ho, wo, cout) -> (h, w, cin)
-    const int total = g.kh * g.kw * g.cin * g.cout;
-    hipLaunchKernelGGL(conv_wt_rot_kernel, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, w, wt, g.kh, g.kw,
-                       g.cin, g.cout);
-    SSMI_LAUNCH_CHECK();
+    if (w_rot && dgrad_as_fwd(g, true)) {
+      wt = const_cast<float*>(w_rot);       // rotated by the caller, read only
+    } else {
+      const int total = g.kh * g.kw * g.cin * g.cout;
+      hipLaunchKernelGGL(conv_wt_rot_kernel, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, w, wt, g.kh,
+                         g.kw, g.cin, g.cout);
+      SSMI_LAUNCH_CHECK();
+    }
     Geo f = g;
     f.h = g.ho; f.w = g.wo; f.cin = g.cout; f.x_ld = g.y_ld;
     f.ho = g.h; f.wo = g.w; f.cout = g.cin; f.y_ld = g.x_ld;
@@ -2414,6 +2443,33 @@ ssmi_status ssmi_conv2d_bwd_data_ws(const ssmi_conv_desc* d, const void* dy, con
   });
 }
 
+int32_t ssmi_conv2d_bwd_data_uses_rotated(const ssmi_conv_desc* d) {
+  if (check_desc(d) != SSMI_OK) return 0;
+  return dgrad_as_fwd(to_geo(d), true) ? 1 : 0;
+}
+
+ssmi_status ssmi_conv_rotate_weights(const ssmi_rot_entry* table, int32_t count, const float* theta, float* theta_rot,
+                                     void* stream) {
+  static_assert(sizeof(RotEntry) == sizeof(ssmi_rot_entry), "rotation table entry layout");
+  SSMI_REQUIRE(table && theta && theta_rot && count > 0 && count <= 65535, SSMI_E_INVALID_ARG, "conv_rotate_weights: bad argument");
+  hipLaunchKernelGGL(conv_wt_rot_batch_kernel, dim3(16, (unsigned)count), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const RotEntry*>(table), theta, theta_rot);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_conv2d_bwd_data_rot(const ssmi_conv_desc* d, const void* dy, const float* w, const float* w_rot, const void* add,
+                                     void* dx, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(dy && w && dx, SSMI_E_INVALID_ARG, "conv2d_bwd_data_rot: NULL tensor");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_bwd_data<T>(to_geo(d), static_cast<const T*>(dy), w, static_cast<const T*>(add), nullptr, static_cast<T*>(dx),
+                              as_stream(stream), BnBwdArgs{}, nullptr, nullptr, w_rot);
+  });
+}
+
 size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d) {
   if (check_desc(d) != SSMI_OK) return 0;
   const int64_t npix = (int64_t)d->n * d->h * d->w;
@@ -2424,7 +2480,7 @@ size_t ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(const ssmi_conv_desc* d) {
 
 extern "C++" {
 template <typename T>
-static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T* dy, const float* w, const T* add, T* da,
+static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T* dy, const float* w, const float* w_rot, const T* add, T* da,
                                                const T* bn_x, int32_t ld_x, const float* mean, const float* invstd,
                                                const float* gamma, const float* beta, int32_t act, const float* alpha,
                                                float slope, const float* drop, int64_t hw, T* dx_bn, float* dgamma,
@@ -2438,7 +2494,7 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
   static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;   // A/B switch for measurements
   if (no_fuse || d->stride != 1 || c % 4 != 0 || c > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < c ||
       npix * ld_x * 4 >= 0x7FFFFFFFLL || (drop && (hw <= 0 || npix % hw != 0))) {
-    ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, BnBwdArgs{}, nullptr, wt);   // unfused: two plain passes
+    ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, BnBwdArgs{}, nullptr, wt, w_rot);   // unfused: two plain passes
     if (s) return s;
     return bn_act_drop_bwd_impl<T>(da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn, dgamma,
                                    dbeta, dalpha, npix, c, ws, ws_bytes - dgrad_wt_bytes(g), stream);
@@ -2448,7 +2504,7 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
   bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
   bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
   int rows = 0;
-  ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows, wt);
+  ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows, wt, w_rot);
   if (s) return s;
   float* coef = part + (size_t)rows * 3 * c;
   return launch_bn_bwd_tail<T>(part, rows, da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn,
@@ -2472,7 +2528,30 @@ ssmi_status ssmi_conv2d_bwd_data_bn_bwd(const ssmi_conv_desc* d, const void* dy,
                "conv2d_bwd_data_bn_bwd: bad activation");
   return dispatch_dtype(d->dtype, [&](auto tag) {
     using T = decltype(tag);
-    return conv2d_bwd_data_bn_bwd_impl<T>(d, static_cast<const T*>(dy), w, static_cast<const T*>(add), static_cast<T*>(da),
+    return conv2d_bwd_data_bn_bwd_impl<T>(d, static_cast<const T*>(dy), w, nullptr, static_cast<const T*>(add), static_cast<T*>(da),
+                                          static_cast<const T*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop,
+                                          hw, static_cast<T*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream);
+  });
+}
+
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot(const ssmi_conv_desc* d, const void* dy, const float* w, const float* w_rot,
+                                            const void* add,
+                                        void* da, const void* bn_x, int32_t ld_x, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, int32_t act,
+                                        const float* alpha, float slope, const float* drop, int64_t hw, void* dx_bn,
+                                        float* dgamma, float* dbeta, float* dalpha, void* ws, size_t ws_bytes,
+                                        void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(dy && w && da && bn_x && mean && invstd && gamma && beta && dx_bn, SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd_rot: NULL tensor");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_bwd_data_bn_bwd_rot: workspace too small");
+  SSMI_REQUIRE(act >= SSMI_ACT_NONE && act <= SSMI_ACT_LEAKY && (act != SSMI_ACT_PRELU || alpha), SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd_rot: bad activation");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return conv2d_bwd_data_bn_bwd_impl<T>(d, static_cast<const T*>(dy), w, w_rot, static_cast<const T*>(add), static_cast<T*>(da),
                                           static_cast<const T*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop,
                                           hw, static_cast<T*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream);
   });

@@ -161,6 +161,8 @@ class Conv:
         self.store = store
         self.desc = None
         self.ws_bytes = 0
+        self.uses_rot = False     # the data gradient can use a pre-rotated kernel matrix (decided by the library in plan())
+        self.wrot = None          # that matrix: a view of the network's rotated arena, refreshed once per step
 
     def plan(self, n, h, w, x_ld=None, y_ld=None):
         """(h, w) is the spatial size of this layer's INPUT.  Returns the output (h, w)."""
@@ -185,6 +187,7 @@ class Conv:
                                 L.conv2d_bwd_data_bn_bwd_workspace_bytes(C.byref(d)),
                                 L.conv2d_bwd_data_workspace_bytes(C.byref(d)))
             self.bwd_data_ws_bytes = L.conv2d_bwd_data_workspace_bytes(C.byref(d))
+            self.uses_rot = bool(L.conv2d_bwd_data_uses_rotated(C.byref(d)))
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
             H, W = h * self.stride, w * self.stride
@@ -247,6 +250,8 @@ class Conv:
         if self.transpose:
             assert add is None
             L.conv2d_transpose_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(dx), st)
+        elif self.wrot is not None:
+            L.conv2d_bwd_data_rot(self._dref, _ptr(dy), _ptr(self.w), _ptr(self.wrot), _ptr(add), _ptr(dx), st)
         elif ws is not None and self.bwd_data_ws_bytes:
             L.conv2d_bwd_data_ws(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), _ptr(ws), ws.numel() * 4, st)
         else:
@@ -264,10 +269,10 @@ class Conv:
                                   _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(drop), hw, _ptr(dx_bn), _ptr(bn.dgamma),
                                   _ptr(bn.dbeta), _ptr(bn.dalpha), npix, self.cin, _ptr(ws), ws.numel() * 4, st)
             return
-        self.store.L.conv2d_bwd_data_bn_bwd(self._dref, _ptr(dy), _ptr(self.w), None, _ptr(da), _ptr(bn_x), ld_x, _ptr(bn.mean),
-                                     _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), slope, _ptr(drop),
-                                     hw, _ptr(dx_bn), _ptr(bn.dgamma), _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(ws),
-                                     ws.numel() * 4, st)
+        self.store.L.conv2d_bwd_data_bn_bwd_rot(self._dref, _ptr(dy), _ptr(self.w), _ptr(self.wrot), None, _ptr(da), _ptr(bn_x),
+                                                ld_x, _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), act,
+                                                _ptr(bn.alpha), slope, _ptr(drop), hw, _ptr(dx_bn), _ptr(bn.dgamma),
+                                                _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(ws), ws.numel() * 4, st)
 
     def bwd_weight(self, x, dy, ws, st):
         L = self.store.L
@@ -867,6 +872,38 @@ class GraphBase:
         self.overlap_weight_gradients = True
         self.drop_layers = [d for b in blocks for d in b.dropouts()]
 
+    # -- rotated kernel matrices for the data gradients ---------------------------------------------------
+    def _plan_rotated_weights(self, dev):
+        """Layers whose data gradient runs as a forward convolution over dy read a rotated, transposed copy of their
+        kernel; all copies live in one arena shaped like theta and are rewritten by ONE launch per training step."""
+        import numpy as _np
+        st = self.store
+        rows = []
+        for b in self.blocks:
+            for cv in b.convs():
+                cv.wrot = None
+                if cv.uses_rot and not cv.transpose and dev.type == "cuda" and not os.environ.get("SSMI_NO_ROTATED_ARENA"):
+                    sp = st.specs[cv.name + "/kernel"]
+                    rows.append((cv, sp))
+        self.rot_table = None
+        self.rot_count = len(rows)
+        if not rows:
+            return
+        if getattr(st, "theta_rot", None) is None or st.theta_rot.numel() != st.theta.numel():
+            st.theta_rot = torch.zeros_like(st.theta)
+        tab = _np.zeros(len(rows), dtype=_np.dtype([("offset", "<i8"), ("kh", "<i4"), ("kw", "<i4"), ("cin", "<i4"), ("cout", "<i4")]))
+        for i, (cv, sp) in enumerate(rows):
+            tab[i] = (sp.offset, cv.kh, cv.kw, cv.cin, cv.cout)
+            cv.wrot = st.theta_rot[sp.offset:sp.offset + sp.size]
+        self.rot_table = torch.from_numpy(tab.view(_np.uint8).copy()).to(dev)
+
+    def rotate_weights(self, stream=None):
+        """Refreshes the rotated arena from theta; to be called once per training step before the backward pass."""
+        if self.rot_table is None:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        lib().conv_rotate_weights(_ptr(self.rot_table), self.rot_count, _ptr(self.store.theta), _ptr(self.store.theta_rot), st)
+
     # -- planning -------------------------------------------------------------------------------------
     def plan(self, n, h, w):
         if self.shape == (n, h, w):
@@ -877,6 +914,7 @@ class GraphBase:
         dev = self.device
         L = lib()
         self._plan_blocks(n, h, w, dev)
+        self._plan_rotated_weights(dev)
         self.drop_arena, self.drop_groups, self.drop_views = plan_dropout_arena(self.drop_layers, n, dev)
         for b in self.blocks:
             b.bind_dropout(self.drop_views)
@@ -935,6 +973,7 @@ class GraphBase:
 
     def backward(self, dlogits: torch.Tensor):
         cfg = self._cfg
+        self.rotate_weights(cfg.st)
         d = dlogits
         for b in reversed(self.blocks):
             d = b.bwd(d, cfg)

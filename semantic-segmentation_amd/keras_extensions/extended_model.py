@@ -442,6 +442,7 @@ class ExtendedModel(object):
         carry = {}
 
         def seg_first(st):
+            g.rotate_weights(st)      # data-gradient forms of the kernels, from the weights this step starts with
             if g.drop_groups:
                 g.refresh_dropout(self.seed, self.optimizer.step_block, stream=st)
             g.forward(self.images_buf, training=True, update_moving=True, unbiased_moving=self.unbiased_moving_variance,
