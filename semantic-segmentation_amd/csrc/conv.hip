@@ -1751,7 +1751,8 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
   // Register-weight kernel: narrow outputs, stride 1, the two reductions that dominate the 16-channel stages of ENet
   // (1x1 over 64 channels, 3x3 over 16 channels).  SSMI_NO_REGW=1 keeps the LDS kernel (A/B measurements).
   static const bool no_regw = getenv("SSMI_NO_REGW") != nullptr;
-  if (!no_regw && force == 0 && m16 && vec && s == 1 && ((ntaps == 1 && a.C_r == 64) || (ntaps == 9 && g.kh == 3 && a.C_r == 16)) &&
+  if (!no_regw && force == 0 && m16 && vec && s == 1 &&
+      ((ntaps == 1 && (a.C_r == 16 || a.C_r == 64 || a.C_r == 128)) || (ntaps == 9 && g.kh == 3 && a.C_r == 16)) &&
       (mode == 0 || (g.ho == g.h && g.wo == g.w)) && !(mode == 0 && bb.mean != nullptr)) {
     const int64_t M = (int64_t)g.n * qh * qw;
     // Measured on MI355X (batch 16, 128x128): 3x3 16->16 forward 28.3 -> 23.3 us and data gradient 28.4 -> 22.9 us with two
@@ -1768,7 +1769,9 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
     if (part_rows) *part_rows = (int)bx;
     set_last_kernel("conv_regw<%d, %d, %d>", ntaps, a.C_r, mt_);
 #define LR(NTAP_, CR_, MT_) hipLaunchKernelGGL((conv_regw<T, NTAP_, CR_, MT_>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb)
-    if (ntaps == 1) { if (mt_ == 1) LR(1, 64, 1); else if (mt_ == 2) LR(1, 64, 2); else LR(1, 64, 4); }
+    if (ntaps == 1 && a.C_r == 64) { if (mt_ == 1) LR(1, 64, 1); else if (mt_ == 2) LR(1, 64, 2); else LR(1, 64, 4); }
+    else if (ntaps == 1 && a.C_r == 16) { if (mt_ == 1) LR(1, 16, 1); else LR(1, 16, 2); }
+    else if (ntaps == 1) { if (mt_ == 1) LR(1, 128, 1); else LR(1, 128, 2); }
     else { if (mt_ == 1) LR(9, 16, 1); else LR(9, 16, 2); }
 #undef LR
     hipError_t e = hipGetLastError();
