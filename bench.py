@@ -314,11 +314,16 @@ def measure_roofline(model, stream, steps=3):
     ai = fl / by
     gbs = by / (ms * 1e-3) / 1e9
     tfs = fl / (ms * 1e-3) / 1e12
+    # HBM bytes per launch from the committed counter passes (scripts/clean_evidence.sh: FETCH_SIZE / WRITE_SIZE with one kernel
+    # on the chip at a time); the trace names carry the storage type as first template argument, the records do not
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            traffic = json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    import re
+    for fname in ("r02_traffic.json", "r01_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", fname)
+        if traffic is None and os.path.exists(tpath):
+            with open(tpath) as f:
+                table = {re.sub(r"<(float|__bf16), ", "<", k): v for k, v in json.load(f).items()}
+            traffic = table.get(kernel, {}).get("hbm_bytes_per_launch")
     common = {"kernel": "ssmi::" + kernel, "launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
               "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
               "arithmetic_intensity_flop_per_byte": round(ai, 2), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),
