@@ -81,6 +81,13 @@ typedef struct ssmi_conv_desc {
   int32_t pad_t, pad_l;
   int32_t x_ld, y_ld;
   int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x, y, their gradients, `add`, `skip` and `bn_x` */
+  /* Optional (NULL = none), SSMI_BF16 only: bfloat16 copies of this layer's kernel written by ssmi_conv_pack_weights_bf16,
+   *   w_fwd_pack[tap][co][ci] and w_dgrad_pack[kh*kw-1-tap][ci][co] = bf16(w[tap][ci][co]).
+   * With them the forward convolution / the stride-1 data gradient of layers with cin (resp. cout) a multiple of 16 and more
+   * than 16 output (resp. input) channels run on the bfloat16 matrix instructions (v_mfma_f32_32x32x16_bf16): products of
+   * bfloat16 activations and bfloat16-ROUNDED weights, float32 accumulation.  The packs must be rewritten whenever w changes. */
+  const void* w_fwd_pack;
+  const void* w_dgrad_pack;
 } ssmi_conv_desc;
 
 /* TF SAME padding rule: out = ceil(in/stride); total = max((out-1)*stride + (k-1)*dil + 1 - in, 0);
@@ -138,6 +145,13 @@ typedef struct ssmi_rot_entry {
   int64_t offset;            /* in floats, from theta / theta_rot */
   int32_t kh, kw, cin, cout;
 } ssmi_rot_entry;
+/* bfloat16 kernel packs for a whole parameter arena (one launch): for every table entry (device memory) writes
+ * fwd_pack / dgrad_pack (bfloat16 arrays of 2 * n elements for a theta of n floats, either may be NULL; the pack of the entry
+ * at theta + offset starts at element 2 * offset, i.e. at the same BYTE offset as in theta) as described at ssmi_conv_desc.
+ * ssmi_conv2d_pack_usage(desc): bit 0 = the forward pass would use w_fwd_pack, bit 1 = the data gradient w_dgrad_pack. */
+ssmi_status ssmi_conv_pack_weights_bf16(const ssmi_rot_entry* table, int32_t count, const float* theta, uint16_t* fwd_pack,
+                                        uint16_t* dgrad_pack, void* stream);
+int32_t ssmi_conv2d_pack_usage(const ssmi_conv_desc* d);
 int32_t ssmi_conv2d_bwd_data_uses_rotated(const ssmi_conv_desc* d);
 ssmi_status ssmi_conv_rotate_weights(const ssmi_rot_entry* table, int32_t count, const float* theta, float* theta_rot,
                                      void* stream);

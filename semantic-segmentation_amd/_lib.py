@@ -20,7 +20,7 @@ class SsmiError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("n", "h", "w", "cin", "ho", "wo", "cout", "kh", "kw", "stride", "dil", "pad_t", "pad_l", "x_ld", "y_ld",
-                 "dtype")]
+                 "dtype")] + [("w_fwd_pack", C.c_void_p), ("w_dgrad_pack", C.c_void_p)]
 
 
 class MergeDesc(C.Structure):
@@ -62,6 +62,8 @@ _PROTOS = {
     "ssmi_conv2d_bwd_data_rot": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssmi_conv2d_bwd_data_uses_rotated": (_i32, [_PD]),
     "ssmi_conv_rotate_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "ssmi_conv_pack_weights_bf16": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_pack_usage": (_i32, [_PD]),
     "ssmi_conv2d_bwd_weight_workspace_bytes": (_sz, [_PD]),
     "ssmi_conv2d_bwd_weight": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_transpose_fwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp]),
@@ -133,7 +135,7 @@ _PROTOS["ssmi_cast_bf16_to_f32"] = (_i32, [_vp, _vp, _i64, _vp])
 F32, BF16 = 0, 1      # ssmi dtype codes of activation tensors
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 

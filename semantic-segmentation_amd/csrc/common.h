@@ -64,6 +64,8 @@ struct BnBwdArgs {
   // forward kernel run as a data gradient (rotated, transposed kernel matrix): x != nullptr selects the BN-backward sums
   // above instead of the inference epilogue; add: gradient arriving over a skip connection, layout of the output
   const void* add;
+  // bfloat16 storage only: the kernel as a bfloat16 pack [tap][cout][cin] (nullptr: float32 kernel words, fp32 MFMA)
+  const void* wpack;
 };
 
 // Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.

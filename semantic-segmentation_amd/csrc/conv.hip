@@ -16,6 +16,7 @@ namespace ssmi {
 
 struct Geo {
   int n, h, w, cin, ho, wo, cout, kh, kw, stride, dil, pad_t, pad_l, x_ld, y_ld;
+  const void *wfp, *wrp;      // bfloat16 kernel packs (forward / data-gradient form) or nullptr
 };
 
 static Geo to_geo(const ssmi_conv_desc* d) {
@@ -23,6 +24,8 @@ static Geo to_geo(const ssmi_conv_desc* d) {
   g.n = d->n; g.h = d->h; g.w = d->w; g.cin = d->cin; g.ho = d->ho; g.wo = d->wo; g.cout = d->cout;
   g.kh = d->kh; g.kw = d->kw; g.stride = d->stride; g.dil = d->dil; g.pad_t = d->pad_t; g.pad_l = d->pad_l;
   g.x_ld = d->x_ld; g.y_ld = d->y_ld;
+  g.wfp = d->dtype == SSMI_BF16 ? d->w_fwd_pack : nullptr;
+  g.wrp = d->dtype == SSMI_BF16 ? d->w_dgrad_pack : nullptr;
   return g;
 }
 
@@ -82,7 +85,64 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
   }
   const unsigned wrow = (unsigned)g.cout * 4u;   // bytes per (tap, ci) kernel row
 
-  if (VEC) {
+  bool packed = false;
+  if constexpr (sizeof(T) == 2 && VEC) packed = bn.wpack != nullptr;      // uniform
+  if (packed) {
+    if constexpr (sizeof(T) == 2 && VEC) {
+      // bfloat16 matrix instructions: one v_mfma_f32_32x32x16_bf16 per 16 input channels and column tile.  Lane (r, hh)
+      // feeds A = 8 consecutive channels of its pixel (one 16-byte load, no unpacking) and B = the same 8 channels of
+      // column r's kernel row from the pack [tap][cout][cin] (one 16-byte load).  Two steps of operands in flight.
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const int ntaps = g.kh * g.kw;
+      const __amdgpu_buffer_rsrc_t rp = make_rsrc(bn.wpack, (unsigned)(ntaps * g.cin * g.cout) * 2u);
+      unsigned bcol[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bcol[t] = colv[t] ? (unsigned)((cbase + t * 32 + r) * g.cin + 8 * hh) * 2u : kOOB;
+      const unsigned tapbytes = (unsigned)(g.cin * g.cout) * 2u;
+      int tap = 0, ky = 0, kx = 0, c0 = 0;            // state of the NEXT fetch
+      unsigned xo = 0, wtap = 0;
+      auto settap = [&]() {
+        const int iy = oy * g.stride + ky * g.dil - g.pad_t, ix = ox * g.stride + kx * g.dil - g.pad_l;
+        const bool inb = pv && tap < ntaps && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        // byte offset of the pixel in the bfloat16 tensor; the out-of-range marker is 2^30 (the descriptor is half as large)
+        xo = inb ? (n_ * (unsigned)(g.h * g.w) + (unsigned)(iy * g.w + ix)) * (unsigned)g.x_ld * 2u : (kOOB >> 1);
+        wtap = tap < ntaps ? (unsigned)tap * tapbytes : kOOB;
+      };
+      settap();
+      auto fetch = [&](u32x4& a, u32x4 (&b)[NT]) {
+        const unsigned cb = (unsigned)(c0 + 8 * hh) * 2u;
+        a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo + cb) | (xo & (kOOB >> 1)), 0, 0));
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          b[t] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (wtap + (unsigned)c0 * 2u + bcol[t]) | (wtap & kOOB) | (bcol[t] & kOOB), 0, 0));
+        c0 += 16;
+        if (c0 >= g.cin) {
+          c0 = 0;
+          ++tap;
+          if (++kx == g.kw) { kx = 0; ++ky; }
+          settap();
+        }
+      };
+      auto mma = [&](const u32x4& a, const u32x4 (&b)[NT]) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[t]), acc[t], 0, 0, 0);
+      };
+      const int nsteps = ntaps * (g.cin >> 4);
+      u32x4 a0, a1, a2, b0[NT], b1[NT], b2[NT];
+      fetch(a0, b0);
+      fetch(a1, b1);
+      for (int i = 0; i < nsteps; i += 3) {
+        fetch(a2, b2);               // past the end: zeros (tap >= ntaps)
+        mma(a0, b0);
+        fetch(a0, b0);
+        if (i + 1 < nsteps) mma(a1, b1);
+        fetch(a1, b1);
+        if (i + 2 < nsteps) mma(a2, b2);
+      }
+    }
+  } else if (VEC) {
     // Flattened (tap, 8-channel block) reduction, software pipelined: the operands of step i+1 are in flight while
     // step i is multiplied (one A load of 16 bytes + 4*NT kernel words per step, double buffered in registers).
     const int ntaps = g.kh * g.kw;
@@ -1662,6 +1722,36 @@ __global__ __launch_bounds__(256) void conv_wt_rot_batch_kernel(const RotEntry* 
   }
 }
 
+// bfloat16 kernel packs of every table entry: fpack[tap][co][ci] and rpack[ntaps-1-tap][ci][co] = bf16(w[tap][ci][co])
+__global__ __launch_bounds__(256) void conv_pack_bf16_batch_kernel(const RotEntry* __restrict__ table, const float* __restrict__ theta,
+                                                                   bf16* __restrict__ fpack, bf16* __restrict__ rpack) {
+  const RotEntry en = table[blockIdx.y];
+  const float* w = theta + en.offset;
+  const int per_tap = en.cin * en.cout, ntaps = en.kh * en.kw;
+  const int total = ntaps * per_tap;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+    const int tap = e / per_tap;
+    const int rem = e - tap * per_tap;
+    const int ci = rem / en.cout, co = rem - ci * en.cout;
+    const bf16 v = (bf16)w[e];
+    // a layer's pack starts at element 2 * offset of the pack array: byte offset 4 * offset, 16-byte aligned like theta's segments
+    if (fpack) fpack[2 * en.offset + (int64_t)(tap * en.cout + co) * en.cin + ci] = v;
+    if (rpack) rpack[2 * en.offset + (int64_t)(ntaps - 1 - tap) * per_tap + rem] = v;
+  }
+}
+
+// Which passes of a bfloat16 layer run on the bfloat16 matrix instructions when the packs are there.  Forward: input
+// channels in whole 16-blocks (16-byte operand loads) and more than 16 output channels (narrower outputs stay on the
+// 16-wide register / LDS kernels).  Data gradient: stride 1, same-size output, the mirror conditions.
+static bool fwd_pack_ok(const Geo& g) {
+  static const bool off = getenv("SSMI_NO_BF16_MFMA") != nullptr;
+  return !off && g.cin % 16 == 0 && g.x_ld % 8 == 0 && g.cout > 16;      // cin % 16 == 0 implies the VEC instantiation
+}
+static bool dgrad_pack_ok(const Geo& g) {
+  static const bool off = getenv("SSMI_NO_BF16_MFMA") != nullptr;
+  return !off && g.stride == 1 && g.ho == g.h && g.wo == g.w && g.cout % 16 == 0 && g.y_ld % 8 == 0 && g.cin > 16;
+}
+
 static ssmi_status check_desc(const ssmi_conv_desc* d) {
   SSMI_REQUIRE(d != nullptr, SSMI_E_INVALID_ARG, "conv desc is NULL");
   SSMI_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cin > 0 && d->ho > 0 && d->wo > 0 && d->cout > 0, SSMI_E_SHAPE,
@@ -1878,13 +1968,19 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
   ProfileScope prof(st, conv_bytes(g, bn.add != nullptr, sizeof(T)), conv_flops(g));
+  bn.wpack = nullptr;
+  if (sizeof(T) == 2 && g.wfp && fwd_pack_ok(g) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(g.wfp) & 15) == 0) {
+    bn.wpack = g.wfp;
+    direct_only = true;
+  }
   if (!direct_only && launch_gemm_lds<T>(g, sz, 0, x, w, bias, (const T*)nullptr, y, st, &e, part, part_rows, bn)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
-  set_last_kernel("conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
+  set_last_kernel(bn.wpack ? "conv_fwd_kernel<%d, %s> bf16 mfma" : "conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
 #define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<T, NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn)
   if (vec) {
     if (nt == 1) L(1, true); else if (nt == 2) L(2, true); else L(4, true);
@@ -1993,6 +2089,19 @@ static ssmi_status launch_bwd_data(const Geo& g, const T* dy, const float* w, co
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  if (sizeof(T) == 2 && g.wrp && dgrad_pack_ok(g) && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(g.wrp) & 15) == 0) {
+    // bfloat16 matrix instructions: forward convolution over dy with the data-gradient pack [tap'][ci][co]
+    Geo f = g;
+    f.h = g.ho; f.w = g.wo; f.cin = g.cout; f.x_ld = g.y_ld;
+    f.ho = g.h; f.wo = g.w; f.cout = g.cin; f.y_ld = g.x_ld;
+    f.pad_t = (g.kh - 1) * g.dil - g.pad_t;
+    f.pad_l = (g.kw - 1) * g.dil - g.pad_l;
+    f.wfp = g.wrp;
+    f.wrp = nullptr;
+    bb.add = add;
+    return launch_fwd<T>(f, dy, w, bias, dx, st, nullptr, part_rows, bb, true);
+  }
   if ((w_rot && dgrad_as_fwd(g, true)) || (wt && dgrad_as_fwd(g))) {
     // forward convolution over dy with the rotated, transposed kernel matrix: n, (ho, wo, cout) -> (h, w, cin)
     if (w_rot && dgrad_as_fwd(g, true)) {
@@ -2444,6 +2553,23 @@ ssmi_status ssmi_conv2d_bwd_data_ws(const ssmi_conv_desc* d, const void* dy, con
     return launch_bwd_data<T>(to_geo(d), static_cast<const T*>(dy), w, static_cast<const T*>(add), nullptr, static_cast<T*>(dx),
                               as_stream(stream), BnBwdArgs{}, nullptr, need ? static_cast<float*>(ws) : nullptr);
   });
+}
+
+int32_t ssmi_conv2d_pack_usage(const ssmi_conv_desc* d) {
+  if (check_desc(d) != SSMI_OK || d->dtype != SSMI_BF16) return 0;
+  const Geo g = to_geo(d);
+  return (fwd_pack_ok(g) ? 1 : 0) | (dgrad_pack_ok(g) ? 2 : 0);
+}
+
+ssmi_status ssmi_conv_pack_weights_bf16(const ssmi_rot_entry* table, int32_t count, const float* theta, uint16_t* fwd_pack,
+                                        uint16_t* dgrad_pack, void* stream) {
+  SSMI_REQUIRE(table && theta && (fwd_pack || dgrad_pack) && count > 0 && count <= 65535, SSMI_E_INVALID_ARG,
+               "conv_pack_weights_bf16: bad argument");
+  hipLaunchKernelGGL(conv_pack_bf16_batch_kernel, dim3(16, (unsigned)count), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const RotEntry*>(table), theta, reinterpret_cast<bf16*>(fwd_pack),
+                     reinterpret_cast<bf16*>(dgrad_pack));
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
 }
 
 int32_t ssmi_conv2d_bwd_data_uses_rotated(const ssmi_conv_desc* d) {

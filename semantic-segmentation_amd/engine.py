@@ -161,6 +161,7 @@ class Conv:
         self.store = store
         self.desc = None
         self.ws_bytes = 0
+        self.pack_usage = 0       # bf16 storage: bit 0 / 1 = forward / data gradient can run from a bfloat16 kernel pack
         self.uses_rot = False     # the data gradient can use a pre-rotated kernel matrix (decided by the library in plan())
         self.wrot = None          # that matrix: a view of the network's rotated arena, refreshed once per step
 
@@ -188,6 +189,7 @@ class Conv:
                                 L.conv2d_bwd_data_workspace_bytes(C.byref(d)))
             self.bwd_data_ws_bytes = L.conv2d_bwd_data_workspace_bytes(C.byref(d))
             self.uses_rot = bool(L.conv2d_bwd_data_uses_rotated(C.byref(d)))
+            self.pack_usage = int(L.conv2d_pack_usage(C.byref(d))) if not os.environ.get("SSMI_NO_BF16_MFMA") else 0
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
             H, W = h * self.stride, w * self.stride
@@ -897,6 +899,47 @@ class GraphBase:
             cv.wrot = st.theta_rot[sp.offset:sp.offset + sp.size]
         self.rot_table = torch.from_numpy(tab.view(_np.uint8).copy()).to(dev)
 
+    def _plan_weight_packs(self, dev):
+        """bf16 storage: layers whose forward pass / data gradient can run on the bfloat16 matrix instructions read bfloat16
+        copies of their kernels (forward form [tap][cout][cin], data-gradient form [tap'][cin][cout]); both forms of all such
+        layers live in two bfloat16 arenas indexed like theta and are rewritten by ONE launch in front of every forward pass.
+        The descriptors carry the addresses, so the layers need no further arguments."""
+        import numpy as _np
+        st = self.store
+        self.pack_table = None
+        self.pack_count = 0
+        self.packed_layers = {}
+        if st.act_dtype != torch.bfloat16 or dev.type != "cuda":
+            return
+        rows = []
+        for b in self.blocks:
+            for cv in b.convs():
+                if cv.pack_usage and not cv.transpose and cv.desc is not None:
+                    rows.append((cv, st.specs[cv.name + "/kernel"]))
+        if not rows:
+            return
+        if getattr(st, "theta_fpack", None) is None or st.theta_fpack.numel() != 2 * st.theta.numel():
+            st.theta_fpack = torch.zeros(2 * st.theta.numel(), dtype=torch.bfloat16, device=dev)
+            st.theta_rpack = torch.zeros(2 * st.theta.numel(), dtype=torch.bfloat16, device=dev)
+        tab = _np.zeros(len(rows), dtype=_np.dtype([("offset", "<i8"), ("kh", "<i4"), ("kw", "<i4"), ("cin", "<i4"), ("cout", "<i4")]))
+        for i, (cv, sp) in enumerate(rows):
+            tab[i] = (sp.offset, cv.kh, cv.kw, cv.cin, cv.cout)
+            if cv.pack_usage & 1:       # a layer's pack sits at the byte offset its kernel has in theta (16-byte aligned)
+                cv.desc.w_fwd_pack = st.theta_fpack.data_ptr() + 4 * sp.offset
+            if cv.pack_usage & 2:
+                cv.desc.w_dgrad_pack = st.theta_rpack.data_ptr() + 4 * sp.offset
+            self.packed_layers[cv.name] = cv.pack_usage
+        self.pack_table = torch.from_numpy(tab.view(_np.uint8).copy()).to(dev)
+        self.pack_count = len(rows)
+
+    def pack_weights(self, stream=None):
+        """Refreshes the bfloat16 kernel packs from theta (bf16 storage only; one launch)."""
+        if getattr(self, "pack_table", None) is None:
+            return
+        st = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        lib().conv_pack_weights_bf16(_ptr(self.pack_table), self.pack_count, _ptr(self.store.theta), _ptr(self.store.theta_fpack),
+                                     _ptr(self.store.theta_rpack), st)
+
     def rotate_weights(self, stream=None):
         """Refreshes the rotated arena from theta; to be called once per training step before the backward pass."""
         if self.rot_table is None:
@@ -915,6 +958,7 @@ class GraphBase:
         L = lib()
         self._plan_blocks(n, h, w, dev)
         self._plan_rotated_weights(dev)
+        self._plan_weight_packs(dev)
         self.drop_arena, self.drop_groups, self.drop_views = plan_dropout_arena(self.drop_layers, n, dev)
         for b in self.blocks:
             b.bind_dropout(self.drop_views)
@@ -956,6 +1000,7 @@ class GraphBase:
             images = self._images_act
         main = torch.cuda.current_stream()
         st = stream if stream is not None else main.cuda_stream
+        self.pack_weights(st)       # bf16 storage: bfloat16 kernel packs of the weights this pass runs with
         side = self.side_stream if (self.overlap_weight_gradients and training and st == main.cuda_stream and st != 0) else None
         multi = side is not None and getattr(self, "side_streams", None)
         cfg = RunCfg(training, update_moving and training, unbiased_moving,
