@@ -237,11 +237,15 @@ def make_dropout_masks(model_name: str, batch: int, seed: int, dtype=np.float64)
 # --------------------------------------------------------------------------------------
 
 class _Ctx:
-    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect, forced=None, storage=None):
+    def __init__(self, params: Dict[str, torch.Tensor], training: bool, drop_masks, collect, forced=None, storage=None,
+                 bf16_weights=None):
         # storage == "bf16": every tensor the device implementation keeps in memory between kernels (convolution outputs,
         # activated outputs, block outputs, logits) and every stored gradient is rounded to bfloat16 at that point, the
         # arithmetic in between stays in this evaluation's own precision
         self.storage = storage
+        # names of convolution layers whose kernel enters the convolution (forward and data gradient) rounded to bfloat16,
+        # as on the bfloat16 matrix instructions; the kernel's own gradient is that of the unrounded kernel
+        self.bf16_weights = set(bf16_weights or ())
         self.unrounded = {}
         self.p = params
         self.training = training
@@ -261,7 +265,10 @@ class _Ctx:
         return t
 
     def conv(self, name, x, stride=1, dil=1, padding="same"):
-        y = K.conv2d(x, self.p[name + "/kernel"], self.p.get(name + "/bias"), stride, dil, padding)
+        kernel = self.p[name + "/kernel"]
+        if name in self.bf16_weights:
+            kernel = K.round_bf16(kernel, fwd=True, bwd=False)
+        y = K.conv2d(x, kernel, self.p.get(name + "/bias"), stride, dil, padding)
         if self.storage == "bf16":
             # the stored tensor is rounded, but a BatchNormalization that consumes it takes its batch statistics from the
             # convolution's unrounded accumulators (column sums in the kernel epilogue); the gradient of both uses meets in
@@ -357,7 +364,7 @@ def classifier_head(c, x):
 
 
 def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch.Tensor, training: bool = True,
-                 drop_masks=None, collect: bool = False, forced=None, storage=None):
+                 drop_masks=None, collect: bool = False, forced=None, storage=None, bf16_weights=None):
     """Returns (logits, ctx) where ctx.bn_stats holds batch (mean, biased var) per BN layer and
     ctx.acts the named intermediate tensors when collect=True."""
     model_name, encoder_only = split_name(model_name)
@@ -368,7 +375,7 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
                "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)
     if variant is None:
         raise ValueError("Unknown model name: {}".format(model_name))
-    c = _Ctx(params, training, drop_masks, collect, forced, storage)
+    c = _Ctx(params, training, drop_masks, collect, forced, storage, bf16_weights)
     idx_stack = []
     images = c.q(images, bwd=False)
     conv = c.conv("initial_block_conv2d", images, stride=2)
@@ -433,7 +440,7 @@ def block_table(model_name: str) -> "OrderedDict[str, tuple]":
 
 
 def block_step(model_name: str, weights, block: str, x: np.ndarray, dout: np.ndarray, drop_masks=None, forced=None,
-               storage: Optional[str] = None, unpool_idx: Optional[np.ndarray] = None, dtype=torch.float64):
+               storage: Optional[str] = None, unpool_idx: Optional[np.ndarray] = None, dtype=torch.float64, bf16_weights=None):
     """ONE block of the network evaluated on its own: forward from the given input `x` (training phase), then the
     vector-Jacobian product with the given output gradient `dout`.  `block`: a bottleneck name, "initial_block" (x = images)
     or "head" (everything after de_bn_5.1; dout = gradient of the logits).  Used to check an implementation layer by layer
@@ -448,7 +455,7 @@ def block_step(model_name: str, weights, block: str, x: np.ndarray, dout: np.nda
         params[k].requires_grad_(True)
     masks = {k: torch.tensor(v, dtype=dtype) for k, v in (drop_masks or {}).items()}
     fz = {k: torch.as_tensor(np.asarray(v)).to(torch.int64 if k.endswith("/argmax") else dtype) for k, v in (forced or {}).items()}
-    c = _Ctx(params, True, masks, False, fz, storage)
+    c = _Ctx(params, True, masks, False, fz, storage, bf16_weights)
     xt = torch.tensor(np.asarray(x), dtype=dtype, requires_grad=block != "initial_block")
     if block == "initial_block":
         conv = c.conv("initial_block_conv2d", xt, stride=2)
@@ -490,7 +497,7 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
                pixel_weights: np.ndarray, drop_masks=None, dtype=torch.float64, collect=False,
                adam: Optional[dict] = None, adam_state: Optional[dict] = None, ignore_classes=(0,),
                mean_teacher: Optional[dict] = None, superpixel: Optional[dict] = None, classification: bool = False,
-               forced: Optional[dict] = None, storage: Optional[str] = None):
+               forced: Optional[dict] = None, storage: Optional[str] = None, bf16_weights=None):
     """One supervised training step exactly as the reference assembles it
     (src/trainers.py:2436-2440: total = 1*loss + 0*mean(0*logits)):
     forward (training phase) -> weighted CE -> gradients -> BN moving-average updates -> optional Adam.
@@ -508,7 +515,7 @@ def train_step(model_name: str, weights: "OrderedDict[str, np.ndarray]", images:
     fz = None
     if forced:
         fz = {k: torch.as_tensor(np.asarray(v)).to(torch.int64 if k.endswith("/argmax") else dtype) for k, v in forced.items()}
-    logits, ctx = enet_forward(model_name, params, x, True, masks, collect, fz, storage)
+    logits, ctx = enet_forward(model_name, params, x, True, masks, collect, fz, storage, bf16_weights)
     if classification:      # labels / pixel_weights are [B, classes] float arrays (src/losses.py:636-652)
         lab = torch.tensor(labels, dtype=dtype)
         w = torch.tensor(pixel_weights, dtype=dtype)

@@ -264,6 +264,74 @@ def test_pool_and_loss_bf16():
         assert np.array_equal(b[2].cpu().numpy(), K.confusion_matrix_np(labels, logits, C_, [0]))
 
 
+PACKED_CASES = [  # kh, kw, cin, cout, stride, dil, padding, N, H, W
+    (1, 1, 128, 32, 1, 1, "valid", 2, 12, 20), (3, 3, 32, 32, 1, 1, "same", 2, 9, 13), (3, 3, 32, 32, 1, 4, "same", 1, 16, 16),
+    (5, 1, 32, 32, 1, 1, "same", 2, 8, 8), (1, 5, 32, 32, 1, 1, "same", 1, 7, 24), (1, 1, 32, 128, 1, 1, "valid", 2, 10, 10),
+    (2, 2, 64, 32, 2, 1, "valid", 2, 12, 16), (3, 3, 64, 64, 1, 1, "same", 1, 12, 12), (1, 1, 48, 80, 1, 1, "valid", 1, 6, 10),
+]
+
+
+@pytest.mark.parametrize("case", PACKED_CASES, ids=lambda c: "k{}x{}_{}to{}_s{}_d{}_{}".format(*c[:7]))
+def test_conv2d_bf16_matrix_instruction_path(case):
+    """Forward and data gradient from bfloat16 kernel packs (v_mfma_f32_32x32x16_bf16) against the float32-MFMA kernels run
+    on the same bfloat16 activations with the kernel ROUNDED to bfloat16: the products are the same numbers, only the
+    summation order differs (float32 accumulation both ways), so after the bfloat16 store all but a few results are
+    identical and the rest differ by one bfloat16 ulp.  Fused BatchNormalization statistics: rtol 1e-5."""
+    eng, L0 = pkg("engine"), pkg("_lib")
+    kh, kw, cin, cout, s, d, pad, N, H, W = case
+    rng = np.random.RandomState(kh * 100 + cin + cout + d)
+    x = _bf(rng.standard_normal((N, H, W, cin)))
+    w = rng.standard_normal((kh, kw, cin, cout)).astype(np.float32) * np.sqrt(2.0 / (kh * kw * cin))
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for packed in (False, True):
+        store = eng.ParamStore(torch.bfloat16)
+        cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=s, dil=d, padding=pad, bias=True)
+        bn = eng.BatchNorm(store, "bn", cout)
+        store.materialise(torch.device(DEV))
+        store.init_values(1)
+        ho, wo = cv.plan(N, H, W)
+        bn.plan(torch.device(DEV))
+        store.views["c/kernel"].copy_(torch.from_numpy(w if packed else _bf(w)))
+        store.views["c/bias"].copy_(torch.from_numpy(b))
+        usage = int(store.L.conv2d_pack_usage(cv._dref))
+        keep = []
+        if packed:
+            assert usage & 1, "the library does not take this layer to the bfloat16 matrix instructions"
+            sp = store.specs["c/kernel"]
+            fp = torch.zeros(2 * store.theta.numel(), dtype=torch.bfloat16, device=DEV)
+            rp = torch.zeros_like(fp)
+            tab = np.zeros(1, dtype=np.dtype([("offset", "<i8"), ("kh", "<i4"), ("kw", "<i4"), ("cin", "<i4"), ("cout", "<i4")]))
+            tab[0] = (sp.offset, kh, kw, cin, cout)
+            tabd = torch.from_numpy(tab.view(np.uint8).copy()).to(DEV)
+            L0.lib().conv_pack_weights_bf16(tabd.data_ptr(), 1, store.theta.data_ptr(), fp.data_ptr(), rp.data_ptr(), st)
+            cv.desc.w_fwd_pack = fp.data_ptr() + 4 * sp.offset
+            if usage & 2:
+                cv.desc.w_dgrad_pack = rp.data_ptr() + 4 * sp.offset
+            keep = [fp, rp, tabd]
+        xd = _dev(x, torch.bfloat16)
+        y = torch.empty(N, ho, wo, cout, dtype=torch.bfloat16, device=DEV)
+        ws = torch.empty(cv.ws_bytes // 4 + 64, device=DEV)
+        cv.fwd_bn(xd, y, bn, N * ho * wo, True, False, False, ws, st)
+        dy = _dev(_bf(np.random.RandomState(7).standard_normal((N, ho, wo, cout))), torch.bfloat16)
+        dx = torch.empty(N, H, W, cin, dtype=torch.bfloat16, device=DEV)
+        cv.bwd_data(dy, dx, st)
+        torch.cuda.synchronize()
+        outs[packed] = (y.float().cpu().numpy(), bn.mean.cpu().numpy().copy(), bn.invstd.cpu().numpy().copy(),
+                        dx.float().cpu().numpy(), usage)
+        del keep
+    ref, got = outs[False], outs[True]
+    for what, a, r_ in (("forward", got[0], ref[0]),) + ((("data gradient", got[3], ref[3]),) if got[4] & 2 else ()):
+        diff = np.abs(a - r_)
+        ulp = np.maximum(np.abs(r_), 1e-30) * 2.0 ** -7          # one bfloat16 step is at most 2^-7 of the value
+        scale = np.abs(r_).max()
+        assert np.all(diff <= ulp + 2.0 ** -8 * 1e-2 * scale), "{}: max deviation {:.3e} on scale {:.3e}".format(what, diff.max(), scale)
+        assert (diff > 0).mean() <= 2e-2, "{}: {:.2%} of the results differ".format(what, (diff > 0).mean())
+    np.testing.assert_allclose(got[1], ref[1], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[2], ref[2], rtol=1e-5)
+
+
 def _compiled(name, w0, lr=5e-4, dtype="bf16"):
     models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
     m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY,
@@ -309,7 +377,10 @@ def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed):
     hip_logits = g.logits.float().cpu().numpy()
     # --- whole network, quantities that survive compounding --------------------------------------------------------------
     ref = E.train_step(name, w0, images, labels, pw, masks)                       # exact storage, the oracle's own branches
-    refq = E.train_step(name, w0, images, labels, pw, masks, storage="bf16")      # same arithmetic, bfloat16 storage
+    # layers that run on the bfloat16 matrix instructions multiply bfloat16-rounded kernels: the oracle does the same
+    bfw = {k for k, u in g.packed_layers.items() if u & 1}
+    assert bfw, "no layer took the bfloat16 matrix-instruction path"
+    refq = E.train_step(name, w0, images, labels, pw, masks, storage="bf16", bf16_weights=bfw)   # same arithmetic and storage
     # the loss is a mean over all pixels: storage rounding averages out of it even where single logits moved
     assert abs(outs[0] - ref["loss"]) <= 2e-2 * abs(ref["loss"]), (outs[0], ref["loss"])
     # the kernels' distance to exact storage is the distance ANY evaluation with bfloat16 storage has (here: the fp64
@@ -339,7 +410,7 @@ def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed):
         dout = g.dlogits if last else blocks[i + 1].dx
         ui = getattr(blk, "unpool_idx", None)
         r = E.block_step(name, w0, bname, _np(x_in), _np(dout), masks, forced, "bf16",
-                         None if ui is None else ui.cpu().numpy().astype(np.int64))
+                         None if ui is None else ui.cpu().numpy().astype(np.int64), bf16_weights=bfw)
         note("out", _rel_l2(_np(blk.out), r["out"]), bname)
         if r["dx"] is not None:
             note("dx", _rel_l2(_np(blk.dx), r["dx"]), bname)
