@@ -129,17 +129,19 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_f
         for (int t = 0; t < NT; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[t]), acc[t], 0, 0, 0);
       };
+      // A step is ONE matrix instruction per column tile (32 cycles), far shorter than the memory round trip that feeds
+      // it: the loop is as fast as its loads in flight allow, so the operands of PD steps are fetched ahead.
       const int nsteps = ntaps * (g.cin >> 4);
-      u32x4 a0, a1, a2, b0[NT], b1[NT], b2[NT];
-      fetch(a0, b0);
-      fetch(a1, b1);
-      for (int i = 0; i < nsteps; i += 3) {
-        fetch(a2, b2);               // past the end: zeros (tap >= ntaps)
-        mma(a0, b0);
-        fetch(a0, b0);
-        if (i + 1 < nsteps) mma(a1, b1);
-        fetch(a1, b1);
-        if (i + 2 < nsteps) mma(a2, b2);
+      constexpr int PD = NT == 1 ? 6 : (NT == 2 ? 4 : 3);
+      u32x4 pa[PD], pb[PD][NT];
+#pragma unroll
+      for (int d = 0; d < PD; ++d) fetch(pa[d], pb[d]);
+      for (int i = 0; i < nsteps; i += PD) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+          if (i + d < nsteps) mma(pa[d], pb[d]);
+          fetch(pa[d], pb[d]);       // step i + d + PD; past the end: zeros (tap >= ntaps)
+        }
       }
     }
   } else if (VEC) {
