@@ -975,10 +975,12 @@ class GraphBase:
             else self.ws
         if self.side_stream is None and dev.type == "cuda" and self.overlap_weight_gradients:
             self.side_stream = torch.cuda.Stream(device=dev)
-        # Two weight-gradient streams, used by alternate blocks: a strip kernel keeps one latency-bound workgroup per CU,
-        # so two of them beside the data-gradient chain fill the chip better than one (ENet 512x512 batch 16: 10.92 ms with
-        # one stream, 10.38 with two, 11.1 with three).  SSMI_WGRAD_STREAMS overrides for measurements.
-        nside = int(os.environ.get("SSMI_WGRAD_STREAMS", "2"))
+        # Several weight-gradient streams, used by the blocks in turn: a strip kernel keeps one latency-bound workgroup per CU,
+        # so a few of them beside the data-gradient chain fill the chip better than one.  Measured (ENet 512x512 batch 16,
+        # float32 / bf16 storage, ms per step): 1 stream 10.41 / 9.22, 2: 9.84 / 8.46, 3: 10.42 / 9.15, 4: 9.72 / 8.30,
+        # 5: 10.19 / 8.82, 6: 9.80 / 8.38, 8: 9.73 / 8.30 - odd counts put the two heavy layers of consecutive blocks on the
+        # same stream.  SSMI_WGRAD_STREAMS overrides for measurements.
+        nside = int(os.environ.get("SSMI_WGRAD_STREAMS", "4"))
         self.side_streams = self.side_wss = None
         if nside > 1 and self.side_stream is not None:
             self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=dev) for _ in range(nside - 1)]
