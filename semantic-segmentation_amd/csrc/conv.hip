@@ -2361,6 +2361,8 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
       break;
     }
   }
+  static const bool force_direct = getenv("SSMI_WG_DIRECT") != nullptr;      // A/B switch: operands straight from global memory
+  if (force_direct) p.use_lds = false;
   if (!p.use_lds && p.m16) {   // the direct kernel only has 32x32 tiles
     p.m16 = false;
     tiles(32);
