@@ -553,6 +553,23 @@ ssmi_status ssmi_graph_end_capture(void* stream, ssmi_graph** out);
 ssmi_status ssmi_graph_launch(ssmi_graph* g, void* stream);
 ssmi_status ssmi_graph_destroy(ssmi_graph* g);
 
+/* ----------------------------------------------------------------------------------------------------
+ * Collectives of the data-parallel step (src/trainers.py trains on ONE device; this is the exchange step of the one-process-
+ * per-GPU trainer: gradient buckets summed over the ranks, int64 confusion matrices summed for sharded evaluation,
+ * parameters broadcast from rank 0).  A thin layer over RCCL, looked up with dlopen at the first call (the process's own
+ * copy is reused).  Rank 0 calls ssmi_comm_unique_id and hands the 128 bytes to the other ranks by any channel; every rank
+ * then calls ssmi_comm_init with its device current.  The collectives are in place and asynchronous on `stream`.
+ * ---------------------------------------------------------------------------------------------------- */
+typedef struct ssmi_comm ssmi_comm;
+ssmi_status ssmi_comm_unique_id(char id[128]);
+ssmi_status ssmi_comm_init(const char id[128], int32_t rank, int32_t nranks, ssmi_comm** out);
+ssmi_status ssmi_comm_destroy(ssmi_comm* comm);
+int32_t ssmi_comm_size(const ssmi_comm* comm);
+int32_t ssmi_comm_rank(const ssmi_comm* comm);
+ssmi_status ssmi_comm_allreduce_sum_f32(ssmi_comm* comm, float* buf, int64_t count, void* stream);
+ssmi_status ssmi_comm_allreduce_sum_i64(ssmi_comm* comm, int64_t* buf, int64_t count, void* stream);
+ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, int32_t root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,14 @@ _PROTOS = {
                                                _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_bwd_data_rot": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ssmi_conv2d_bwd_data_uses_rotated": (_i32, [_PD]),
+    "ssmi_comm_unique_id": (_i32, [_vp]),
+    "ssmi_comm_init": (_i32, [_vp, _i32, _i32, _vp]),
+    "ssmi_comm_destroy": (_i32, [_vp]),
+    "ssmi_comm_size": (_i32, [_vp]),
+    "ssmi_comm_rank": (_i32, [_vp]),
+    "ssmi_comm_allreduce_sum_f32": (_i32, [_vp, _vp, _i64, _vp]),
+    "ssmi_comm_allreduce_sum_i64": (_i32, [_vp, _vp, _i64, _vp]),
+    "ssmi_comm_broadcast_f32": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "ssmi_conv_rotate_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "ssmi_conv_pack_weights_bf16": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     "ssmi_conv2d_pack_usage": (_i32, [_PD]),
@@ -135,7 +143,7 @@ _PROTOS["ssmi_cast_bf16_to_f32"] = (_i32, [_vp, _vp, _i64, _vp])
 F32, BF16 = 0, 1      # ssmi dtype codes of activation tensors
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 

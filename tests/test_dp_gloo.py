@@ -145,3 +145,40 @@ def test_two_gloo_ranks_share_the_gpu_and_finish_the_data_parallel_step():
     assert d["n_gpus"] == 2 and dp["rccl_ranks"] == 2 and dp["backend"] == "gloo" and dp["buckets_per_step"] == 2
     assert dp["bytes_reduced_per_step"] == sum(dp["bucket_bytes"]) and len(dp["segments_ms"]) == 2
     assert np.isfinite(d["config"]["final_loss"]) and d["value"] > 0
+
+
+@pytest.mark.gpu
+def test_c_abi_collectives_one_rank():
+    """ssmi_comm_* (RCCL behind the C ABI) with a communicator of one rank: sums and the broadcast are the identity, the
+    calls are stream-ordered with the kernels around them, the handle reports rank and size.  Run in a child process: the
+    communicator belongs to a process of its own, not to the test runner."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, sys, os
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch
+from conftest import pkg
+L = pkg("_lib").lib()
+uid = C.create_string_buffer(128)
+L.comm_unique_id(uid)
+comm = C.c_void_p()
+L.comm_init(uid, 0, 1, C.byref(comm))
+assert L.comm_size(comm) == 1 and L.comm_rank(comm) == 0
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    g = torch.arange(100000, dtype=torch.float32, device="cuda") * 0.5
+    ref = g.clone()
+    g.mul_(3.0)
+    L.comm_allreduce_sum_f32(comm, g.data_ptr(), g.numel(), s.cuda_stream)
+    g.add_(1.0)
+    cm = torch.arange(24 * 24, dtype=torch.int64, device="cuda")
+    L.comm_allreduce_sum_i64(comm, cm.data_ptr(), cm.numel(), s.cuda_stream)
+    L.comm_broadcast_f32(comm, g.data_ptr(), g.numel(), 0, s.cuda_stream)
+s.synchronize()
+assert torch.equal(g, ref * 3.0 + 1.0) and torch.equal(cm.cpu(), torch.arange(24 * 24))
+L.comm_destroy(comm)
+print("comm ok")
+''' % (ROOT, ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150, text=True)
+    assert r.returncode == 0 and "comm ok" in r.stdout, r.stderr[-3000:]
