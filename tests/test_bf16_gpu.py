@@ -1,4 +1,4 @@
-"""bfloat16 activation storage (BASELINE configuration "ENet 512x512 batch 16, fp32 and bf16 training").
+"""bfloat16 activation storage (the benchmark configuration names "ENet 512x512 batch 16, fp32 and bf16 training").
 
 Activations and their gradients live in HBM as bfloat16; kernels, statistics, optimizer state and every multiply-add are
 float32.  Three layers of checks:
@@ -8,7 +8,7 @@ float32.  Three layers of checks:
     (float32 outputs) must be identical.  That ties every bfloat16 kernel to its float32 twin, which tests/test_ops_gpu.py
     ties to the fp64 oracle at rtol 1e-3;
   * step level against the fp64 CPU oracle, BLOCK BY BLOCK on the kernels' own tensors: every block's output, input
-    gradient and parameter gradients within 2e-2 (relative L2 norm, the north star's bf16 tolerance) of the oracle's
+    gradient and parameter gradients within 2e-2 (relative L2 norm; 2e-2 is the tolerance this project states for bf16) of the oracle's
     evaluation of that block on the block input / output gradient the device stored, the oracle rounding to bfloat16 where
     the kernels store (oracle/enet_oracle.py block_step, storage="bf16") and following the PReLU / pooling branches the
     kernels took.  Whole-network tensors cannot carry that tolerance with this storage format, whoever computes them: a
