@@ -39,6 +39,7 @@ if os.environ.get("SSMI_WIDE"):        # the 3x3 layers of SegNet / U-Net at 512
               ("3x3 1024->512 @64", 3, 3, 1024, 512, 1, 1, "same", False, False, 64)]
 if os.environ.get("SSMI_SHAPES"):      # comma-separated indices into SHAPES
     SHAPES = [SHAPES[int(i)] for i in os.environ["SSMI_SHAPES"].split(",")]
+ADT = torch.bfloat16 if os.environ.get("SSMI_BENCH_DTYPE") == "bf16" else torch.float32      # activation storage type
 dev = torch.device("cuda")
 stream = torch.cuda.Stream()
 print("%-26s %10s %10s %10s   %8s %8s %8s   GB/s(fwd) TF(fwd) TF(wg)" % ("layer", "fwd us", "bwdD us", "bwdW us", "MB in", "MB out", "GFLOP"))
@@ -46,14 +47,14 @@ tot = [0, 0, 0]
 with torch.cuda.stream(stream):
     st = stream.cuda_stream
     for (label, kh, kw, cin, cout, s, d, pad, bias, tr, H) in SHAPES:
-        store = eng.ParamStore()
+        store = eng.ParamStore(ADT)
         cv = eng.Conv(store, "c", kh, kw, cin, cout, stride=s, dil=d, padding=pad, bias=bias, transpose=tr)
         store.materialise(dev)
         store.init_values(1)
         ho, wo = cv.plan(B, H, H)
-        x = torch.randn(B, H, H, cin, device=dev)
-        y = torch.empty(B, ho, wo, cout, device=dev)
-        dy = torch.randn_like(y)
+        x = torch.randn(B, H, H, cin, device=dev).to(ADT)
+        y = torch.empty(B, ho, wo, cout, device=dev, dtype=ADT)
+        dy = torch.randn(B, ho, wo, cout, device=dev).to(ADT)
         dx = torch.empty_like(x)
         ws = torch.empty(cv.ws_bytes // 4 + 16, device=dev)
         def t(fn, reps=20):
@@ -66,7 +67,7 @@ with torch.cuda.stream(stream):
         tf = t(lambda: cv.fwd(x, y, st))
         tb = t(lambda: cv.bwd_data(dy, dx, st))
         tw = t(lambda: cv.bwd_weight(x, dy, ws, st))
-        mb_in, mb_out = x.numel() * 4 / 1e6, y.numel() * 4 / 1e6
+        mb_in, mb_out = x.numel() * x.element_size() / 1e6, y.numel() * y.element_size() / 1e6
         macs = (y.numel() if not tr else x.numel() * cout) * kh * kw * cin
         gflop = 2 * macs / 1e9
         print("%-26s %10.1f %10.1f %10.1f   %8.1f %8.1f %8.2f   %8.0f %7.1f %7.1f" % (label, tf, tb, tw, mb_in, mb_out, gflop, (mb_in + mb_out) / tf * 1e3, gflop / tf * 1e3, gflop / tw * 1e3))

@@ -157,6 +157,11 @@ template <> struct Act<float> {
   static __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const void* p, unsigned bytes4) { return make_rsrc(p, bytes4); }
   static __device__ __forceinline__ float ld(__amdgpu_buffer_rsrc_t r, unsigned off4) { return bload(r, off4); }
   static __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off4) { return bload4(r, off4); }
+  // raw form of a 4-element load: what sits in registers while the load is in flight; up4() makes it float32 at the use.
+  // (Converting right behind the load makes the wave wait for the data there, which defeats every prefetch.)
+  typedef f32x4 raw4;
+  static __device__ __forceinline__ raw4 ld4r(__amdgpu_buffer_rsrc_t r, unsigned off4) { return bload4(r, off4); }
+  static __device__ __forceinline__ f32x4 up4(raw4 v) { return v; }
   static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned off4, float v) { bstore(r, off4, v); }
   // plain pointers (element index arithmetic done by the caller on T*)
   static __device__ __forceinline__ float gld(const float* p) { return *p; }
@@ -173,6 +178,11 @@ template <> struct Act<bf16> {
   static __device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off4) {
     return unpack_bf16x4(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off4 >> 1, 0, 0)));
   }
+  typedef u32x2 raw4;
+  static __device__ __forceinline__ raw4 ld4r(__amdgpu_buffer_rsrc_t r, unsigned off4) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off4 >> 1, 0, 0));
+  }
+  static __device__ __forceinline__ f32x4 up4(raw4 v) { return unpack_bf16x4(v); }
   static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned off4, float v) {
     const bf16 h = (bf16)v;
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, h), r, off4 >> 1, 0, 0);

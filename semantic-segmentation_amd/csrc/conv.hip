@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace ssmi {
 
@@ -1488,7 +1489,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
   const int nchunks = (row1 - row0) * cpr;
   const unsigned xpix = (unsigned)g.x_ld * 4u, ypix = (unsigned)g.y_ld * 4u;
 
-  f32x4 xr[kXvMax], yr[kYvMax];
+  // staged operands stay in their storage form while in flight (bf16: half the registers, and no conversion that would
+  // make the wave wait for the loads right here); commit() converts on the way into LDS
+  typename Act<T>::raw4 xr[kXvMax], yr[kYvMax];
+  float xs[kXvMax], ys[kYvMax];            // the scalar path (not VEC)
   auto prefetch = [&](int ch) {
     const bool cv = ch < nchunks;
     const int chs = cv ? ch : 0;
@@ -1497,23 +1501,55 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
     const int n_ = row / g.ho, oy = row % g.ho;
     const int iy0 = oy * g.stride - g.pad_t, ix0 = ox0 * g.stride - g.pad_l;
     const int pv = min(l.P, g.wo - ox0);
+    if constexpr (sizeof(T) == 2) {
+      // bf16: every offset first, then the loads back to back, and no branch around a load (the unused slots,
+      // i >= xv_n / yv_n, carry out-of-range coordinates and read nothing).  Interleaved and behind uniform branches,
+      // this instantiation reused a pending load's destination register for the next address and drained the memory
+      // counter in front of every load, so the loads of a chunk went out one round trip at a time.
+      unsigned xo[kXvMax], yo[kYvMax];
 #pragma unroll
-    for (int i = 0; i < kXvMax; ++i) {
-      if (i < l.xv_n) {
+      for (int i = 0; i < kXvMax; ++i) {
         const int iy = iy0 + x_kyd[i], ix = ix0 + x_colp[i];
-        const bool ok = cv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
-        const unsigned off = ok ? (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i] : kOOB;
-        if (VEC) xr[i] = Act<T>::ld4(rx, off);
-        else xr[i][0] = Act<T>::ld(rx, off);
+        const bool ok = cv & ((unsigned)iy < (unsigned)g.h) & ((unsigned)ix < (unsigned)g.w);
+        const unsigned off = (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i];
+        xo[i] = ok ? off : kOOB;
       }
-    }
 #pragma unroll
-    for (int i = 0; i < kYvMax; ++i) {
-      if (i < l.yv_n) {
-        const bool ok = cv && y_p[i] < pv;
-        const unsigned off = ok ? (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i] : kOOB;
-        if (VEC) yr[i] = Act<T>::ld4(ry, off);
-        else yr[i][0] = Act<T>::ld(ry, (ok && (y_rel[i] >> 2) < (unsigned)g.cout) ? off : kOOB);
+      for (int i = 0; i < kYvMax; ++i) {
+        const bool ok = cv & (y_p[i] < pv) & (VEC || (y_rel[i] >> 2) < (unsigned)g.cout);
+        const unsigned off = (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i];
+        yo[i] = ok ? off : kOOB;
+      }
+#pragma unroll
+      for (int i = 0; i < kXvMax; ++i) {
+        if (VEC) xr[i] = Act<T>::ld4r(rx, xo[i]);
+        else xs[i] = Act<T>::ld(rx, xo[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < kYvMax; ++i) {
+        if (VEC) yr[i] = Act<T>::ld4r(ry, yo[i]);
+        else ys[i] = Act<T>::ld(ry, yo[i]);
+      }
+    } else {
+      // fp32: the loads already leave back to back; skipping the unused slots measures faster than issuing them
+#pragma unroll
+      for (int i = 0; i < kXvMax; ++i) {
+        if (i < l.xv_n) {
+          const int iy = iy0 + x_kyd[i], ix = ix0 + x_colp[i];
+          const bool ok = cv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+          const unsigned off = ok ? (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i] : kOOB;
+          if (VEC) xr[i] = Act<T>::ld4r(rx, off);
+          else xs[i] = Act<T>::ld(rx, off);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kYvMax; ++i) {
+        if (i < l.yv_n) {
+          const bool ok = cv && y_p[i] < pv;
+          const unsigned off = ok ? (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i] : kOOB;
+          if (VEC) yr[i] = Act<T>::ld4r(ry, off);
+          else ys[i] = Act<T>::ld(ry, (ok && (y_rel[i] >> 2) < (unsigned)g.cout) ? off : kOOB);
+        }
       }
     }
   };
@@ -1525,8 +1561,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
       if (i < l.xv_n) {
         const int e = tid + i * 256;
         if (e < l.x_elems) {
-          if (VEC) *reinterpret_cast<f32x4*>(smem + e * 4) = xr[i];
-          else smem[e] = xr[i][0];
+          if (VEC) *reinterpret_cast<f32x4*>(smem + e * 4) = Act<T>::up4(xr[i]);
+          else smem[e] = xs[i];
         }
       }
     }
@@ -1536,8 +1572,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
         const int e = tid + i * 256;
         if (e < l.y_elems) {
           float* dst = smem + l.yl_off + y_p[i] * l.coutp + (y_rel[i] >> 2);
-          if (VEC) *reinterpret_cast<f32x4*>(dst) = yr[i];
-          else *dst = yr[i][0];
+          if (VEC) *reinterpret_cast<f32x4*>(dst) = Act<T>::up4(yr[i]);
+          else *dst = ys[i];
         }
       }
     }
@@ -1554,19 +1590,35 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
     if (has_tile) {
       const int steps = (pv + KQ - 1) / KQ;
       const float* yl = smem + l.yl_off + hh * l.coutp;
+      // four steps per round, all eight LDS reads of a round issued before its first MFMA (left to `#pragma unroll`
+      // the compiler kept one step per iteration: two reads, a full LDS wait, one MFMA)
+      auto run = [&](int st, auto u) {
+        constexpr int U = decltype(u)::value;
+        float av[U][TPW], bv[U][TPW];
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            av[q][j] = smem[abase[j] + (st + q) * astr[j]];
+            bv[q][j] = yl[(st + q) * KQ * l.coutp + col[j]];
+          }
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][j], bv[q][j], acc[j], 0, 0, 0);
+            else acc[j] = MFMA32(av[q][j], bv[q][j], acc[j]);
+          }
+      };
+      if constexpr (sizeof(T) == 2) {
+        constexpr int U = TPW == 1 ? 4 : 2;
+        int st = 0;
+        for (; st + U <= steps; st += U) run(st, std::integral_constant<int, U>{});
+        for (; st < steps; ++st) run(st, std::integral_constant<int, 1>{});
+      } else {
+        // fp32 measures faster one step at a time: the unrolled body costs it 20-30 registers
 #pragma unroll 4
-      for (int st = 0; st < steps; ++st) {
-        float av[TPW], bv[TPW];
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          av[j] = smem[abase[j] + st * astr[j]];
-          bv[j] = yl[st * KQ * l.coutp + col[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          if constexpr (M16) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[j], 0, 0, 0);
-          else acc[j] = MFMA32(av[j], bv[j], acc[j]);
-        }
+        for (int st = 0; st < steps; ++st) run(st, std::integral_constant<int, 1>{});
       }
     }
   }
