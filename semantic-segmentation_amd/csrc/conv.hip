@@ -1397,7 +1397,10 @@ static constexpr int kXvMax = 12, kYvMax = 8;
 
 // M16: 16x16 output tiles on v_mfma_f32_16x16x4_f32 (4 pixels per step) for cout <= 16, where 32-wide tiles would
 // spend half or more of the matrix core on padding columns.
-template <typename T, int TPW, bool VEC, bool M16>
+// XV / YV: staging slots per thread that this instantiation carries (>= xv_n / yv_n of the launch).  The slots cost
+// registers whether a layer fills them or not, and these launches share the SIMDs with the data-gradient chain of the
+// main stream, so the launcher picks the smallest class that fits the layer.
+template <typename T, int TPW, bool VEC, bool M16, int XV, int YV>
 __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgArgs a, WgLds l, const T* __restrict__ x,
                                                            const T* __restrict__ dy, float* __restrict__ part) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1442,43 +1445,42 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
 #pragma unroll
     for (int i = 0; i < NR; ++i) acc[j][i] = 0.f;
 
-  // ---- per-thread staging maps (independent of the chunk) ----
-  // x patch element e -> (ky, colp, c): LDS word = e*EW; global = row(ky) + colp*x_ld + c
-  int x_kyd[kXvMax], x_colp[kXvMax];
-  unsigned x_rel[kXvMax];
+  // ---- per-thread staging maps (independent of the chunk), one packed word per slot ----
+  // x patch element e -> (ky, colp, c): LDS word = e*EW; global = row(ky) + colp*x_ld + c.
+  // xm = [31] unused | [30:23] ky*dil | [22:12] colp | [11:0] c     ym = [31] unused | [19:12] pixel | [11:0] c
+  unsigned xm[XV], ym[YV];
   const int cin_e = g.cin / EW;   // elements per pixel (VEC requires cin % 4 == 0)
 #pragma unroll
-  for (int i = 0; i < kXvMax; ++i) {
-    x_colp[i] = 0;
-    x_kyd[i] = -(1 << 28);   // always out of range -> loads nothing
-    x_rel[i] = 0u;
+  for (int i = 0; i < XV; ++i) {
+    xm[i] = 0x80000000u;
     if (i < l.xv_n) {        // uniform: the unused slots cost no divisions
       const unsigned e = (unsigned)(tid + i * 256);
       if (e < (unsigned)l.x_elems) {
         const unsigned t = e / (unsigned)cin_e;
         const unsigned ky = t / (unsigned)l.Wp;
-        x_rel[i] = (e - t * (unsigned)cin_e) * (unsigned)EW * 4u;
-        x_colp[i] = (int)(t - ky * (unsigned)l.Wp);
-        x_kyd[i] = (int)ky * g.dil;
+        xm[i] = ((ky * (unsigned)g.dil) << 23) | ((t - ky * (unsigned)l.Wp) << 12) | ((e - t * (unsigned)cin_e) * (unsigned)EW);
       }
     }
   }
-  int y_p[kYvMax];
-  unsigned y_rel[kYvMax];
   const int cout_e = (g.cout + EW - 1) / EW;
 #pragma unroll
-  for (int i = 0; i < kYvMax; ++i) {
-    y_p[i] = 1 << 28;
-    y_rel[i] = 0u;
+  for (int i = 0; i < YV; ++i) {
+    ym[i] = 0x80000000u;
     if (i < l.yv_n) {
       const unsigned e = (unsigned)(tid + i * 256);
       if (e < (unsigned)l.y_elems) {
         const unsigned q = e / (unsigned)cout_e;
-        y_p[i] = (int)q;
-        y_rel[i] = (e - q * (unsigned)cout_e) * (unsigned)EW * 4u;
+        ym[i] = (q << 12) | ((e - q * (unsigned)cout_e) * (unsigned)EW);
       }
     }
   }
+  auto x_kyd = [&](int i) { return (int)((xm[i] >> 23) & 0xFFu); };
+  auto x_colp = [&](int i) { return (int)((xm[i] >> 12) & 0x7FFu); };
+  auto x_rel = [&](int i) { return (xm[i] & 0xFFFu) * 4u; };       // byte offset of the channel inside the pixel
+  auto x_ok = [&](int i) { return (int)xm[i] >= 0; };
+  auto y_p = [&](int i) { return (int)((ym[i] >> 12) & 0xFFu); };
+  auto y_rel = [&](int i) { return (ym[i] & 0xFFFu) * 4u; };
+  auto y_ok = [&](int i) { return (int)ym[i] >= 0; };
   // zero the whole block once (pad columns of the dy chunk, the zero word)
   for (int i = tid; i < l.lds_words; i += 256) smem[i] = 0.f;
 
@@ -1491,8 +1493,8 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
 
   // staged operands stay in their storage form while in flight (bf16: half the registers, and no conversion that would
   // make the wave wait for the loads right here); commit() converts on the way into LDS
-  typename Act<T>::raw4 xr[kXvMax], yr[kYvMax];
-  float xs[kXvMax], ys[kYvMax];            // the scalar path (not VEC)
+  typename Act<T>::raw4 xr[VEC ? XV : 1], yr[VEC ? YV : 1];
+  float xs[VEC ? 1 : XV], ys[VEC ? 1 : YV];            // the scalar path (not VEC)
   auto prefetch = [&](int ch) {
     const bool cv = ch < nchunks;
     const int chs = cv ? ch : 0;
@@ -1502,53 +1504,53 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
     const int iy0 = oy * g.stride - g.pad_t, ix0 = ox0 * g.stride - g.pad_l;
     const int pv = min(l.P, g.wo - ox0);
     if constexpr (sizeof(T) == 2) {
-      // bf16: every offset first, then the loads back to back, and no branch around a load (the unused slots,
-      // i >= xv_n / yv_n, carry out-of-range coordinates and read nothing).  Interleaved and behind uniform branches,
-      // this instantiation reused a pending load's destination register for the next address and drained the memory
-      // counter in front of every load, so the loads of a chunk went out one round trip at a time.
-      unsigned xo[kXvMax], yo[kYvMax];
+      // bf16: every offset first, then the loads back to back, and no branch around a load (the unused slots read
+      // nothing).  Interleaved and behind uniform branches, this instantiation reused a pending load's destination
+      // register for the next address and drained the memory counter in front of every load, so the loads of a chunk
+      // went out one round trip at a time.
+      unsigned xo[XV], yo[YV];
 #pragma unroll
-      for (int i = 0; i < kXvMax; ++i) {
-        const int iy = iy0 + x_kyd[i], ix = ix0 + x_colp[i];
-        const bool ok = cv & ((unsigned)iy < (unsigned)g.h) & ((unsigned)ix < (unsigned)g.w);
-        const unsigned off = (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i];
+      for (int i = 0; i < XV; ++i) {
+        const int iy = iy0 + x_kyd(i), ix = ix0 + x_colp(i);
+        const bool ok = cv & x_ok(i) & ((unsigned)iy < (unsigned)g.h) & ((unsigned)ix < (unsigned)g.w);
+        const unsigned off = (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel(i);
         xo[i] = ok ? off : kOOB;
       }
 #pragma unroll
-      for (int i = 0; i < kYvMax; ++i) {
-        const bool ok = cv & (y_p[i] < pv) & (VEC || (y_rel[i] >> 2) < (unsigned)g.cout);
-        const unsigned off = (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i];
+      for (int i = 0; i < YV; ++i) {
+        const bool ok = cv & y_ok(i) & (y_p(i) < pv) & (VEC || (y_rel(i) >> 2) < (unsigned)g.cout);
+        const unsigned off = (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p(i)) * ypix + y_rel(i);
         yo[i] = ok ? off : kOOB;
       }
 #pragma unroll
-      for (int i = 0; i < kXvMax; ++i) {
-        if (VEC) xr[i] = Act<T>::ld4r(rx, xo[i]);
+      for (int i = 0; i < XV; ++i) {
+        if constexpr (VEC) xr[i] = Act<T>::ld4r(rx, xo[i]);
         else xs[i] = Act<T>::ld(rx, xo[i]);
       }
 #pragma unroll
-      for (int i = 0; i < kYvMax; ++i) {
-        if (VEC) yr[i] = Act<T>::ld4r(ry, yo[i]);
+      for (int i = 0; i < YV; ++i) {
+        if constexpr (VEC) yr[i] = Act<T>::ld4r(ry, yo[i]);
         else ys[i] = Act<T>::ld(ry, yo[i]);
       }
     } else {
       // fp32: the loads already leave back to back; skipping the unused slots measures faster than issuing them
 #pragma unroll
-      for (int i = 0; i < kXvMax; ++i) {
+      for (int i = 0; i < XV; ++i) {
         if (i < l.xv_n) {
-          const int iy = iy0 + x_kyd[i], ix = ix0 + x_colp[i];
-          const bool ok = cv && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
-          const unsigned off = ok ? (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel[i] : kOOB;
-          if (VEC) xr[i] = Act<T>::ld4r(rx, off);
+          const int iy = iy0 + x_kyd(i), ix = ix0 + x_colp(i);
+          const bool ok = cv && x_ok(i) && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+          const unsigned off = ok ? (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + x_rel(i) : kOOB;
+          if constexpr (VEC) xr[i] = Act<T>::ld4r(rx, off);
           else xs[i] = Act<T>::ld(rx, off);
         }
       }
 #pragma unroll
-      for (int i = 0; i < kYvMax; ++i) {
+      for (int i = 0; i < YV; ++i) {
         if (i < l.yv_n) {
-          const bool ok = cv && y_p[i] < pv;
-          const unsigned off = ok ? (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p[i]) * ypix + y_rel[i] : kOOB;
-          if (VEC) yr[i] = Act<T>::ld4r(ry, off);
-          else ys[i] = Act<T>::ld(ry, (ok && (y_rel[i] >> 2) < (unsigned)g.cout) ? off : kOOB);
+          const bool ok = cv && y_ok(i) && y_p(i) < pv && (VEC || (y_rel(i) >> 2) < (unsigned)g.cout);
+          const unsigned off = ok ? (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + y_p(i)) * ypix + y_rel(i) : kOOB;
+          if constexpr (VEC) yr[i] = Act<T>::ld4r(ry, off);
+          else ys[i] = Act<T>::ld(ry, off);
         }
       }
     }
@@ -1557,22 +1559,22 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
     const int ox0 = (ch % cpr) * l.P;
     const int pv = min(l.P, g.wo - ox0);
 #pragma unroll
-    for (int i = 0; i < kXvMax; ++i) {
+    for (int i = 0; i < XV; ++i) {
       if (i < l.xv_n) {
         const int e = tid + i * 256;
         if (e < l.x_elems) {
-          if (VEC) *reinterpret_cast<f32x4*>(smem + e * 4) = Act<T>::up4(xr[i]);
+          if constexpr (VEC) *reinterpret_cast<f32x4*>(smem + e * 4) = Act<T>::up4(xr[i]);
           else smem[e] = xs[i];
         }
       }
     }
 #pragma unroll
-    for (int i = 0; i < kYvMax; ++i) {
+    for (int i = 0; i < YV; ++i) {
       if (i < l.yv_n) {
         const int e = tid + i * 256;
         if (e < l.y_elems) {
-          float* dst = smem + l.yl_off + y_p[i] * l.coutp + (y_rel[i] >> 2);
-          if (VEC) *reinterpret_cast<f32x4*>(dst) = Act<T>::up4(yr[i]);
+          float* dst = smem + l.yl_off + y_p(i) * l.coutp + (y_rel(i) >> 2);
+          if constexpr (VEC) *reinterpret_cast<f32x4*>(dst) = Act<T>::up4(yr[i]);
           else *dst = ys[i];
         }
       }
@@ -2408,7 +2410,9 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
     l.zero_off = xw + ((P + 3) & ~3);
     l.yl_off = l.zero_off + 4;
     l.lds_words = l.yl_off + P * l.coutp;
-    if (l.xv_n <= kXvMax && l.yv_n <= kYvMax && l.lds_words * 4 <= 64 * 1024) {
+    // (the last three bounds are the field widths of the packed staging maps)
+    if (l.xv_n <= kXvMax && l.yv_n <= kYvMax && l.lds_words * 4 <= 64 * 1024 && g.cin <= 4096 && g.cout <= 4096 &&
+        l.Wp < 2048 && (g.kh - 1) * g.dil < 256) {
       p.use_lds = true;
       break;
     }
@@ -2476,12 +2480,17 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
   dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
   if (p.use_lds) {
     const size_t lds = (size_t)p.l.lds_words * 4;
-#define LL(TPW, V, M) hipLaunchKernelGGL((conv_bwd_weight_lds<T, TPW, V, M>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part)
+    // slot classes (x patch, dy chunk): most layers stage a long patch and a short dy chunk, the 1x1 expansions the
+    // reverse; everything else takes the full-size class
+    const int cls = (p.l.xv_n <= 8 && p.l.yv_n <= 2) ? 0 : (p.l.xv_n <= 2 && p.l.yv_n <= 8) ? 1 : 2;
+#define LC(TPW, V, M, XV, YV) hipLaunchKernelGGL((conv_bwd_weight_lds<T, TPW, V, M, XV, YV>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part)
+#define LL(TPW, V, M) do { if (cls == 0) LC(TPW, V, M, 8, 2); else if (cls == 1) LC(TPW, V, M, 2, 8); else LC(TPW, V, M, kXvMax, kYvMax); } while (0)
 #define LT(V, M) do { if (p.tpw == 1) LL(1, V, M); else if (p.tpw == 2) LL(2, V, M); else LL(3, V, M); } while (0)
     if (p.vec) { if (p.m16) LT(true, true); else LT(true, false); }
     else { if (p.m16) LT(false, true); else LT(false, false); }
 #undef LT
 #undef LL
+#undef LC
   } else {
 #define L(TPW) hipLaunchKernelGGL((conv_bwd_weight_kernel<T, TPW>), grid, dim3(256), 0, st, g, sz, p.a, x, dy, part)
     if (p.tpw == 1) L(1); else if (p.tpw == 2) L(2); else L(3);

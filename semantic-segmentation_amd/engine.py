@@ -336,6 +336,9 @@ class BatchNorm:
                          self.c, _ptr(ws), ws.numel() * 4, st)
 
 
+_ABLATE_WGRAD = os.environ.get("SSMI_ABLATE_WGRAD") is not None
+
+
 class RunCfg:
     """Per-call switches threaded through the blocks.
 
@@ -361,6 +364,8 @@ class RunCfg:
         self._turn = 0
 
     def wgrad(self, conv, x, dy):
+        if _ABLATE_WGRAD:       # timing experiment only: the step then computes no weight gradients at all
+            return
         if self.side is None:
             conv.bwd_weight(x, dy, self.ws, self.st)
             return
