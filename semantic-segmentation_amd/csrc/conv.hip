@@ -47,7 +47,7 @@ struct Sizes {
 // 10.19 -> 10.12 ms, 1024x1024 evaluation 5.06 -> 4.93 ms, SegNet step 59.0 -> 58.3 ms.  The strip and tiled
 // weight-gradient kernels measured slower with such bounds (spills, or no gain) and keep the default.
 template <typename T, int NT, bool VEC>
-__global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
+__global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 3 * NT * 32];
