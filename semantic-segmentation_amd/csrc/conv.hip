@@ -2480,11 +2480,12 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
   dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
   if (p.use_lds) {
     const size_t lds = (size_t)p.l.lds_words * 4;
-    // slot classes (x patch, dy chunk): most layers stage a long patch and a short dy chunk, the 1x1 expansions the
-    // reverse; everything else takes the full-size class
-    const int cls = (p.l.xv_n <= 8 && p.l.yv_n <= 2) ? 0 : (p.l.xv_n <= 2 && p.l.yv_n <= 8) ? 1 : 2;
+    // slot classes (x patch, dy chunk): most layers stage a long patch and a short dy chunk (the widest patches -
+    // dilation 16, 5x1, the 2x2 stride-2 reductions - need all twelve patch slots), the 1x1 expansions the reverse;
+    // everything else takes the full-size class
+    const int cls = (p.l.xv_n <= 8 && p.l.yv_n <= 2) ? 0 : (p.l.xv_n <= 2 && p.l.yv_n <= 8) ? 1 : (p.l.yv_n <= 2) ? 3 : 2;
 #define LC(TPW, V, M, XV, YV) hipLaunchKernelGGL((conv_bwd_weight_lds<T, TPW, V, M, XV, YV>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part)
-#define LL(TPW, V, M) do { if (cls == 0) LC(TPW, V, M, 8, 2); else if (cls == 1) LC(TPW, V, M, 2, 8); else LC(TPW, V, M, kXvMax, kYvMax); } while (0)
+#define LL(TPW, V, M) do { if (cls == 0) LC(TPW, V, M, 8, 2); else if (cls == 1) LC(TPW, V, M, 2, 8); else if (cls == 3) LC(TPW, V, M, kXvMax, 2); else LC(TPW, V, M, kXvMax, kYvMax); } while (0)
 #define LT(V, M) do { if (p.tpw == 1) LL(1, V, M); else if (p.tpw == 2) LL(2, V, M); else LL(3, V, M); } while (0)
     if (p.vec) { if (p.m16) LT(true, true); else LT(true, false); }
     else { if (p.m16) LT(false, true); else LT(false, false); }
