@@ -2398,7 +2398,8 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
   // of LDS (long chunks keep more bytes in flight per workgroup and amortise the two barriers per chunk)
   const int wo_even = (g.wo + 3) & ~3;   // multiple of the pixels per MFMA step
   p.use_lds = false;
-  for (int P = wo_even < 256 ? wo_even : 256; P >= 4; P = (P > 64 ? P - 32 : P - 4)) {
+  static const int p_max = [] { const char* e = getenv("SSMI_WG_PMAX"); return e ? atoi(e) : 256; }();   // measurement switch
+  for (int P = wo_even < p_max ? wo_even : p_max; P >= 4; P = (P > 64 ? P - 32 : P - 4)) {
     l.P = P;
     l.Wp = (P - 1) * g.stride + (g.kw - 1) * g.dil + 1;
     l.x_elems = g.kh * l.Wp * (g.cin / ew);
@@ -2429,7 +2430,11 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
   // kernel reads back, which at 512 strips is more traffic than the operands themselves; the weight gradients run
   // beside the data-gradient chain on their own stream, so they do not need to fill the chip on their own
   // (ENet step: 512 strips 11.12 ms, 256: 10.88, 128: 11.56).  SSMI_WG_STRIPS overrides for measurements.
-  static const int strips_lds = [] { const char* e = getenv("SSMI_WG_STRIPS"); return e ? atoi(e) : 256; }();
+  // The scalar-staging variant (channel counts that are no multiple of four: a network's first convolution) moves four
+  // bytes per load and is the last weight gradient of a backward pass, when the chip is otherwise empty: four
+  // workgroups per CU (init 3x3/2 3->13 at batch 16: 104 us with 256 strips, 65 with 512, 52 with 1024).
+  static const int strips_env = [] { const char* e = getenv("SSMI_WG_STRIPS"); return e ? atoi(e) : 0; }();
+  const int strips_lds = strips_env ? strips_env : (p.vec ? 256 : 1024);
   int target = ((p.use_lds ? strips_lds : 256) * spb) / p.groups;
   if (target < spb) target = spb;
   if (target > R) target = R;
