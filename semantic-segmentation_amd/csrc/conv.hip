@@ -1754,7 +1754,8 @@ __global__ __launch_bounds__(256) void conv_wt_rot_kernel(const float* __restric
 static bool dgrad_as_fwd(const Geo& g, bool prerotated = false) {
   (void)prerotated;
   static const bool off = getenv("SSMI_NO_DGRAD_AS_FWD") != nullptr;
-  return !off && g.stride == 1 && g.cin >= 64 && g.cout >= 64 && g.cout % 8 == 0 && g.y_ld % 4 == 0 && g.ho == g.h && g.wo == g.w;
+  static const int min_ch = [] { const char* e = getenv("SSMI_DGRAD_AS_FWD_MIN"); return e ? atoi(e) : 32; }();   // measurement switch (ENet fp32 step: 64 -> 9.68 ms, 32 -> 9.62, 16 -> 9.84)
+  return !off && g.stride == 1 && g.cin >= min_ch && g.cout >= min_ch && g.cout % 8 == 0 && g.y_ld % 4 == 0 && g.ho == g.h && g.wo == g.w;
 }
 static size_t dgrad_wt_bytes(const Geo& g) { return dgrad_as_fwd(g) ? (size_t)g.kh * g.kw * g.cin * g.cout * sizeof(float) : 0; }
 
