@@ -42,10 +42,12 @@ struct Sizes {
 // a block of 8 channels is permuted identically for A and B (lane half hh takes channels 4*hh .. 4*hh+3).
 // ---------------------------------------------------------------------------------------------------
 // The second launch bound (workgroups per CU = waves per SIMD) is the occupancy each variant reaches without spilling.
-// Stating it makes the compiler keep the MFMA accumulators in the unified VGPR budget instead of a separate AGPR block:
-// 74 + 16 / 97 + 32 / 152 + 64 registers (5 / 3 / 2 waves per SIMD) became 74 / 97 / 154 (6 / 4 / 3 waves); ENet step
-// 10.19 -> 10.12 ms, 1024x1024 evaluation 5.06 -> 4.93 ms, SegNet step 59.0 -> 58.3 ms.  The strip and tiled
-// weight-gradient kernels measured slower with such bounds (spills, or no gain) and keep the default.
+// Stating it makes the compiler keep the MFMA accumulators in the unified VGPR budget instead of a separate AGPR block
+// (ENet step 10.19 -> 10.12 ms, 1024x1024 evaluation 5.06 -> 4.93 ms, SegNet step 59.0 -> 58.3 ms when the bounds went
+// in).  A bound that is too tight spills silently: NT = 1 stood at 5 until the bf16 and data-gradient epilogues had
+// grown the kernel past 96 registers and 9-11 of them lived in scratch (with 4: ENet bf16 step 7.90 -> 7.68 ms) -
+// check `.vgpr_spill_count` / `.private_segment_fixed_size` of the listing after every change to this kernel.  The strip
+// and tiled weight-gradient kernels measured slower with such bounds (spills, or no gain) and keep the default.
 template <typename T, int NT, bool VEC>
 __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
