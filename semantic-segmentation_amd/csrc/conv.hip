@@ -1639,6 +1639,207 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// weight gradient of bf16 tensors on the bf16 matrix instructions (v_mfma_f32_32x32x16_bf16, pixels are the reduction
+// dimension, 16 per instruction).  Same strips, chunks and register staging as conv_bwd_weight_lds, but the LDS images
+// keep the tensors' own form - rows of pixels, bf16 channels - and the operands are fetched with the transposing read
+// (ds_read_b64_tr_b16): a group of 16 lanes reads a block of 4 pixel rows x 16 channels, lane i receives channel i of
+// the four rows, i.e. four consecutive pixels of ONE channel, which is what an operand of a product summed over pixels
+// needs.  Within a group lane 4q+p supplies the address of row q, channels 4p..4p+3 (8 bytes); rows and 4-channel
+// chunks are free, so taps, strides and dilation only move addresses.  Rows of the kernel matrix past K read a
+// constant word: {1,0,0,0} for the bias row (dy rows past the chunk are zero, so ones for every pixel are right),
+// zeros otherwise; output channels past cout read zeros.  The instruction needs every lane active: no lane-dependent
+// branch surrounds the reads.
+// LDS (bytes): x image [kh][Wq][cin] bf16 with Wq = (Pq-1)*stride + (kw-1)*dil + 1, Pq = P rounded up to 16 (the pad
+// pixels stay zero) | ones word | zero word | dy image [Pq][cout] bf16.
+// ---------------------------------------------------------------------------------------------------
+struct WgBf {
+  int Pq, Wq;
+  int ones_b, zero_b, yl_b;    // byte offsets
+  int lds_bytes;
+};
+
+template <int TPW, int XV, int YV>
+__global__ __launch_bounds__(256) void conv_bwd_weight_lds_bf16(Geo g, Sizes sz, WgArgs a, WgLds l, WgBf q, const bf16* __restrict__ x,
+                                                                const bf16* __restrict__ dy, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  const lds_ptr lds = (lds_ptr)smem;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int strip = blockIdx.x;
+  const int tile0 = blockIdx.y * (a.wps * TPW) + wave;
+  const __amdgpu_buffer_rsrc_t rx = Act<bf16>::rsrc(x, sz.x_bytes), ry = Act<bf16>::rsrc(dy, sz.y_bytes);
+
+  // ---- per-lane addresses of the transposing reads (fixed for the whole kernel) ----
+  // supplier role of this lane inside its group of 16: row sq of the 4-pixel block, 4-channel chunk sp; half gh of the tile
+  const int sq = (lane & 15) >> 2, sp = lane & 3, gh = (lane >> 4) & 1;
+  bool colv[TPW];
+  int kt_[TPW], col[TPW];
+  int abase[TPW], astep[TPW], bbase[TPW], bstep[TPW];   // bytes; step = per 16 pixels, the second read of a step sits a quarter step on
+  bool has_tile = false;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int t = tile0 + a.wps * j;
+    const bool tv = (wave < a.wps) && t < a.T;
+    has_tile |= tv;
+    const int ts = tv ? t : 0;
+    const int kt = ts / a.cotiles, ct = ts % a.cotiles;
+    kt_[j] = kt;
+    col[j] = ct * 32 + r;
+    colv[j] = tv && col[j] < g.cout;
+    const int kk = kt * 32 + 16 * gh + 4 * sp;           // first kernel-matrix row of the chunk this lane addresses
+    const bool kv = tv && kk < a.K;
+    const bool kb = tv && kk == a.K && a.K_aug > a.K;
+    const int ks = kv ? kk : 0;
+    const int tap = ks / g.cin, ci = ks % g.cin;
+    const int ky = tap / g.kw, kx = tap % g.kw;
+    abase[j] = kv ? ((ky * q.Wq + (8 * hh + sq) * g.stride + kx * g.dil) * g.cin + ci) * 2 : (kb ? q.ones_b : q.zero_b);
+    astep[j] = kv ? 16 * g.stride * g.cin * 2 : 0;
+    const int co = ct * 32 + 16 * gh + 4 * sp;
+    const bool cv = tv && co < g.cout;
+    bbase[j] = cv ? q.yl_b + ((8 * hh + sq) * g.cout + co) * 2 : q.zero_b;
+    bstep[j] = cv ? 16 * g.cout * 2 : 0;
+  }
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // ---- per-thread staging maps, one packed word per slot ----
+  // xm = [31] unused | [30:23] ky | [22:12] colp | [11:0] c      ym = [31] unused | [19:12] pixel | [11:0] c
+  unsigned xm[XV], ym[YV];
+  const int cin_e = g.cin / 4;
+#pragma unroll
+  for (int i = 0; i < XV; ++i) {
+    xm[i] = 0x80000000u;
+    if (i < l.xv_n) {
+      const unsigned e = (unsigned)(tid + i * 256);
+      if (e < (unsigned)l.x_elems) {
+        const unsigned t = e / (unsigned)cin_e;
+        const unsigned ky = t / (unsigned)l.Wp;
+        xm[i] = (ky << 23) | ((t - ky * (unsigned)l.Wp) << 12) | ((e - t * (unsigned)cin_e) * 4u);
+      }
+    }
+  }
+  const int cout_e = g.cout / 4;
+#pragma unroll
+  for (int i = 0; i < YV; ++i) {
+    ym[i] = 0x80000000u;
+    if (i < l.yv_n) {
+      const unsigned e = (unsigned)(tid + i * 256);
+      if (e < (unsigned)l.y_elems) {
+        const unsigned pq = e / (unsigned)cout_e;
+        ym[i] = (pq << 12) | ((e - pq * (unsigned)cout_e) * 4u);
+      }
+    }
+  }
+  for (int i = tid; i < q.lds_bytes / 4; i += 256) smem[i] = 0.f;
+  __syncthreads();
+  if (tid == 0) *reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + q.ones_b) = 0x00003F80u;   // bf16 {1, 0}, then {0, 0}
+
+  const int R = g.n * g.ho;
+  const int row0 = strip * a.rows_per_strip;
+  const int row1 = min(R, row0 + a.rows_per_strip);
+  const int cpr = (g.wo + l.P - 1) / l.P;
+  const int nchunks = (row1 - row0) * cpr;
+  const unsigned xpix = (unsigned)g.x_ld * 4u, ypix = (unsigned)g.y_ld * 4u;   // Act<bf16> offsets count 4-byte units of a float tensor
+
+  u32x2 xr[XV], yr[YV];
+  auto prefetch = [&](int ch) {
+    const bool cv = ch < nchunks;
+    const int chs = cv ? ch : 0;
+    const int row = row0 + chs / cpr;
+    const int ox0 = (chs % cpr) * l.P;
+    const int n_ = row / g.ho, oy = row % g.ho;
+    const int iy0 = oy * g.stride - g.pad_t, ix0 = ox0 * g.stride - g.pad_l;
+    const int pv = min(l.P, g.wo - ox0);
+    unsigned xo[XV], yo[YV];
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      const int iy = iy0 + (int)((xm[i] >> 23) & 0xFFu) * g.dil, ix = ix0 + (int)((xm[i] >> 12) & 0x7FFu);
+      const bool ok = cv & ((int)xm[i] >= 0) & ((unsigned)iy < (unsigned)g.h) & ((unsigned)ix < (unsigned)g.w);
+      const unsigned off = (unsigned)((n_ * g.h + iy) * g.w + ix) * xpix + (xm[i] & 0xFFFu) * 4u;
+      xo[i] = ok ? off : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < YV; ++i) {
+      const int yp = (int)((ym[i] >> 12) & 0xFFu);
+      const bool ok = cv & ((int)ym[i] >= 0) & (yp < pv);
+      const unsigned off = (unsigned)((n_ * g.ho + oy) * g.wo + ox0 + yp) * ypix + (ym[i] & 0xFFFu) * 4u;
+      yo[i] = ok ? off : kOOB;
+    }
+#pragma unroll
+    for (int i = 0; i < XV; ++i) xr[i] = Act<bf16>::ld4r(rx, xo[i]);
+#pragma unroll
+    for (int i = 0; i < YV; ++i) yr[i] = Act<bf16>::ld4r(ry, yo[i]);
+  };
+  auto commit = [&]() {
+    char* base = reinterpret_cast<char*>(smem);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      if (i < l.xv_n) {
+        const int e = tid + i * 256;
+        if (e < l.x_elems) {
+          const int ky = (int)((xm[i] >> 23) & 0xFFu), colp = (int)((xm[i] >> 12) & 0x7FFu), c = (int)(xm[i] & 0xFFFu);
+          *reinterpret_cast<u32x2*>(base + ((ky * q.Wq + colp) * g.cin + c) * 2) = xr[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < YV; ++i) {
+      if (i < l.yv_n) {
+        const int e = tid + i * 256;
+        if (e < l.y_elems) *reinterpret_cast<u32x2*>(base + q.yl_b + e * 8) = yr[i];
+      }
+    }
+  };
+
+  struct Pair { s16x4 lo, hi; };
+  auto operand = [&](int addr, int quarter) {
+    Pair pr;
+    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + addr));
+    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lds + addr + quarter));
+    return __builtin_bit_cast(bf16x8, pr);
+  };
+  const int steps = q.Pq >> 4;
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();            // everyone is done reading the previous chunk
+    commit();
+    __syncthreads();
+    prefetch(ch + 1);           // in flight while this chunk is multiplied
+    if (has_tile) {             // uniform per wave: every lane of a participating wave takes part in the reads
+#pragma unroll 2
+      for (int st = 0; st < steps; ++st) {
+        bf16x8 av[TPW], bv[TPW];
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          av[j] = operand(abase[j] + st * astep[j], astep[j] >> 2);
+          bv[j] = operand(bbase[j] + st * bstep[j], bstep[j] >> 2);
+        }
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[j], bv[j], acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  float* pbase = part + (int64_t)strip * a.K_aug * g.cout;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    if (!colv[j]) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = kt_[j] * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (kk < a.K_aug) pbase[(int64_t)kk * g.cout + col[j]] = acc[j][i];
+    }
+  }
+}
+
 // Strip reduction: 16 outputs x 16 strip-slices per workgroup; every thread adds its strips (slice, slice+16, ...) with
 // four independent accumulators, the 16 slices are then combined through LDS in a fixed order (deterministic).
 __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __restrict__ part, int nstrips, int K,
@@ -2367,12 +2568,15 @@ static TiledPlan plan_tiled(const Geo& g, bool with_bias) {
 struct WgPlan {
   WgArgs a;
   WgLds l;
+  WgBf q;           // bf16 matrix-instruction variant only
   bool use_lds, vec, m16;
   int tpw, groups, blocks_x;
   size_t bytes;
 };
 
-static WgPlan plan_wg(const Geo& g, bool with_bias) {
+// bf16_mfma: plan for conv_bwd_weight_lds_bf16 (32x32 tiles for every layer, bf16 LDS images); use_lds then says whether
+// that kernel can run the layer
+static WgPlan plan_wg(const Geo& g, bool with_bias, bool bf16_mfma = false) {
   WgPlan p;
   WgArgs& a = p.a;
   a.K = g.kh * g.kw * g.cin;
@@ -2389,7 +2593,7 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
     p.tpw = tpw;
     p.groups = (a.T + a.wps * tpw - 1) / (a.wps * tpw);
   };
-  p.m16 = g.cout <= 16;
+  p.m16 = g.cout <= 16 && !bf16_mfma;
   tiles(p.m16 ? 16 : 32);
 
   // LDS-staged variant
@@ -2414,8 +2618,19 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
     l.zero_off = xw + ((P + 3) & ~3);
     l.yl_off = l.zero_off + 4;
     l.lds_words = l.yl_off + P * l.coutp;
+    size_t lds_bytes = (size_t)l.lds_words * 4;
+    if (bf16_mfma) {
+      WgBf& q = p.q;
+      q.Pq = (P + 15) & ~15;
+      q.Wq = (q.Pq - 1) * g.stride + (g.kw - 1) * g.dil + 1;
+      q.ones_b = (g.kh * q.Wq * g.cin * 2 + 15) & ~15;
+      q.zero_b = q.ones_b + 8;
+      q.yl_b = q.ones_b + 16;
+      q.lds_bytes = q.yl_b + q.Pq * g.cout * 2;
+      lds_bytes = (size_t)q.lds_bytes;
+    }
     // (the last three bounds are the field widths of the packed staging maps)
-    if (l.xv_n <= kXvMax && l.yv_n <= kYvMax && l.lds_words * 4 <= 64 * 1024 && g.cin <= 4096 && g.cout <= 4096 &&
+    if (l.xv_n <= kXvMax && l.yv_n <= kYvMax && lds_bytes <= 64 * 1024 && g.cin <= 4096 && g.cout <= 4096 &&
         l.Wp < 2048 && (g.kh - 1) * g.dil < 256) {
       p.use_lds = true;
       break;
@@ -2423,6 +2638,7 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
   }
   static const bool force_direct = getenv("SSMI_WG_DIRECT") != nullptr;      // A/B switch: operands straight from global memory
   if (force_direct) p.use_lds = false;
+  if (bf16_mfma && !(p.vec && g.kh < 256)) p.use_lds = false;      // 8-byte staging only; ky travels in 8 bits of the map
   if (!p.use_lds && p.m16) {   // the direct kernel only has 32x32 tiles
     p.m16 = false;
     tiles(32);
@@ -2451,7 +2667,8 @@ static WgPlan plan_wg(const Geo& g, bool with_bias) {
 static size_t wg_ws_bytes(const Geo& g) {
   const TiledPlan t = plan_tiled(g, true);
   const size_t b0 = plan_wg(g, false).bytes, b1 = plan_wg(g, true).bytes;
-  const size_t b = b0 > b1 ? b0 : b1;
+  const size_t b2 = plan_wg(g, true, true).bytes;      // the bf16 matrix-instruction variant tiles (and so strips) differently
+  const size_t b = std::max(b0, std::max(b1, b2));
   return t.use && t.bytes > b ? t.bytes : b;      // the strip kernels remain the fallback for unaligned pointers
 }
 
@@ -2482,11 +2699,28 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
     return SSMI_OK;
   }
   WgPlan p = plan_wg(g, dbias != nullptr);
+  bool bf16_mfma = false;
+  if constexpr (sizeof(T) == 2) {
+    static const bool off = getenv("SSMI_NO_BF16_WGRAD") != nullptr || getenv("SSMI_NO_BF16_MFMA") != nullptr;
+    if (!off) {
+      const WgPlan pb = plan_wg(g, dbias != nullptr, true);
+      if (pb.use_lds) { p = pb; bf16_mfma = true; }
+    }
+  }
   SSMI_REQUIRE(ws != nullptr && ws_bytes >= p.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
                ws_bytes, p.bytes);
   float* part = reinterpret_cast<float*>(ws);
   dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
-  if (p.use_lds) {
+  if (bf16_mfma) {
+    if constexpr (sizeof(T) == 2) {
+      const int cls = (p.l.xv_n <= 8 && p.l.yv_n <= 2) ? 0 : (p.l.xv_n <= 2 && p.l.yv_n <= 8) ? 1 : 2;
+#define LB(TPW, XV, YV) hipLaunchKernelGGL((conv_bwd_weight_lds_bf16<TPW, XV, YV>), grid, dim3(256), (size_t)p.q.lds_bytes, st, g, sz, p.a, p.l, p.q, x, dy, part)
+#define LT(TPW) do { if (cls == 0) LB(TPW, 8, 2); else if (cls == 1) LB(TPW, 2, 8); else LB(TPW, kXvMax, kYvMax); } while (0)
+      if (p.tpw == 1) LT(1); else if (p.tpw == 2) LT(2); else LT(3);
+#undef LT
+#undef LB
+    }
+  } else if (p.use_lds) {
     const size_t lds = (size_t)p.l.lds_words * 4;
     // slot classes (x patch, dy chunk): most layers stage a long patch and a short dy chunk (the widest patches -
     // dilation 16, 5x1, the 2x2 stride-2 reductions - need all twelve patch slots), the 1x1 expansions the reverse;

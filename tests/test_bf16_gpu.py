@@ -64,6 +64,13 @@ CONV_CASES = [
 ]
 
 
+def _same_sums(a, b, what):
+    """Equal up to the rounding of float32 sums taken in a different order (1e-5 of the tensor's largest entry)."""
+    scale = float(a.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= 1e-5 * scale + 1e-30, "{}: {} apart at scale {}".format(what, err, scale)
+
+
 def _conv_pair(case, transpose=False):
     kh, kw, cin, cout, s, d, pad, bias, N, H, W = case
     eng = pkg("engine")
@@ -109,9 +116,11 @@ def test_conv2d_bf16_equals_rounded_float32_kernel(case):
     a, b = res[torch.float32], res[torch.bfloat16]
     for k in ("y", "dx", "dx2"):
         assert torch.equal(a[k].to(torch.bfloat16), b[k]), "{}: bf16 kernel != rounded float32 kernel".format(k)
-    assert torch.equal(a["dw"], b["dw"]), "weight gradient differs between the storage types"
+    # The weight gradient sees the same bf16 operands in both runs: every product is exact in float32 and only the order
+    # of the float32 additions differs (bf16 storage sums 16 pixels per matrix instruction, float32 storage 2 or 4).
+    _same_sums(a["dw"], b["dw"], "weight gradient")
     if bias:
-        assert torch.equal(a["db"], b["db"])
+        _same_sums(a["db"], b["db"], "bias gradient")
 
 
 @pytest.mark.parametrize("k,cin,cout,N,H,W", [(3, 16, 16, 2, 6, 5), (3, 4, 4, 1, 8, 8), (2, 16, 24, 2, 5, 7), (2, 16, 24, 1, 3, 40)])
@@ -134,7 +143,8 @@ def test_conv2d_transpose_bf16_equals_rounded_float32_kernel(k, cin, cout, N, H,
         res[dt] = (y, dx, store.gviews["c/kernel"].clone(), store.gviews["c/bias"].clone())
     a, b = res[torch.float32], res[torch.bfloat16]
     assert torch.equal(a[0].to(torch.bfloat16), b[0]) and torch.equal(a[1].to(torch.bfloat16), b[1])
-    assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+    _same_sums(a[2], b[2], "weight gradient")
+    _same_sums(a[3], b[3], "bias gradient")
 
 
 @pytest.mark.parametrize("c,npix,act", [(16, 1000, 1), (4, 333, 1), (128, 260, 1), (64, 77, 0), (24, 50, 2)])
