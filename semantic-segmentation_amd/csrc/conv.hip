@@ -2593,7 +2593,9 @@ static WgPlan plan_wg(const Geo& g, bool with_bias, bool bf16_mfma = false) {
     p.tpw = tpw;
     p.groups = (a.T + a.wps * tpw - 1) / (a.wps * tpw);
   };
-  p.m16 = g.cout <= 16 && !bf16_mfma;
+  // 16x16 tiles when either side of dW is at most 16 long (1x1 16->64: two 32-row tiles would be half padding and keep
+  // two of the four waves idle; four 16x16 column tiles take a quarter of the matrix-core time)
+  p.m16 = (g.cout <= 16 || a.K_aug <= 16) && !bf16_mfma;
   tiles(p.m16 ? 16 : 32);
 
   // LDS-staged variant
