@@ -2538,6 +2538,146 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_tiled(Geo g, Sizes sz, in
   }
 }
 
+// The same tiled GEMM for bf16 tensors on v_mfma_f32_32x32x16_bf16: the slabs stay bf16 rows of pixels in LDS (64 pixels
+// per chunk: a chunk of matrix work is eight times shorter than with the float32 instructions, so chunks are longer to
+// keep the two barriers per chunk cheap) and the operands come from the transposing LDS read, as in
+// conv_bwd_weight_lds_bf16.  Rows are padded by 64 bytes: the four pixel rows and two 16-channel halves that one
+// 32-lane half reads in one instruction then fall into distinct banks.
+template <int WK, int WC>
+__global__ __launch_bounds__(256) void conv_bwd_weight_tiled_bf16(Geo g, Sizes sz, int K, int K_aug, int pix_per_share,
+                                                                  const bf16* __restrict__ x, const bf16* __restrict__ dy,
+                                                                  float* __restrict__ part) {
+  static_assert(WK * WC == 4, "four waves per workgroup");
+  constexpr int TK = WK * 64, TC = WC * 64, P = 64;
+  constexpr int SA = TK * 2 + 64, SB = TC * 2 + 64;             // row strides in bytes
+  constexpr int KA4 = TK / 4, PA = 256 / KA4, NA = P / PA;     // A staging: thread -> (k group, pixel slots)
+  constexpr int KB4 = TC / 4, PB = 256 / KB4, NB = P / PB;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  char* const As = reinterpret_cast<char*>(smem);
+  char* const Bs = As + P * SA;
+  const lds_ptr lA = (lds_ptr)smem;
+  const lds_ptr lB = lA + P * SA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int sq = (lane & 15) >> 2, sp = lane & 3, gh = (lane >> 4) & 1;   // this lane's part in a transposing read
+  const int wk = wave % WK, wc = wave / WK;
+  const int k0 = blockIdx.x * TK, c0 = blockIdx.y * TC;
+  const __amdgpu_buffer_rsrc_t rx = Act<bf16>::rsrc(x, sz.x_bytes), ry = Act<bf16>::rsrc(dy, sz.y_bytes);
+  const unsigned M = (unsigned)(g.n * g.ho * g.wo);
+  const unsigned p_begin = (unsigned)blockIdx.z * (unsigned)pix_per_share;
+  const unsigned p_end = min(M, p_begin + (unsigned)pix_per_share);
+  const int nchunks = p_end > p_begin ? (int)((p_end - p_begin + P - 1) / P) : 0;
+
+  const int ka = tid % KA4, pa0 = tid / KA4;
+  const int kk = k0 + ka * 4;
+  const bool kvalid = kk < K;
+  const int tap = kvalid ? kk / g.cin : 0;
+  const int ci = kvalid ? kk - tap * g.cin : 0;
+  const int ky = tap / g.kw, kx = tap - ky * g.kw;
+  const int offy = ky * g.dil - g.pad_t, offx = kx * g.dil - g.pad_l;
+  const int cb = tid % KB4, pb0 = tid / KB4;
+  const int co = c0 + cb * 4;
+  const bool covalid = co < g.cout;
+
+  u32x2 ra[NA], rb[NB];
+  auto prefetch = [&](int ch) {
+    const bool cv = ch < nchunks;
+    unsigned oa[NA], ob[NB];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const unsigned pix = p_begin + (unsigned)ch * P + (unsigned)(pa0 + j * PA);
+      const bool pv = cv & kvalid & (pix < p_end);
+      const unsigned pp = pv ? pix : 0u;
+      const unsigned t1 = pp / (unsigned)g.wo;
+      const int ox = (int)(pp - t1 * (unsigned)g.wo);
+      const unsigned n_ = t1 / (unsigned)g.ho;
+      const int oy = (int)(t1 - n_ * (unsigned)g.ho);
+      const int iy = oy * g.stride + offy, ix = ox * g.stride + offx;
+      const bool ok = pv & ((unsigned)iy < (unsigned)g.h) & ((unsigned)ix < (unsigned)g.w);
+      oa[j] = ok ? (((n_ * (unsigned)g.h + (unsigned)iy) * (unsigned)g.w + (unsigned)ix) * (unsigned)g.x_ld + (unsigned)ci) * 4u : kOOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const unsigned pix = p_begin + (unsigned)ch * P + (unsigned)(pb0 + j * PB);
+      ob[j] = (cv & covalid & (pix < p_end)) ? (pix * (unsigned)g.y_ld + (unsigned)co) * 4u : kOOB;
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) ra[j] = Act<bf16>::ld4r(rx, oa[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = Act<bf16>::ld4r(ry, ob[j]);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a_][b_][i] = 0.f;
+  float bsum0 = 0.f, bsum1 = 0.f;
+  const bool do_bias = (K_aug > K) && blockIdx.x == 0 && wk == 0;
+
+  struct Pair { s16x4 lo, hi; };
+  auto operand = [&](lds_ptr base, int addr, int quarter) {
+    Pair pr;
+    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + addr));
+    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + addr + quarter));
+    return __builtin_bit_cast(bf16x8, pr);
+  };
+  const int a_addr = (8 * hh + sq) * SA + (wk * 64 + 16 * gh + 4 * sp) * 2;
+  const int b_addr = (8 * hh + sq) * SB + (wc * 64 + 16 * gh + 4 * sp) * 2;
+
+  prefetch(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();            // everyone is done reading the previous chunk
+#pragma unroll
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<u32x2*>(As + (pa0 + j * PA) * SA + ka * 8) = ra[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x2*>(Bs + (pb0 + j * PB) * SB + cb * 8) = rb[j];
+    __syncthreads();
+    prefetch(ch + 1);           // in flight while this chunk is multiplied
+#pragma unroll
+    for (int st = 0; st < P / 16; ++st) {
+      const bf16x8 a0 = operand(lA, a_addr + st * 16 * SA, 4 * SA), a1 = operand(lA, a_addr + st * 16 * SA + 64, 4 * SA);
+      const bf16x8 b0 = operand(lB, b_addr + st * 16 * SB, 4 * SB), b1 = operand(lB, b_addr + st * 16 * SB + 64, 4 * SB);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+      if (do_bias) {            // uniform per wave
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { bsum0 += (float)b0[e]; bsum1 += (float)b1[e]; }
+      }
+    }
+  }
+
+  float* pbase = part + (int64_t)blockIdx.z * K_aug * g.cout;
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_) {
+      const int col = c0 + wc * 64 + b_ * 32 + r;
+      if (col >= g.cout) continue;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + wk * 64 + a_ * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (k < K) pbase[(int64_t)k * g.cout + col] = acc[a_][b_][i];
+      }
+    }
+  if (do_bias) {
+    bsum0 += __shfl_xor(bsum0, 32, 64);
+    bsum1 += __shfl_xor(bsum1, 32, 64);
+    if (hh == 0) {
+      const int col = c0 + wc * 64 + r;
+      if (col < g.cout) pbase[(int64_t)K * g.cout + col] = bsum0;
+      if (col + 32 < g.cout) pbase[(int64_t)K * g.cout + col + 32] = bsum1;
+    }
+  }
+}
+
 struct TiledPlan {
   bool use;
   int wk, K, K_aug, shares, chunks_per_share, ktiles, ctiles;
@@ -2687,7 +2827,22 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
     SSMI_REQUIRE(t.bytes < 0x7FFFFFFFULL, SSMI_E_UNSUPPORTED, "conv2d_bwd_weight: partial sums of 2 GiB or more");
     float* part = reinterpret_cast<float*>(ws);
     dim3 grid((unsigned)t.ktiles, (unsigned)t.ctiles, (unsigned)t.shares);
-    if (t.wk == 2)
+    bool on_bf16_mfma = false;
+    if constexpr (sizeof(T) == 2) {
+      static const bool off = getenv("SSMI_NO_BF16_WGRAD") != nullptr || getenv("SSMI_NO_BF16_MFMA") != nullptr;
+      if (!off) {
+        on_bf16_mfma = true;
+        const int pps = t.chunks_per_share * 32;
+        if (t.wk == 2)
+          hipLaunchKernelGGL((conv_bwd_weight_tiled_bf16<2, 2>), grid, dim3(256), (size_t)64 * (2 * (128 * 2 + 64)), st, g, sz, t.K, t.K_aug,
+                             pps, x, dy, part);
+        else
+          hipLaunchKernelGGL((conv_bwd_weight_tiled_bf16<4, 1>), grid, dim3(256), (size_t)64 * ((256 * 2 + 64) + (64 * 2 + 64)), st, g, sz,
+                             t.K, t.K_aug, pps, x, dy, part);
+      }
+    }
+    if (on_bf16_mfma) {
+    } else if (t.wk == 2)
       hipLaunchKernelGGL((conv_bwd_weight_tiled<T, 2, 2>), grid, dim3(256), (size_t)32 * 256 * 4, st, g, sz, t.K, t.K_aug,
                          t.chunks_per_share, x, dy, part);
     else
