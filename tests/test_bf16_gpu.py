@@ -463,6 +463,38 @@ def test_bf16_training_loss_falls_and_graph_replay_is_exact():
     assert runs["graph"][0] == runs["eager"][0] and torch.equal(runs["graph"][1], runs["eager"][1])
 
 
+@pytest.mark.parametrize("name", ["segnet", "unet"])
+def test_bf16_wide_models_follow_the_float32_engine(name):
+    """SegNet / U-Net with bf16 storage (bf16 matrix instructions in forward, data gradient and the tiled weight gradient)
+    against the same engine with float32 storage on the same weights and batch: first-step loss within 2e-2, and the loss
+    falls under training.  The parameter gradients of the whole network are only bounded loosely: rounding every stored
+    activation to bf16 moves them by 20-25 % in norm on these randomly initialised networks whichever kernels multiply
+    (0.249 / 0.207 with the bf16 matrix instructions, the same with the float32 ones in the weight gradients, 0.226 /
+    0.201 with float32 instructions everywhere); what the kernels compute is pinned per layer above."""
+    B, H, W, lr = 2, 64, 64, 1e-3
+    w0 = E.init_weights(name, NC, seed=17, perturb=True)
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=41, block=16)
+    x = [images, labels, pw, np.zeros((B, 1), np.int32)]
+    first, grads, curve = {}, {}, None
+    for dtype in ("f32", "bf16"):
+        m = _compiled(name, w0, lr=lr, dtype=dtype)
+        m.use_hip_graph = False
+        with torch.cuda.stream(torch.cuda.Stream()):
+            first[dtype] = m.train_on_batch(x)[0]
+            torch.cuda.synchronize()
+            grads[dtype] = m.graph.store.grad.double().cpu().numpy().copy()
+            if dtype == "bf16":
+                curve = [first[dtype]] + [m.train_on_batch(x)[0] for _ in range(24)]
+        torch.cuda.synchronize()
+        m.close()
+    assert abs(first["bf16"] - first["f32"]) <= 2e-2 * abs(first["f32"]), first
+    err = _rel_l2(grads["bf16"], grads["f32"])
+    print("{}: first-step loss {:.5f} (bf16) / {:.5f} (f32), parameter gradients {:.3e} apart in norm, loss after 25 steps "
+          "{:.4f}".format(name, first["bf16"], first["f32"], err, curve[-1]))
+    assert err <= 0.5, err
+    assert curve[-1] < 0.9 * curve[0] and np.mean(curve[-5:]) < np.mean(curve[:5]), curve
+
+
 def test_bf16_rejects_what_it_does_not_implement():
     models, losses = pkg("models"), pkg("losses")
     with pytest.raises(ValueError):
