@@ -66,6 +66,7 @@ struct BnBwdArgs {
   const void* add;
   // bfloat16 storage only: the kernel as a bfloat16 pack [tap][cout][cin] (nullptr: float32 kernel words, fp32 MFMA)
   const void* wpack;
+  int lds_b;               // with wpack, wide layers: the workgroup stages the kernel rows through LDS (set by the launcher)
 };
 
 // Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.

@@ -53,11 +53,18 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 3 * NT * 32];
+  // bf16 wide layers: the kernel rows of the workgroup's 128 output channels go through LDS (below)
+  constexpr bool kLdsB = sizeof(T) == 2 && VEC && NT == 4;
+  constexpr int kBRow = 80;                    // bytes per staged kernel row: 32 channels + 16 bytes of padding
+  __shared__ __attribute__((aligned(16))) unsigned char bsm[kLdsB ? 128 * kBRow : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
-  if (tile0 >= M && part == nullptr && bn.x == nullptr) return;   // with statistics every wave reaches the barrier (its rows are masked)
+  bool lds_b = false;
+  if constexpr (kLdsB) lds_b = bn.wpack != nullptr && bn.lds_b != 0;      // uniform
+  // with statistics, or kernel rows staged by the whole workgroup, every wave reaches the barriers (its rows are masked)
+  if (tile0 >= M && part == nullptr && bn.x == nullptr && !lds_b) return;
   const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
   const unsigned p = (unsigned)tile0 + (unsigned)r;       // M < 2^31: 32-bit pixel arithmetic
@@ -90,7 +97,71 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
 
   bool packed = false;
   if constexpr (sizeof(T) == 2 && VEC) packed = bn.wpack != nullptr;      // uniform
-  if (packed) {
+  if (lds_b) {
+    if constexpr (kLdsB) {
+      // Wide layers on the bf16 matrix instructions.  Fed straight from global memory every wave fetches its own copy of
+      // the 128 kernel rows of a step - four 16-byte loads per lane for four matrix instructions - and the launch runs
+      // at the rate of the vector-memory path, not of the matrix cores.  Here the workgroup stages the rows of a 32-channel
+      // chunk once ([128 couts][32 channels] bf16, 8 KB, two 16-byte loads per thread, one chunk ahead in registers) and
+      // the four waves read their B operands from LDS; A (the wave's own 32 pixels) still comes from global memory.
+      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const int ntaps = g.kh * g.kw;
+      const __amdgpu_buffer_rsrc_t rp = make_rsrc(bn.wpack, (unsigned)(ntaps * g.cin * g.cout) * 2u);
+      const int srow = threadIdx.x >> 2, sseg = threadIdx.x & 3;       // staging role: rows srow and srow + 64, segment sseg
+      unsigned gb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int c = cbase + srow + 64 * i;
+        gb[i] = c < g.cout ? (unsigned)(c * g.cin + sseg * 8) * 2u : kOOB;
+      }
+      const unsigned tapbytes = (unsigned)(g.cin * g.cout) * 2u;
+      int tap = 0, ky = 0, kx = 0, c0 = 0;            // state of the NEXT fetch
+      unsigned xo = 0, wtap = 0;
+      auto settap = [&]() {
+        const int iy = oy * g.stride + ky * g.dil - g.pad_t, ix = ox * g.stride + kx * g.dil - g.pad_l;
+        const bool inb = pv && tap < ntaps && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+        xo = inb ? (n_ * (unsigned)(g.h * g.w) + (unsigned)(iy * g.w + ix)) * (unsigned)g.x_ld * 2u : (kOOB >> 1);
+        wtap = tap < ntaps ? (unsigned)tap * tapbytes : kOOB;
+      };
+      settap();
+      u32x4 pa[2], pb[2];
+      auto fetch = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const unsigned cb = (unsigned)(c0 + 16 * k + 8 * hh) * 2u;
+          pa[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo + cb) | (xo & (kOOB >> 1)), 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          pb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (wtap + (unsigned)c0 * 2u + gb[i]) | (wtap & kOOB) | (gb[i] & kOOB), 0, 0));
+        c0 += 32;
+        if (c0 >= g.cin) {
+          c0 = 0;
+          ++tap;
+          if (++kx == g.kw) { kx = 0; ++ky; }
+          settap();
+        }
+      };
+      const int nchunks = ntaps * (g.cin >> 5);
+      fetch();
+      for (int i = 0; i < nchunks; ++i) {
+        __syncthreads();            // everyone is done reading the previous chunk's rows
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(bsm + (srow + 64 * j) * kBRow + sseg * 16) = pb[j];
+        const u32x4 ca0 = pa[0], ca1 = pa[1];
+        __syncthreads();
+        fetch();                    // the next chunk, in flight while this one is multiplied; past the end: zeros
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const u32x4 b0 = *reinterpret_cast<const u32x4*>(bsm + (t * 32 + r) * kBRow + hh * 16);
+          const u32x4 b1 = *reinterpret_cast<const u32x4*>(bsm + (t * 32 + r) * kBRow + 32 + hh * 16);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca0), __builtin_bit_cast(bf16x8, b0), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ca1), __builtin_bit_cast(bf16x8, b1), acc[t], 0, 0, 0);
+        }
+      }
+    }
+  } else if (packed) {
     if constexpr (sizeof(T) == 2 && VEC) {
       // bfloat16 matrix instructions: one v_mfma_f32_32x32x16_bf16 per 16 input channels and column tile.  Lane (r, hh)
       // feeds A = 8 consecutive channels of its pixel (one 16-byte load, no unpacking) and B = the same 8 channels of
@@ -2240,6 +2311,9 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  // kernel rows through LDS: wide layers only (a 1x1 layer over 32 channels has a single chunk and nothing to share)
+  static const bool no_lds_b = getenv("SSMI_NO_LDS_B") != nullptr;
+  bn.lds_b = (!no_lds_b && bn.wpack && nt == 4 && vec && g.cin % 32 == 0 && g.kh * g.kw * g.cin >= 256) ? 1 : 0;
   set_last_kernel(bn.wpack ? "conv_fwd_kernel<%d, %s> bf16 mfma" : "conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
 #define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<T, NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn)
   if (vec) {

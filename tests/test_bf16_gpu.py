@@ -278,6 +278,9 @@ PACKED_CASES = [  # kh, kw, cin, cout, stride, dil, padding, N, H, W
     (1, 1, 128, 32, 1, 1, "valid", 2, 12, 20), (3, 3, 32, 32, 1, 1, "same", 2, 9, 13), (3, 3, 32, 32, 1, 4, "same", 1, 16, 16),
     (5, 1, 32, 32, 1, 1, "same", 2, 8, 8), (1, 5, 32, 32, 1, 1, "same", 1, 7, 24), (1, 1, 32, 128, 1, 1, "valid", 2, 10, 10),
     (2, 2, 64, 32, 2, 1, "valid", 2, 12, 16), (3, 3, 64, 64, 1, 1, "same", 1, 12, 12), (1, 1, 48, 80, 1, 1, "valid", 1, 6, 10),
+    # wide layers: the kernel rows of a workgroup's 128 output channels staged through LDS (ragged pixel and channel tails)
+    (3, 3, 64, 128, 1, 1, "same", 1, 12, 12), (3, 3, 128, 128, 1, 1, "same", 2, 9, 11), (3, 3, 64, 160, 1, 2, "same", 1, 10, 13),
+    (1, 1, 256, 256, 1, 1, "valid", 1, 7, 9),
 ]
 
 
