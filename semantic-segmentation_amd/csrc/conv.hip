@@ -54,9 +54,9 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 3 * NT * 32];
   // bf16 wide layers: the kernel rows of the workgroup's 128 output channels go through LDS (below)
-  constexpr bool kLdsB = sizeof(T) == 2 && VEC && NT == 4;
+  constexpr bool kLdsB = sizeof(T) == 2 && VEC && NT >= 2;
   constexpr int kBRow = 80;                    // bytes per staged kernel row: 32 channels + 16 bytes of padding
-  __shared__ __attribute__((aligned(16))) unsigned char bsm[kLdsB ? 128 * kBRow : 16];
+  __shared__ __attribute__((aligned(16))) unsigned char bsm[kLdsB ? NT * 32 * kBRow : 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
@@ -100,18 +100,20 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
   if (lds_b) {
     if constexpr (kLdsB) {
       // Wide layers on the bf16 matrix instructions.  Fed straight from global memory every wave fetches its own copy of
-      // the 128 kernel rows of a step - four 16-byte loads per lane for four matrix instructions - and the launch runs
-      // at the rate of the vector-memory path, not of the matrix cores.  Here the workgroup stages the rows of a 32-channel
-      // chunk once ([128 couts][32 channels] bf16, 8 KB, two 16-byte loads per thread, one chunk ahead in registers) and
-      // the four waves read their B operands from LDS; A (the wave's own 32 pixels) still comes from global memory.
+      // the workgroup's NT*32 kernel rows of a step - NT 16-byte loads per lane for NT matrix instructions - and the
+      // launch runs at the rate of the vector-memory path, not of the matrix cores.  Here the workgroup stages the rows of a
+      // 32-channel chunk once ([NT*32 couts][32 channels] bf16, one or two 16-byte loads per thread, one chunk ahead in
+      // registers) and the four waves read their B operands from LDS; A (the wave's own 32 pixels) still comes from
+      // global memory.
       typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       const int ntaps = g.kh * g.kw;
       const __amdgpu_buffer_rsrc_t rp = make_rsrc(bn.wpack, (unsigned)(ntaps * g.cin * g.cout) * 2u);
       const int srow = threadIdx.x >> 2, sseg = threadIdx.x & 3;       // staging role: rows srow and srow + 64, segment sseg
-      unsigned gb[2];
+      constexpr int NB = NT / 2;                                        // staged 16-byte pieces per thread
+      unsigned gb[NB];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NB; ++i) {
         const int c = cbase + srow + 64 * i;
         gb[i] = c < g.cout ? (unsigned)(c * g.cin + sseg * 8) * 2u : kOOB;
       }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
         wtap = tap < ntaps ? (unsigned)tap * tapbytes : kOOB;
       };
       settap();
-      u32x4 pa[2], pb[2];
+      u32x4 pa[2], pb[NB];
       auto fetch = [&]() {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
           pa[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo + cb) | (xo & (kOOB >> 1)), 0, 0));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NB; ++i)
           pb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (wtap + (unsigned)c0 * 2u + gb[i]) | (wtap & kOOB) | (gb[i] & kOOB), 0, 0));
         c0 += 32;
         if (c0 >= g.cin) {
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
       for (int i = 0; i < nchunks; ++i) {
         __syncthreads();            // everyone is done reading the previous chunk's rows
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<u32x4*>(bsm + (srow + 64 * j) * kBRow + sseg * 16) = pb[j];
+        for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(bsm + (srow + 64 * j) * kBRow + sseg * 16) = pb[j];
         const u32x4 ca0 = pa[0], ca1 = pa[1];
         __syncthreads();
         fetch();                    // the next chunk, in flight while this one is multiplied; past the end: zeros
@@ -2313,7 +2315,7 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   // kernel rows through LDS: wide layers only (a 1x1 layer over 32 channels has a single chunk and nothing to share)
   static const bool no_lds_b = getenv("SSMI_NO_LDS_B") != nullptr;
-  bn.lds_b = (!no_lds_b && bn.wpack && nt == 4 && vec && g.cin % 32 == 0 && g.kh * g.kw * g.cin >= 256) ? 1 : 0;
+  bn.lds_b = (!no_lds_b && bn.wpack && nt >= 2 && vec && g.cin % 32 == 0 && g.kh * g.kw * g.cin >= 256) ? 1 : 0;
   set_last_kernel(bn.wpack ? "conv_fwd_kernel<%d, %s> bf16 mfma" : "conv_fwd_kernel<%d, %s>", nt, vec ? "true" : "false");
 #define L(NT, V) hipLaunchKernelGGL((conv_fwd_kernel<T, NT, V>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn)
   if (vec) {
