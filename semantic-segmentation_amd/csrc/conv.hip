@@ -3106,7 +3106,7 @@ ssmi_status ssmi_conv_pack_weights_bf16(const ssmi_rot_entry* table, int32_t cou
                                         uint16_t* dgrad_pack, void* stream) {
   SSMI_REQUIRE(table && theta && (fwd_pack || dgrad_pack) && count > 0 && count <= 65535, SSMI_E_INVALID_ARG,
                "conv_pack_weights_bf16: bad argument");
-  hipLaunchKernelGGL(conv_pack_bf16_batch_kernel, dim3(16, (unsigned)count), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(conv_pack_bf16_batch_kernel, dim3(64, (unsigned)count), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const RotEntry*>(table), theta, reinterpret_cast<bf16*>(fwd_pack),
                      reinterpret_cast<bf16*>(dgrad_pack));
   SSMI_LAUNCH_CHECK();
@@ -3122,7 +3122,7 @@ ssmi_status ssmi_conv_rotate_weights(const ssmi_rot_entry* table, int32_t count,
                                      void* stream) {
   static_assert(sizeof(RotEntry) == sizeof(ssmi_rot_entry), "rotation table entry layout");
   SSMI_REQUIRE(table && theta && theta_rot && count > 0 && count <= 65535, SSMI_E_INVALID_ARG, "conv_rotate_weights: bad argument");
-  hipLaunchKernelGGL(conv_wt_rot_batch_kernel, dim3(16, (unsigned)count), dim3(256), 0, as_stream(stream),
+  hipLaunchKernelGGL(conv_wt_rot_batch_kernel, dim3(64, (unsigned)count), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const RotEntry*>(table), theta, theta_rot);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;

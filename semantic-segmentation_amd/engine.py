@@ -889,6 +889,8 @@ class GraphBase:
         for b in self.blocks:
             for cv in b.convs():
                 cv.wrot = None
+                if st.act_dtype == torch.bfloat16 and (cv.pack_usage & 2):
+                    continue        # its data gradient reads the bfloat16 pack instead (the float32 forms remain the fallback)
                 if cv.uses_rot and not cv.transpose and dev.type == "cuda" and not os.environ.get("SSMI_NO_ROTATED_ARENA"):
                     sp = st.specs[cv.name + "/kernel"]
                     rows.append((cv, sp))
