@@ -1947,6 +1947,49 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __res
   }
 }
 
+// The same reduction for long partial rows (the wide layers: hundreds of thousands of elements per row, tens to a few
+// hundred rows).  A workgroup owns 256 consecutive elements: 64 lanes x 16 bytes make every load of a wave one
+// contiguous kilobyte of a row (the kernel above fetches 64-byte pieces), the four waves take the rows slice, slice + 4,
+// ... with four loads in flight per lane, and the four slices are combined through LDS in a fixed order.
+// Requires E % 4 == 0 and (K * cout) % 4 == 0.
+__global__ __launch_bounds__(256) void conv_bwd_weight_reduce_wide(const float* __restrict__ part, int nstrips, int K,
+                                                                   int K_aug, int cout, float* __restrict__ dw,
+                                                                   float* __restrict__ dbias) {
+  __shared__ f32x4 sm[256];
+  const int E = K_aug * cout;
+  const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int e = (blockIdx.x * 64 + lane) * 4;
+  const __amdgpu_buffer_rsrc_t rp = make_rsrc(part, (unsigned)((int64_t)nstrips * E * 4));
+  const unsigned eo = e < E ? (unsigned)e * 4u : kOOB;
+  const unsigned rowb = (unsigned)E * 4u;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  for (int c = slice; c < nstrips; c += 16) {
+    const f32x4 v0 = bload4(rp, eo + (unsigned)c * rowb);
+    const f32x4 v1 = bload4(rp, c + 4 < nstrips ? eo + (unsigned)(c + 4) * rowb : kOOB);
+    const f32x4 v2 = bload4(rp, c + 8 < nstrips ? eo + (unsigned)(c + 8) * rowb : kOOB);
+    const f32x4 v3 = bload4(rp, c + 12 < nstrips ? eo + (unsigned)(c + 12) * rowb : kOOB);
+    s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+  }
+  sm[threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (slice == 0 && e < E) {
+    const f32x4 t = ((sm[lane] + sm[64 + lane]) + sm[128 + lane]) + sm[192 + lane];
+    if (e < K * cout) *reinterpret_cast<f32x4*>(dw + e) = t;
+    else if (dbias) *reinterpret_cast<f32x4*>(dbias + (e - K * cout)) = t;
+  }
+}
+
+// Picks the reduction kernel by the shape of the partial-sum matrix.
+static void launch_wg_reduce(const float* part, int nstrips, int K, int K_aug, int cout, float* dw, float* dbias, hipStream_t st) {
+  const int E = K_aug * cout;
+  static const bool no_wide = getenv("SSMI_NO_WIDE_REDUCE") != nullptr;      // measurement switch
+  const bool aligned = ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(dbias)) & 15) == 0;
+  if (!no_wide && E >= 16384 && cout % 4 == 0 && aligned)
+    hipLaunchKernelGGL(conv_bwd_weight_reduce_wide, dim3((E + 255) / 256), dim3(256), 0, st, part, nstrips, K, K_aug, cout, dw, dbias);
+  else
+    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 15) / 16), dim3(256), 0, st, part, nstrips, K, K_aug, cout, dw, dbias);
+}
+
 // column sums of a [npix, c] matrix with row stride ld (bias gradient of a transposed convolution).
 // VEC (c % 4 == 0, ld % 4 == 0): thread = (pixel lane, group of 4 channels), 16-byte loads, grid-stride over pixels.
 template <typename T, bool VEC>
@@ -2925,9 +2968,7 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
       hipLaunchKernelGGL((conv_bwd_weight_tiled<T, 4, 1>), grid, dim3(256), (size_t)32 * 320 * 4, st, g, sz, t.K, t.K_aug,
                          t.chunks_per_share, x, dy, part);
     SSMI_LAUNCH_CHECK();
-    const int E = t.K_aug * g.cout;
-    hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 15) / 16), dim3(256), 0, st, part, t.shares, t.K, t.K_aug, g.cout,
-                       dw, dbias);
+    launch_wg_reduce(part, t.shares, t.K, t.K_aug, g.cout, dw, dbias, st);
     SSMI_LAUNCH_CHECK();
     return SSMI_OK;
   }
@@ -2973,9 +3014,7 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
 #undef L
   }
   SSMI_LAUNCH_CHECK();
-  const int E = p.a.K_aug * g.cout;
-  hipLaunchKernelGGL(conv_bwd_weight_reduce, dim3((E + 15) / 16), dim3(256), 0, st, part, p.a.nstrips, p.a.K, p.a.K_aug,
-                     g.cout, dw, dbias);
+  launch_wg_reduce(part, p.a.nstrips, p.a.K, p.a.K_aug, g.cout, dw, dbias, st);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
