@@ -337,6 +337,22 @@ ssmi_status ssmi_softmax_xent_fwd_bwd(const float* logits, const int32_t* labels
                                       int32_t num_classes, float grad_scale, float* dlogits, float* loss_out,
                                       int64_t* cm, int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
                                       int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream);
+/* The network's last layer and the loss in one pass: the `logits` layer of the ENets,
+ * Conv2DTranspose(num_classes, (2, 2), strides=(2, 2), padding='same') (src/models.py:1318, 1627), followed by
+ * ssmi_softmax_xent_fwd_bwd on its output, without the logits tensor travelling through memory:
+ *   logits[n, 2i+ky, 2j+kx, co] = bias[co] + sum_ci x[n, i, j, ci] * kernel[ky, kx, co, ci]      (Keras layout (kh, kw, out, in))
+ * x: [n, h, w, cin] of `dtype` with row stride x_ld elements; labels / weights / the optional outputs cover the
+ * n * 2h * 2w output pixels; logits_out (nullable) receives the logits the loss was computed from, dlogits (nullable)
+ * the gradient for ssmi_conv2d_transpose_bwd_data / _bwd_weight of the same layer; every other argument as in
+ * ssmi_softmax_xent_fwd_bwd (workspace size: ssmi_softmax_xent_workspace_bytes).  Built for cin = 16 and 24 classes
+ * (ssmi_logits_tconv2x2_xent_supported); other shapes return SSMI_E_UNSUPPORTED and take the two-call route. */
+int32_t ssmi_logits_tconv2x2_xent_supported(int32_t cin, int32_t num_classes);
+ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t cin,
+                                              int32_t x_ld, const float* kernel, const float* bias, int32_t num_classes,
+                                              const int32_t* labels, const float* weights, int64_t npix, float grad_scale,
+                                              void* logits_out, void* dlogits, float* loss_out, int64_t* cm,
+                                              int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                              int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream);
 /* ssmi_softmax_xent_fwd_bwd for callers that cannot allocate or carry a workspace (code under HIP-graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, results and
  * arithmetic (bit-identical) as ssmi_softmax_xent_fwd_bwd, but the per-block partial sums of the loss go through a

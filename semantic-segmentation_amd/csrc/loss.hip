@@ -161,6 +161,115 @@ __global__ void xent_final(const double* __restrict__ part, int nblocks, double 
   if (threadIdx.x == 0) *loss_out = (float)(sm[0] * inv_npix);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The network's last layer and the loss in one pass: logits = Conv2DTranspose(2x2, stride 2, 'same')(x) + bias
+// (src/models.py:1318, every output pixel reads ONE input pixel through the tap its parity selects) feed the loss
+// arithmetic of xent_kernel straight from registers.  The logits tensor (num_classes floats per full-resolution pixel,
+// the largest tensor of the network) is neither written nor read back unless the caller asks for it; the evaluation
+// phase then moves the 16-channel half-resolution input, the labels and the weights only.
+// One thread per OUTPUT pixel; the kernel [tap][cout][cin] is staged once per workgroup as [tap][cin][cout] so that a
+// 16-byte LDS read yields four output channels of one input channel (lanes of one parity read the same address).
+// bf16 storage: the logits are rounded to bf16 before the loss sees them - the stored logits, when requested, are the
+// values the loss, the argmax and the gradient were computed from, as in the two-kernel form.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int C, int CIN>
+__global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, int hin, int win,
+                                                           const int32_t* __restrict__ labels, const float* __restrict__ weights,
+                                                           int npix, float inv_npix, float grad_scale, T* __restrict__ logits_out,
+                                                           T* __restrict__ dlogits, double* __restrict__ part,
+                                                           int64_t* __restrict__ cm, int npix_metrics, uint64_t ignore_mask,
+                                                           int32_t* __restrict__ pred_out, int32_t* __restrict__ bad_labels) {
+  extern __shared__ __attribute__((aligned(16))) int head_lds[];
+  float* wl = reinterpret_cast<float*>(head_lds);            // [4][CIN][C]
+  float* bl = wl + 4 * CIN * C;                               // [C]
+  int* cm_lds = head_lds + 4 * CIN * C + C;                   // [C][C]
+  static_assert(C % 4 == 0 && CIN % 4 == 0, "16-byte accesses");
+  for (int e = threadIdx.x; e < 4 * C * CIN; e += 256) {
+    const int tap = e / (C * CIN), rem = e % (C * CIN), co = rem / CIN, ci = rem % CIN;
+    wl[(tap * CIN + ci) * C + co] = w[e];
+  }
+  if (threadIdx.x < C) bl[threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  if (cm)
+    for (int e = threadIdx.x; e < C * C; e += 256) cm_lds[e] = 0;
+  __syncthreads();
+  const int wout = 2 * win, hout = 2 * hin;
+  float local = 0.f;
+  int bad = 0;
+  const int nloop = npix_metrics > npix ? npix_metrics : npix;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < nloop; p += gridDim.x * 256) {
+    const bool in_loss = p < npix;
+    const int row = p / wout, ox = p - row * wout;
+    const int img = row / hout, oy = row - img * hout;
+    const T* xp = x + (int64_t)((img * hin + (oy >> 1)) * win + (ox >> 1)) * x_ld;
+    float xv[CIN];
+#pragma unroll
+    for (int j = 0; j < CIN / 4; ++j) {
+      const f32x4 t = Act<T>::gld4(xp + 4 * j);
+      xv[4 * j] = t[0]; xv[4 * j + 1] = t[1]; xv[4 * j + 2] = t[2]; xv[4 * j + 3] = t[3];
+    }
+    const float* wt = wl + (((oy & 1) * 2 + (ox & 1)) * CIN) * C;
+    f32x4 zq[C / 4];
+#pragma unroll
+    for (int m = 0; m < C / 4; ++m) zq[m] = *reinterpret_cast<const f32x4*>(bl + 4 * m);
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      const f32x4 xs = {xv[ci], xv[ci], xv[ci], xv[ci]};
+#pragma unroll
+      for (int m = 0; m < C / 4; ++m)
+        zq[m] = __builtin_elementwise_fma(xs, *reinterpret_cast<const f32x4*>(wt + ci * C + 4 * m), zq[m]);
+    }
+    float z[C];
+#pragma unroll
+    for (int m = 0; m < C / 4; ++m) {
+      if constexpr (sizeof(T) == 2) {      // the logits as bf16 storage holds them
+        const u32x2 pk = pack_bf16x4(zq[m]);
+        zq[m] = unpack_bf16x4(pk);
+      }
+      z[4 * m] = zq[m][0]; z[4 * m + 1] = zq[m][1]; z[4 * m + 2] = zq[m][2]; z[4 * m + 3] = zq[m][3];
+    }
+    if (logits_out) {
+      T* lp = logits_out + (int64_t)p * C;
+#pragma unroll
+      for (int m = 0; m < C / 4; ++m) Act<T>::gst4(lp + 4 * m, zq[m]);
+    }
+    float mx = z[0];
+    int am = 0;
+#pragma unroll
+    for (int j = 1; j < C; ++j)
+      if (z[j] > mx) { mx = z[j]; am = j; }
+    float se = 0.f;
+    float e[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) { e[j] = __expf(z[j] - mx); se += e[j]; }
+    const int lab = labels[p];
+    const bool lv = (unsigned)lab < (unsigned)C;
+    const float wgt = (lv && in_loss) ? weights[p] : 0.f;
+    if (!lv) ++bad;
+    float zl = 0.f;
+#pragma unroll
+    for (int j = 0; j < C; ++j) zl = (j == lab) ? z[j] : zl;
+    const float lse = mx + __logf(se);
+    local += wgt * (lse - zl);
+    if (dlogits && in_loss) {
+      const float k = grad_scale * wgt * inv_npix;
+      const float inv = 1.f / se;
+      T* dp = dlogits + (int64_t)p * C;
+#pragma unroll
+      for (int j = 0; j < C / 4; ++j) {
+        f32x4 t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) t[q] = k * (e[4 * j + q] * inv - ((4 * j + q) == lab ? 1.f : 0.f));
+        Act<T>::gst4(dp + 4 * j, t);
+      }
+    }
+    if (pred_out) pred_out[p] = am;
+    if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
+  }
+  if (cm) __syncthreads();
+  loss_block_finish(local, bad, cm_lds, C, part, cm, bad_labels);
+}
+
 
 // Mean-teacher consistency cost (src/losses.py:195-215): coef * mean over pixels of mean_c (softmax(teacher) -
 // softmax(student))^2, with its gradient w.r.t. the student logits.  CT > 0 keeps both softmax rows in registers;
@@ -505,6 +614,49 @@ ssmi_status ssmi_softmax_xent_fwd_bwd_bf16(const uint16_t* logits, const int32_t
   return softmax_xent_impl<bf16>(reinterpret_cast<const bf16*>(logits), labels, weights, npix, num_classes, grad_scale,
                                  reinterpret_cast<bf16*>(dlogits), loss_out, cm, npix_metrics, ignore_mask, pred_out, bad_labels,
                                  ws, ws_bytes, stream);
+}
+
+int32_t ssmi_logits_tconv2x2_xent_supported(int32_t cin, int32_t num_classes) { return cin == 16 && num_classes == 24; }
+
+ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int32_t n, int32_t h, int32_t w, int32_t cin,
+                                              int32_t x_ld, const float* kernel, const float* bias, int32_t num_classes,
+                                              const int32_t* labels, const float* weights, int64_t npix, float grad_scale,
+                                              void* logits_out, void* dlogits, float* loss_out, int64_t* cm,
+                                              int64_t npix_metrics, uint64_t ignore_mask, int32_t* pred_out,
+                                              int32_t* bad_labels, void* ws, size_t ws_bytes, void* stream) {
+  SSMI_REQUIRE(x && kernel && labels && weights && loss_out && n > 0 && h > 0 && w > 0 && npix > 0, SSMI_E_INVALID_ARG,
+               "logits_tconv2x2_xent: bad argument");
+  SSMI_REQUIRE(ssmi_logits_tconv2x2_xent_supported(cin, num_classes), SSMI_E_UNSUPPORTED,
+               "logits_tconv2x2_xent: built for 16 input channels and 24 classes (got %d, %d)", cin, num_classes);
+  const int64_t total = (int64_t)n * (2 * h) * (2 * w);
+  SSMI_REQUIRE(npix <= total && npix_metrics >= 0 && npix_metrics <= total, SSMI_E_INVALID_ARG,
+               "logits_tconv2x2_xent: npix / npix_metrics exceed the %lld output pixels", (long long)total);
+  SSMI_REQUIRE(total * num_classes < 0x7FFFFFFFLL / 2 * 2 && x_ld >= cin && x_ld % 4 == 0, SSMI_E_UNSUPPORTED,
+               "logits_tconv2x2_xent: tensor too large for 32-bit pixel indices, or row stride %d not a multiple of 4", x_ld);
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_softmax_xent_workspace_bytes(npix), SSMI_E_WORKSPACE, "logits_tconv2x2_xent: workspace too small");
+  const size_t esz = dtype == SSMI_BF16 ? 2 : 4;
+  SSMI_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(logits_out) | reinterpret_cast<uintptr_t>(dlogits)) &
+                (4 * esz - 1)) == 0, SSMI_E_INVALID_ARG, "logits_tconv2x2_xent: tensors must be aligned to four elements");
+  hipStream_t st = as_stream(stream);
+  const int64_t span = npix_metrics > npix ? npix_metrics : npix;
+  int64_t nb64 = ceil_div64(span, 256);
+  if (nb64 > kLossBlocks) nb64 = kLossBlocks;
+  const int nb = (int)nb64;
+  double* part = reinterpret_cast<double*>(ws);
+  const float inv = (float)(1.0 / (double)npix);
+  const size_t lds = (size_t)(4 * 16 * 24 + 24 + 24 * 24) * sizeof(int);
+  const ssmi_status s = dispatch_dtype(dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL((head2x2_xent_kernel<T, 24, 16>), dim3(nb), dim3(256), lds, st, reinterpret_cast<const T*>(x), x_ld, kernel,
+                       bias, h, w, labels, weights, (int)npix, inv, grad_scale, reinterpret_cast<T*>(logits_out),
+                       reinterpret_cast<T*>(dlogits), part, cm, (int)npix_metrics, ignore_mask, pred_out, bad_labels);
+    SSMI_LAUNCH_CHECK();
+    return SSMI_OK;
+  });
+  if (s) return s;
+  hipLaunchKernelGGL(xent_final, dim3(1), dim3(256), 0, st, part, nb, 1.0 / (double)npix, loss_out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

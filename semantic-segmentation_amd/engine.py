@@ -825,6 +825,23 @@ class LogitsHead(Block):
         self.conv.fwd(x, self.out, cfg.st)
         return self.out
 
+    @property
+    def fusable(self) -> bool:
+        """The transposed convolution can run inside the loss kernel (ssmi_logits_tconv2x2_xent_fwd_bwd)."""
+        return bool(lib().logits_tconv2x2_xent_supported(self.conv.cin, self.num_classes)) and \
+            not os.environ.get("SSMI_NO_FUSED_HEAD")
+
+    def xent_fused(self, x, labels, weights, npix, loss_out, cm, npix_metrics, ignore_bits, bad, ws, st, want_grad, keep_logits):
+        """logits = tconv(x) and the pixelwise cross-entropy on them in ONE launch; the logits tensor is written only when
+        `keep_logits`, the gradient only when `want_grad`."""
+        self.x = x
+        n, h, w, cin = x.shape
+        lib().logits_tconv2x2_xent_fwd_bwd(self.store.dtype_code, _ptr(x), n, h, w, cin, cin, _ptr(self.conv.w), _ptr(self.conv.b),
+                                           self.num_classes, _ptr(labels), _ptr(weights), npix, 1.0,
+                                           _ptr(self.out) if keep_logits else None, _ptr(self.dout) if want_grad else None,
+                                           _ptr(loss_out), _ptr(cm), npix_metrics, ignore_bits, None, _ptr(bad), _ptr(ws),
+                                           ws.numel() * 4, st)
+
     def bwd(self, dout, cfg):
         cfg.wgrad(self.conv, self.x, dout)
         self.conv.bwd_data(dout, self.dx, cfg.st)
@@ -996,7 +1013,9 @@ class GraphBase:
 
     # -- execution ------------------------------------------------------------------------------------
     def forward(self, images: torch.Tensor, training: bool, update_moving: bool = True, unbiased_moving: bool = False,
-                use_dropout: Optional[bool] = None, stream: Optional[int] = None):
+                use_dropout: Optional[bool] = None, stream: Optional[int] = None, fuse_head: bool = False):
+        """`fuse_head`: stop in front of a last layer that the loss kernel computes itself (LogitsHead.xent_fused); the
+        return value is then that layer's input and `logits` stays unwritten unless the loss call is told to keep it."""
         n, h, w, c = images.shape
         assert c == 3 and images.dtype == torch.float32 and images.is_contiguous()
         self.plan(n, h, w)
@@ -1020,8 +1039,12 @@ class GraphBase:
         if not training and sto.n_state:
             lib().bn_infer_stats_arena(_ptr(sto.state), _ptr(sto.var_mask), sto.n_state, BN_EPS, _ptr(sto.bn_stats), st)
         x = images
-        for b in self.blocks:
+        head = self.blocks[-1]
+        fused = fuse_head and isinstance(head, LogitsHead) and head.fusable
+        for b in (self.blocks[:-1] if fused else self.blocks):
             x = b.fwd(x, cfg)
+        self.head_input = x if fused else None
+        self.logits_valid = not fused
         self._cfg = cfg
         return x
 
@@ -1042,6 +1065,9 @@ class GraphBase:
 
     @property
     def logits(self):
+        if not getattr(self, "logits_valid", True):
+            raise RuntimeError("the last step computed the logits inside the loss kernel and did not store them; "
+                               "set model.keep_logits = True to have them written")
         return self.blocks[-1].out
 
     @property

@@ -87,6 +87,7 @@ class ExtendedModel(object):
         self._graphs: Dict[tuple, list] = {}
         self._seed = 14874
         self._unbiased_moving_variance = False
+        self._keep_logits = False
         self.use_hip_graph = True
         self.grad_sync = None          # trainers.GradientBucketReducer when data-parallel
         self._timed_steps = None       # list of per-step event records while segment_timing(True)
@@ -113,6 +114,19 @@ class ExtendedModel(object):
         if int(v) != self._seed:
             self._clear_graphs()
         self._seed = int(v)
+
+    @property
+    def keep_logits(self):
+        """Training / evaluation steps of the ENets compute the logits inside the loss kernel and do not store them (nothing
+        in the reference's step reads them: src/keras_extensions/extended_model.py:1002).  True has the same kernel write
+        them to `graph.logits` as well (tests, debugging).  predict_on_batch always stores them."""
+        return self._keep_logits
+
+    @keep_logits.setter
+    def keep_logits(self, v):
+        if bool(v) != self._keep_logits:
+            self._clear_graphs()
+        self._keep_logits = bool(v)
 
     @property
     def unbiased_moving_variance(self):
@@ -426,13 +440,22 @@ class ExtendedModel(object):
                 return
             if self.mean_teacher or self.superpixel:
                 return loss_call_semi(st, want_grad)
+            if getattr(g, "head_input", None) is not None:
+                # the last layer runs inside the loss kernel; its output is stored only on request
+                g.blocks[-1].xent_fused(g.head_input, self.labels_buf, self.weights_buf, npix, self._loss_buf, self._cm, npix_m,
+                                        self._ignore_bits, self._bad, g.ws, st, want_grad, self.keep_logits)
+                g.logits_valid = bool(self.keep_logits)
+                return
             L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npix, C_, 1.0,
                                    _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), _ptr(self._cm), npix_m,
                                    self._ignore_bits, None, _ptr(self._bad), _ptr(g.ws), g.ws.numel() * 4, st)
 
+        # supervised segmentation loss: the last layer of the ENets runs inside the loss kernel (engine.LogitsHead.xent_fused)
+        fuse_head = not (self.classification or self.mean_teacher or self.superpixel)
+
         if not training:
             def seg_eval(st):
-                g.forward(self.images_buf, training=False, stream=st)
+                g.forward(self.images_buf, training=False, stream=st, fuse_head=fuse_head)
                 loss_call(st, False)
             return [seg_eval]
 
@@ -446,7 +469,7 @@ class ExtendedModel(object):
             if g.drop_groups:
                 g.refresh_dropout(self.seed, self.optimizer.step_block, stream=st)
             g.forward(self.images_buf, training=True, update_moving=True, unbiased_moving=self.unbiased_moving_variance,
-                      stream=st)
+                      stream=st, fuse_head=fuse_head)
             loss_call(st, True)
             carry["d"] = g.dlogits
             seg_bwd(0)(st)

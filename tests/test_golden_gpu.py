@@ -115,6 +115,7 @@ def test_training_step_vectors(model):
     m.compile(optimizer=opt.SGD(lr=0.0), loss={'loss': losses.dummy_loss, 'logits': lambda t, p: 0 * p},
               loss_weights={'loss': 1.0, 'logits': 0.0})
     m.use_hip_graph = False
+    m.keep_logits = True
     m._ensure_buffers(B, H, W)
     gr = m.graph
     gr.drop_groups = []

@@ -100,6 +100,7 @@ def _run_case(model_name, B, H, W, seed, steps=2, smooth=False, monkeypatch=None
             monkeypatch.setattr(pkg("engine_unet"), "LEAKY_ALPHA", 1.0)
     mb = models.get_model(model_name, (None, None, 3), nc, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
     model = mb.model
+    model.keep_logits = True      # the ENet steps compute the logits inside the loss kernel; this test compares them
     assert model.weight_names() == list(w0.keys())
     model.set_weights([w0[k] for k in model.weight_names()])
     adam = dict(lr=5e-4, beta_1=0.9, beta_2=0.999, eps=1e-8)
