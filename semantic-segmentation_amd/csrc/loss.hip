@@ -174,7 +174,7 @@ __global__ void xent_final(const double* __restrict__ part, int nblocks, double 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int C, int CIN>
 __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, int hin, int win,
+                                                           const float* __restrict__ bias, int nimg, int hin, int win,
                                                            const int32_t* __restrict__ labels, const float* __restrict__ weights,
                                                            int npix, float inv_npix, float grad_scale, T* __restrict__ logits_out,
                                                            T* __restrict__ dlogits, double* __restrict__ part,
@@ -197,74 +197,106 @@ __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__
   float local = 0.f;
   int bad = 0;
   const int nloop = npix_metrics > npix ? npix_metrics : npix;
-  for (int p = blockIdx.x * 256 + threadIdx.x; p < nloop; p += gridDim.x * 256) {
-    const bool in_loss = p < npix;
-    const int row = p / wout, ox = p - row * wout;
+  // A thread owns two output pixels of one row that share a tap: columns ox and ox + 2 (input columns 2 q and 2 q + 1), so
+  // every kernel word read from LDS feeds two pixels.  Work item g -> (row, q, tx): consecutive lanes alternate tx.
+  const int npair = (win + 1) >> 1;
+  const int nwork = nimg * hout * npair * 2;
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < nwork; g += gridDim.x * 256) {
+    const int tx = g & 1, pr = g >> 1;
+    const int row = pr / npair, q = pr - row * npair;
     const int img = row / hout, oy = row - img * hout;
-    const T* xp = x + (int64_t)((img * hin + (oy >> 1)) * win + (ox >> 1)) * x_ld;
-    float xv[CIN];
+    const int pa = row * wout + 4 * q + tx;               // pixel indices in the order of the label / logits tensors
+    const bool hasb = 2 * q + 1 < win;
+    if (pa >= nloop) continue;
+    const T* xp = x + (int64_t)((img * hin + (oy >> 1)) * win + 2 * q) * x_ld;
+    float xa[CIN], xb[CIN];
 #pragma unroll
     for (int j = 0; j < CIN / 4; ++j) {
       const f32x4 t = Act<T>::gld4(xp + 4 * j);
-      xv[4 * j] = t[0]; xv[4 * j + 1] = t[1]; xv[4 * j + 2] = t[2]; xv[4 * j + 3] = t[3];
+      xa[4 * j] = t[0]; xa[4 * j + 1] = t[1]; xa[4 * j + 2] = t[2]; xa[4 * j + 3] = t[3];
     }
-    const float* wt = wl + (((oy & 1) * 2 + (ox & 1)) * CIN) * C;
-    f32x4 zq[C / 4];
+    const T* xq = hasb ? xp + x_ld : xp;
 #pragma unroll
-    for (int m = 0; m < C / 4; ++m) zq[m] = *reinterpret_cast<const f32x4*>(bl + 4 * m);
+    for (int j = 0; j < CIN / 4; ++j) {
+      const f32x4 t = Act<T>::gld4(xq + 4 * j);
+      xb[4 * j] = t[0]; xb[4 * j + 1] = t[1]; xb[4 * j + 2] = t[2]; xb[4 * j + 3] = t[3];
+    }
+    const float* wt = wl + (((oy & 1) * 2 + tx) * CIN) * C;
+    f32x4 za[C / 4], zb[C / 4];
+#pragma unroll
+    for (int m = 0; m < C / 4; ++m) za[m] = zb[m] = *reinterpret_cast<const f32x4*>(bl + 4 * m);
+    // kernel words of input channel ci + 1 are fetched while channel ci is multiplied; the scheduling barrier keeps the
+    // compiler from hoisting all 96 LDS reads in front of the first multiply (which took 500 registers)
+    f32x4 wv[2][C / 4];
+#pragma unroll
+    for (int m = 0; m < C / 4; ++m) wv[0][m] = *reinterpret_cast<const f32x4*>(wt + 4 * m);
 #pragma unroll
     for (int ci = 0; ci < CIN; ++ci) {
-      const f32x4 xs = {xv[ci], xv[ci], xv[ci], xv[ci]};
+      if (ci + 1 < CIN) {
 #pragma unroll
-      for (int m = 0; m < C / 4; ++m)
-        zq[m] = __builtin_elementwise_fma(xs, *reinterpret_cast<const f32x4*>(wt + ci * C + 4 * m), zq[m]);
-    }
-    float z[C];
-#pragma unroll
-    for (int m = 0; m < C / 4; ++m) {
-      if constexpr (sizeof(T) == 2) {      // the logits as bf16 storage holds them
-        const u32x2 pk = pack_bf16x4(zq[m]);
-        zq[m] = unpack_bf16x4(pk);
+        for (int m = 0; m < C / 4; ++m) wv[(ci + 1) & 1][m] = *reinterpret_cast<const f32x4*>(wt + (ci + 1) * C + 4 * m);
       }
-      z[4 * m] = zq[m][0]; z[4 * m + 1] = zq[m][1]; z[4 * m + 2] = zq[m][2]; z[4 * m + 3] = zq[m][3];
-    }
-    if (logits_out) {
-      T* lp = logits_out + (int64_t)p * C;
+      const f32x4 sa = {xa[ci], xa[ci], xa[ci], xa[ci]}, sb = {xb[ci], xb[ci], xb[ci], xb[ci]};
 #pragma unroll
-      for (int m = 0; m < C / 4; ++m) Act<T>::gst4(lp + 4 * m, zq[m]);
-    }
-    float mx = z[0];
-    int am = 0;
-#pragma unroll
-    for (int j = 1; j < C; ++j)
-      if (z[j] > mx) { mx = z[j]; am = j; }
-    float se = 0.f;
-    float e[C];
-#pragma unroll
-    for (int j = 0; j < C; ++j) { e[j] = __expf(z[j] - mx); se += e[j]; }
-    const int lab = labels[p];
-    const bool lv = (unsigned)lab < (unsigned)C;
-    const float wgt = (lv && in_loss) ? weights[p] : 0.f;
-    if (!lv) ++bad;
-    float zl = 0.f;
-#pragma unroll
-    for (int j = 0; j < C; ++j) zl = (j == lab) ? z[j] : zl;
-    const float lse = mx + __logf(se);
-    local += wgt * (lse - zl);
-    if (dlogits && in_loss) {
-      const float k = grad_scale * wgt * inv_npix;
-      const float inv = 1.f / se;
-      T* dp = dlogits + (int64_t)p * C;
-#pragma unroll
-      for (int j = 0; j < C / 4; ++j) {
-        f32x4 t;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) t[q] = k * (e[4 * j + q] * inv - ((4 * j + q) == lab ? 1.f : 0.f));
-        Act<T>::gst4(dp + 4 * j, t);
+      for (int m = 0; m < C / 4; ++m) {
+        za[m] = __builtin_elementwise_fma(sa, wv[ci & 1][m], za[m]);
+        zb[m] = __builtin_elementwise_fma(sb, wv[ci & 1][m], zb[m]);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (pred_out) pred_out[p] = am;
-    if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
+    // the second pixel's logits are used under a condition only; without this the compiler moves their multiplies into
+    // that branch, behind all the kernel words
+#pragma unroll
+    for (int m = 0; m < C / 4; ++m) asm volatile("" : "+v"(zb[m]));
+    // the loss arithmetic of xent_kernel on one pixel's logits
+    auto pixel = [&](f32x4 (&zq)[C / 4], int p) {
+      const bool in_loss = p < npix;
+      float z[C];
+#pragma unroll
+      for (int m = 0; m < C / 4; ++m) {
+        if constexpr (sizeof(T) == 2) zq[m] = unpack_bf16x4(pack_bf16x4(zq[m]));      // the logits as bf16 storage holds them
+        z[4 * m] = zq[m][0]; z[4 * m + 1] = zq[m][1]; z[4 * m + 2] = zq[m][2]; z[4 * m + 3] = zq[m][3];
+      }
+      if (logits_out) {
+        T* lp = logits_out + (int64_t)p * C;
+#pragma unroll
+        for (int m = 0; m < C / 4; ++m) Act<T>::gst4(lp + 4 * m, zq[m]);
+      }
+      float mx = z[0];
+      int am = 0;
+#pragma unroll
+      for (int j = 1; j < C; ++j)
+        if (z[j] > mx) { mx = z[j]; am = j; }
+      float se = 0.f;
+      float e[C];
+#pragma unroll
+      for (int j = 0; j < C; ++j) { e[j] = __expf(z[j] - mx); se += e[j]; }
+      const int lab = labels[p];
+      const bool lv = (unsigned)lab < (unsigned)C;
+      const float wgt = (lv && in_loss) ? weights[p] : 0.f;
+      if (!lv) ++bad;
+      float zl = 0.f;
+#pragma unroll
+      for (int j = 0; j < C; ++j) zl = (j == lab) ? z[j] : zl;
+      const float lse = mx + __logf(se);
+      local += wgt * (lse - zl);
+      if (dlogits && in_loss) {
+        const float k = grad_scale * wgt * inv_npix;
+        const float inv = 1.f / se;
+        T* dp = dlogits + (int64_t)p * C;
+#pragma unroll
+        for (int j = 0; j < C / 4; ++j) {
+          f32x4 t;
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) t[q4] = k * (e[4 * j + q4] * inv - ((4 * j + q4) == lab ? 1.f : 0.f));
+          Act<T>::gst4(dp + 4 * j, t);
+        }
+      }
+      if (pred_out) pred_out[p] = am;
+      if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
+    };
+    pixel(za, pa);
+    if (hasb && pa + 2 < nloop) pixel(zb, pa + 2);
   }
   if (cm) __syncthreads();
   loss_block_finish(local, bad, cm_lds, C, part, cm, bad_labels);
@@ -638,8 +670,7 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
   SSMI_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(logits_out) | reinterpret_cast<uintptr_t>(dlogits)) &
                 (4 * esz - 1)) == 0, SSMI_E_INVALID_ARG, "logits_tconv2x2_xent: tensors must be aligned to four elements");
   hipStream_t st = as_stream(stream);
-  const int64_t span = npix_metrics > npix ? npix_metrics : npix;
-  int64_t nb64 = ceil_div64(span, 256);
+  int64_t nb64 = ceil_div64((int64_t)n * 2 * h * ((w + 1) / 2) * 2, 256);      // work items: two pixels of a row each
   if (nb64 > kLossBlocks) nb64 = kLossBlocks;
   const int nb = (int)nb64;
   double* part = reinterpret_cast<double*>(ws);
@@ -648,7 +679,7 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
   const ssmi_status s = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
     hipLaunchKernelGGL((head2x2_xent_kernel<T, 24, 16>), dim3(nb), dim3(256), lds, st, reinterpret_cast<const T*>(x), x_ld, kernel,
-                       bias, h, w, labels, weights, (int)npix, inv, grad_scale, reinterpret_cast<T*>(logits_out),
+                       bias, n, h, w, labels, weights, (int)npix, inv, grad_scale, reinterpret_cast<T*>(logits_out),
                        reinterpret_cast<T*>(dlogits), part, cm, (int)npix_metrics, ignore_mask, pred_out, bad_labels);
     SSMI_LAUNCH_CHECK();
     return SSMI_OK;

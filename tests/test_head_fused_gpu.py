@@ -4,8 +4,8 @@ Conv2DTranspose(24, (2, 2), strides 2, 'same') (src/models.py:1318) + the weight
 
 Checked against (1) the CPU oracle (float64 transposed convolution + loss), tolerance 1e-3 as for every float32 operator,
 and (2) the two-call route of the same library: the logits the fused kernel stores, fed to ssmi_softmax_xent_fwd_bwd, must
-give the SAME bits for loss, gradient, matrix and predictions (the arithmetic behind the logits is one piece of code), and
-must agree with ssmi_conv2d_transpose_fwd to float32 / bfloat16 rounding."""
+give the SAME bits for gradient, matrix and predictions (the arithmetic behind the logits is one piece of code) and the
+same loss up to the order of its summation over pixels, and must agree with ssmi_conv2d_transpose_fwd to float32 / bfloat16 rounding."""
 import ctypes as C
 
 import numpy as np
@@ -88,7 +88,8 @@ def _run(dtype, N, H, W, npix_metrics_frac, with_outputs, seed):
                                 t["loss"].data_ptr(), t["cm"].data_ptr(), npix_m, ignore_bits, t["pred"].data_ptr(),
                                 t["bad"].data_ptr(), ws.data_ptr(), ws.numel() * 4, st)
         torch.cuda.synchronize()
-        assert torch.equal(t["loss"], f["loss"])
+        # (the loss itself is a sum over pixels taken in a different order: equal to float32 summation error)
+        assert abs(float(t["loss"].item()) - float(f["loss"].item())) <= 2e-6 * abs(float(t["loss"].item()))
         assert torch.equal(t["dlogits"].view(torch.int16 if bf else torch.int32), f["dlogits"].view(torch.int16 if bf else torch.int32))
         assert torch.equal(t["cm"], f["cm"]) and torch.equal(t["pred"], f["pred"])
         assert int(f["cm"].sum().item()) == int(((labels.reshape(-1)[:npix_m] < NC) & (labels.reshape(-1)[:npix_m] != 0)).sum())
