@@ -172,7 +172,8 @@ __global__ void xent_final(const double* __restrict__ part, int nblocks, double 
 // bf16 storage: the logits are rounded to bf16 before the loss sees them - the stored logits, when requested, are the
 // values the loss, the argmax and the gradient were computed from, as in the two-kernel form.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int C, int CIN>
+// GRAD = false: the evaluation form (no gradient, no staging block; dlogits is ignored).
+template <typename T, int C, int CIN, bool GRAD>
 __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__ x, int x_ld, const float* __restrict__ w,
                                                            const float* __restrict__ bias, int nimg, int hin, int win,
                                                            const int32_t* __restrict__ labels, const float* __restrict__ weights,
@@ -184,6 +185,10 @@ __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__
   float* wl = reinterpret_cast<float*>(head_lds);            // [4][CIN][C]
   float* bl = wl + 4 * CIN * C;                               // [C]
   int* cm_lds = head_lds + 4 * CIN * C + C;                   // [C][C]
+  // gradient rows on their way out, per wave: [64 pixels][C] floats + the pixels' indices (see `pixel` below)
+  float* stg = reinterpret_cast<float*>(cm_lds + C * C) + (threadIdx.x >> 6) * (64 * C + 64);
+  int* stp = reinterpret_cast<int*>(stg + 64 * C);
+  const int lane = threadIdx.x & 63;
   static_assert(C % 4 == 0 && CIN % 4 == 0, "16-byte accesses");
   for (int e = threadIdx.x; e < 4 * C * CIN; e += 256) {
     const int tap = e / (C * CIN), rem = e % (C * CIN), co = rem / CIN, ci = rem % CIN;
@@ -201,13 +206,16 @@ __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__
   // every kernel word read from LDS feeds two pixels.  Work item g -> (row, q, tx): consecutive lanes alternate tx.
   const int npair = (win + 1) >> 1;
   const int nwork = nimg * hout * npair * 2;
-  for (int g = blockIdx.x * 256 + threadIdx.x; g < nwork; g += gridDim.x * 256) {
+  // (whole waves walk the loop together: the lanes of a wave hand their gradient rows to each other, below)
+  for (int g0 = blockIdx.x * 256 + (threadIdx.x & ~63); g0 < nwork; g0 += gridDim.x * 256) {
+    const bool act0 = g0 + lane < nwork;
+    const int g = act0 ? g0 + lane : 0;
     const int tx = g & 1, pr = g >> 1;
     const int row = pr / npair, q = pr - row * npair;
     const int img = row / hout, oy = row - img * hout;
     const int pa = row * wout + 4 * q + tx;               // pixel indices in the order of the label / logits tensors
     const bool hasb = 2 * q + 1 < win;
-    if (pa >= nloop) continue;
+    const bool act = act0 && pa < nloop;
     const T* xp = x + (int64_t)((img * hin + (oy >> 1)) * win + 2 * q) * x_ld;
     float xa[CIN], xb[CIN];
 #pragma unroll
@@ -244,10 +252,10 @@ __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // the second pixel's logits are used under a condition only; without this the compiler moves their multiplies into
-    // that branch, behind all the kernel words
+    // the logits are used under conditions only; without this the compiler moves their multiplies into those branches,
+    // behind all the kernel words
 #pragma unroll
-    for (int m = 0; m < C / 4; ++m) asm volatile("" : "+v"(zb[m]));
+    for (int m = 0; m < C / 4; ++m) asm volatile("" : "+v"(za[m]), "+v"(zb[m]));
     // the loss arithmetic of xent_kernel on one pixel's logits
     auto pixel = [&](f32x4 (&zq)[C / 4], int p) {
       const bool in_loss = p < npix;
@@ -280,23 +288,41 @@ __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__
       for (int j = 0; j < C; ++j) zl = (j == lab) ? z[j] : zl;
       const float lse = mx + __logf(se);
       local += wgt * (lse - zl);
-      if (dlogits && in_loss) {
+      if (GRAD && in_loss) {
         const float k = grad_scale * wgt * inv_npix;
         const float inv = 1.f / se;
-        T* dp = dlogits + (int64_t)p * C;
 #pragma unroll
         for (int j = 0; j < C / 4; ++j) {
           f32x4 t;
 #pragma unroll
           for (int q4 = 0; q4 < 4; ++q4) t[q4] = k * (e[4 * j + q4] * inv - ((4 * j + q4) == lab ? 1.f : 0.f));
-          Act<T>::gst4(dp + 4 * j, t);
+          *reinterpret_cast<f32x4*>(stg + lane * C + 4 * j) = t;
         }
+        stp[lane] = p;
       }
       if (pred_out) pred_out[p] = am;
       if (cm && lv && p < npix_metrics && !((ignore_mask >> lab) & 1ull)) atomicAdd(&cm_lds[lab * C + am], 1);
     };
-    pixel(za, pa);
-    if (hasb && pa + 2 < nloop) pixel(zb, pa + 2);
+    // Gradient rows leave through the wave's LDS block: a lane's row is C consecutive floats, so stored straight from
+    // the registers every store instruction would touch 64 different cache lines with 16 bytes each; read back chunk by
+    // chunk (lane l takes 16-byte chunks l, l + 64, ... of the 64 rows) consecutive lanes write consecutive addresses
+    // within a row and within the two neighbouring rows of a lane pair.
+    auto flush = [&]() {
+      if (!GRAD) return;
+#pragma unroll
+      for (int k = 0; k < C / 4; ++k) {
+        const int c = lane + 64 * k, pi = c / (C / 4), part = c - pi * (C / 4);
+        const int pp = stp[pi];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(stg + pi * C + 4 * part);
+        if (pp >= 0) Act<T>::gst4(dlogits + (int64_t)pp * C + 4 * part, v);
+      }
+    };
+    if (GRAD) stp[lane] = -1;
+    if (act) pixel(za, pa);
+    flush();
+    if (GRAD) stp[lane] = -1;
+    if (act && hasb && pa + 2 < nloop) pixel(zb, pa + 2);
+    flush();
   }
   if (cm) __syncthreads();
   loss_block_finish(local, bad, cm_lds, C, part, cm, bad_labels);
@@ -675,12 +701,17 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
   const int nb = (int)nb64;
   double* part = reinterpret_cast<double*>(ws);
   const float inv = (float)(1.0 / (double)npix);
-  const size_t lds = (size_t)(4 * 16 * 24 + 24 + 24 * 24) * sizeof(int);
+  const size_t lds_eval = (size_t)(4 * 16 * 24 + 24 + 24 * 24) * sizeof(int), lds_grad = lds_eval + (size_t)4 * (64 * 24 + 64) * sizeof(int);
   const ssmi_status s = dispatch_dtype(dtype, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL((head2x2_xent_kernel<T, 24, 16>), dim3(nb), dim3(256), lds, st, reinterpret_cast<const T*>(x), x_ld, kernel,
-                       bias, n, h, w, labels, weights, (int)npix, inv, grad_scale, reinterpret_cast<T*>(logits_out),
-                       reinterpret_cast<T*>(dlogits), part, cm, (int)npix_metrics, ignore_mask, pred_out, bad_labels);
+    if (dlogits)
+      hipLaunchKernelGGL((head2x2_xent_kernel<T, 24, 16, true>), dim3(nb), dim3(256), lds_grad, st, reinterpret_cast<const T*>(x), x_ld,
+                         kernel, bias, n, h, w, labels, weights, (int)npix, inv, grad_scale, reinterpret_cast<T*>(logits_out),
+                         reinterpret_cast<T*>(dlogits), part, cm, (int)npix_metrics, ignore_mask, pred_out, bad_labels);
+    else
+      hipLaunchKernelGGL((head2x2_xent_kernel<T, 24, 16, false>), dim3(nb), dim3(256), lds_eval, st, reinterpret_cast<const T*>(x), x_ld,
+                         kernel, bias, n, h, w, labels, weights, (int)npix, inv, grad_scale, reinterpret_cast<T*>(logits_out),
+                         reinterpret_cast<T*>(dlogits), part, cm, (int)npix_metrics, ignore_mask, pred_out, bad_labels);
     SSMI_LAUNCH_CHECK();
     return SSMI_OK;
   });
