@@ -34,7 +34,18 @@ static Geo to_geo(const ssmi_conv_desc* d) {
 
 struct Sizes {
   unsigned x_bytes, y_bytes, w_bytes;   // byte sizes of the x-like, y-like and kernel tensors
+  int xcd;                              // 1: workgroups take tiles through xcd_tile() (below)
 };
+
+// Workgroups are dealt to the eight XCDs round-robin - b and b + 8 share an XCD, and with it an L2 -, so with tile = b the
+// eight neighbours of a pixel tile sit behind eight different L2s and every halo row of a multi-tap layer is fetched from
+// HBM once per XCD that touches it.  Here the workgroups of one XCD take a CONTIGUOUS range of the n tiles (a bijection
+// for any n), so halo rows are shared in that XCD's L2.  Speed only: nothing depends on where a workgroup runs.
+__device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n, int on) {
+  if (!on) return b;
+  const unsigned q = n >> 3, r = n & 7u, x = b & 7u;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // forward: y[p, co] = bias[co] + sum_{tap, ci} x[pix(p, tap), ci] * w[tap, ci, co]
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int64_t tile0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x, sz.xcd & 1) * 4 + wave) * 32;
   bool lds_b = false;
   if constexpr (kLdsB) lds_b = bn.wpack != nullptr && bn.lds_b != 0;      // uniform
   // with statistics, or kernel rows staged by the whole workgroup, every wave reaches the barriers (its rows are masked)
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 5 : (NT == 2 ? 4 : 2))) void conv_b
   const int qh = (g.h - pa + s - 1) / s, qw = (g.w - pb + s - 1) / s;
   if (qh <= 0 || qw <= 0) return;
   const int64_t M = (int64_t)g.n * qh * qw;
-  const int64_t tile0 = ((int64_t)blockIdx.x * 4 + wave) * 32;
+  const int64_t tile0 = ((int64_t)xcd_tile(blockIdx.x, gridDim.x, sz.xcd & 2) * 4 + wave) * 32;
   if (tile0 >= M && bb.x == nullptr) return;   // with the fused BN backward every wave reaches the barrier
   const __amdgpu_buffer_rsrc_t ry = Act<T>::rsrc(dy, sz.y_bytes), rw = make_rsrc(w, sz.w_bytes);
   const int cbase = blockIdx.y * 32 * NT;
@@ -842,7 +853,8 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   static_assert(!TILE || (MT * TS == 64 && NT == 1 && VEC), "tile variant: 64 pixels per wave, one column tile");
   float* patch = smem + a.patch_off;
   const int64_t nloop = TILE ? (int64_t)g.n * a.tiles_y * a.tiles_x : ngroups;
-  for (int64_t grp = TILE ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * 4 + wave; grp < nloop;
+  const int64_t bxt = (int64_t)xcd_tile(blockIdx.x, gridDim.x, sz.xcd & 4);
+  for (int64_t grp = TILE ? bxt : bxt * 4 + wave; grp < nloop;
        grp += TILE ? (int64_t)gridDim.x : (int64_t)gridDim.x * 4) {
     const int64_t tile0 = grp * (MT * TS);
     bool pv[MT];
@@ -1229,7 +1241,7 @@ __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, co
     }
   };
 
-  int64_t grp = (int64_t)blockIdx.x * 4 + wave;
+  int64_t grp = (int64_t)xcd_tile(blockIdx.x, gridDim.x, sz.xcd & 4) * 4 + wave;
   const int64_t gstep = (int64_t)gridDim.x * 4;
   fetch(grp);
   for (; grp < ngroups; grp += gstep) {
@@ -1485,7 +1497,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
   constexpr int KQ = 64 / TS;            // pixels consumed per MFMA step
   constexpr int NR = M16 ? 4 : 16;       // accumulator registers per tile
   const int r = lane & (TS - 1), hh = lane / TS;
-  const int strip = blockIdx.x;
+  const int strip = (int)xcd_tile(blockIdx.x, gridDim.x, sz.xcd & 8);      // neighbouring strips share the halo rows of their patches
   const int tile0 = blockIdx.y * (a.wps * TPW) + wave;
   const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, sz.x_bytes), ry = Act<T>::rsrc(dy, sz.y_bytes);
   constexpr int EW = VEC ? 4 : 1;   // floats per staged element
@@ -1743,7 +1755,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds_bf16(Geo g, Sizes sz,
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int strip = blockIdx.x;
+  const int strip = (int)xcd_tile(blockIdx.x, gridDim.x, sz.xcd & 8);
   const int tile0 = blockIdx.y * (a.wps * TPW) + wave;
   const __amdgpu_buffer_rsrc_t rx = Act<bf16>::rsrc(x, sz.x_bytes), ry = Act<bf16>::rsrc(dy, sz.y_bytes);
 
@@ -2165,6 +2177,9 @@ static ssmi_status make_sizes(const Geo& g, Sizes* sz) {
   SSMI_REQUIRE(xb < 0x7FFFFFFFLL && yb < 0x7FFFFFFFLL && wb < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
                "conv: tensors of 2 GiB or more are not supported (x %lld B, y %lld B)", (long long)xb, (long long)yb);
   sz->x_bytes = (unsigned)xb; sz->y_bytes = (unsigned)yb; sz->w_bytes = (unsigned)wb;
+  // measurement switch, a bit per kernel family: 1 forward, 2 gather-form data gradient, 4 <=16-channel GEMMs, 8 weight-gradient strips
+  static const int xcd_mask = [] { const char* e = getenv("SSMI_XCD_TILES"); return e ? atoi(e) : 0; }();
+  sz->xcd = xcd_mask;
   return SSMI_OK;
 }
 
