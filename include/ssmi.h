@@ -90,6 +90,14 @@ typedef struct ssmi_conv_desc {
   const void* w_dgrad_pack;
 } ssmi_conv_desc;
 
+/* Per-channel statistics and parameters of a BatchNormalization as the kernels consume them (float32 device vectors). */
+typedef struct ssmi_bn_params {
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+} ssmi_bn_params;
+
 /* TF SAME padding rule: out = ceil(in/stride); total = max((out-1)*stride + (k-1)*dil + 1 - in, 0);
  * before = total/2.  Host-only helper. */
 ssmi_status ssmi_same_pad(int32_t in, int32_t k, int32_t stride, int32_t dil, int32_t* out, int32_t* pad_before);
@@ -124,6 +132,25 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, con
                                      float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
                                      float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes,
                                      void* stream);
+
+/* Normalise on load: the 1x1 expansion of a bottleneck (src/models.py:1138-1147: BatchNormalization -> PReLU -> Conv2D 1x1)
+ * with the BatchNormalization + PReLU applied to the operand inside the convolution kernels, so that the normalised tensor is
+ * never stored: x_raw is the RAW input of that BatchNormalization (the previous convolution's output), `pre` its final
+ * statistics and parameters (training phase: save_mean / save_invstd), pre_alpha the PReLU slopes (NULL: no activation).
+ *   ssmi_conv2d_fwd_bn_stats_prebn(d, x_raw, ...)  == ssmi_conv2d_fwd_bn_stats(d, ssmi_bn_act_fwd(x_raw), ...)
+ *   ssmi_conv2d_bwd_weight_prebn(d, x_raw, ...)    == ssmi_conv2d_bwd_weight(d, ssmi_bn_act_fwd(x_raw), ...)
+ * bit for bit (the same arithmetic per element).  float32 tensors, 1x1 stride-1 layers over 8..64 input channels (multiple
+ * of 8) with more than 32 output channels whose weight gradient takes one tile per wave: ssmi_conv2d_prebn_supported says
+ * whether a layer qualifies; others return SSMI_E_UNSUPPORTED.  The data gradient of the layer is unchanged (it produces
+ * the gradient of the normalised tensor, which ssmi_conv2d_bwd_data_bn_bwd pushes through the BatchNormalization). */
+int32_t ssmi_conv2d_prebn_supported(const ssmi_conv_desc* d, int32_t with_bias);
+ssmi_status ssmi_conv2d_fwd_bn_stats_prebn(const ssmi_conv_desc* d, const void* x_raw, const ssmi_bn_params* pre,
+                                           const float* pre_alpha, const float* w, const float* bias, void* y, float eps,
+                                           float momentum, int32_t unbiased_moving, float* moving_mean, float* moving_var,
+                                           float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
+ssmi_status ssmi_conv2d_bwd_weight_prebn(const ssmi_conv_desc* d, const void* x_raw, const ssmi_bn_params* pre,
+                                         const float* pre_alpha, const void* dy, float* dw, float* dbias, void* ws,
+                                         size_t ws_bytes, void* stream);
 
 /* Gradient w.r.t. x (tf.gradients through Conv2D).  dx[n,h,w,cin] (pixel stride x_ld) is fully overwritten:
  * dx = conv_bwd_data(dy, w) + (add ? add : 0), where `add` (nullable) has the layout of dx.  The `add` operand
@@ -265,13 +292,6 @@ typedef struct ssmi_merge_desc {
   int32_t c_other;
   int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of main, other, out and their gradients */
 } ssmi_merge_desc;
-
-typedef struct ssmi_bn_params {
-  const float* mean;
-  const float* invstd;
-  const float* gamma;
-  const float* beta;
-} ssmi_bn_params;
 
 ssmi_status ssmi_merge_fwd(const ssmi_merge_desc* d, const void* main, const ssmi_bn_params* bn3, const float* drop,
                            const void* other, const ssmi_bn_params* bn_other, const int32_t* idx, const float* alpha,

@@ -67,7 +67,21 @@ struct BnBwdArgs {
   // bfloat16 storage only: the kernel as a bfloat16 pack [tap][cout][cin] (nullptr: float32 kernel words, fp32 MFMA)
   const void* wpack;
   int lds_b;               // with wpack, wide layers: the workgroup stages the kernel rows through LDS (set by the launcher)
+  // forward, PRE instantiations only: the convolution's input is act(BN(x)) of the raw tensor x it is given, applied to
+  // the operand on its way into the matrix core (a 1x1 convolution behind a training-phase BatchNormalization + PReLU:
+  // the normalised tensor is never stored).  pre[0..4] = mean, invstd, gamma, beta, alpha (alpha nullptr: no activation)
+  const float* pre[5];
 };
+
+// Per-channel parameters of a BatchNormalization + PReLU whose output a kernel forms on the fly from the raw tensor
+// (PRE instantiations of conv_fwd_kernel / conv_bwd_weight_lds); same arithmetic as bn_act_fwd_kernel.
+struct PreBn {
+  const float *mean, *invstd, *gamma, *beta, *alpha;      // alpha nullptr: no activation
+};
+__device__ __forceinline__ float pre_bn_act(float x, float m, float is, float g, float b, float a, bool act) {
+  const float z = g * ((x - m) * is) + b;
+  return (!act || z > 0.f) ? z : a * z;
+}
 
 // Finalises part[rows][3][c] into dgamma / dbeta / dalpha and runs the apply pass (bn.hip).  coef: 3*c floats of scratch.
 template <typename T>

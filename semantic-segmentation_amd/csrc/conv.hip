@@ -59,11 +59,22 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n, int on) {
 // grown the kernel past 96 registers and 9-11 of them lived in scratch (with 4: ENet bf16 step 7.90 -> 7.68 ms) -
 // check `.vgpr_spill_count` / `.private_segment_fixed_size` of the listing after every change to this kernel.  The strip
 // and tiled weight-gradient kernels measured slower with such bounds (spills, or no gain) and keep the default.
-template <typename T, int NT, bool VEC>
+// PRE (float32 tensors, VEC, 1x1 stride 1, cin <= 64, statistics epilogue): the operand is act(BN(x)), formed from the raw
+// x when a step is multiplied (bn.pre; parameters of the <= 64 input channels through LDS).  Its own instantiation, so
+// that the plain kernels keep their register counts.
+template <typename T, int NT, bool VEC, bool PRE = false>
 __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 3 * NT * 32];
+  __shared__ __attribute__((aligned(16))) float pre_sm[PRE ? 5 * 64 : 4];
+  if constexpr (PRE) {      // every wave reaches this barrier (PRE launches always carry the statistics epilogue)
+    for (int e = threadIdx.x; e < 5 * g.cin; e += 256) {
+      const int k = e / g.cin, c = e - k * g.cin;
+      pre_sm[k * 64 + c] = bn.pre[k] ? bn.pre[k][c] : 0.f;
+    }
+    __syncthreads();
+  }
   // bf16 wide layers: the kernel rows of the workgroup's 128 output channels go through LDS (below)
   constexpr bool kLdsB = sizeof(T) == 2 && VEC && NT >= 2;
   constexpr int kBRow = 80;                    // bytes per staged kernel row: 32 channels + 16 bytes of padding
@@ -244,9 +255,11 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
       wtap = tap < ntaps ? (unsigned)(tap * g.cin) * wrow : kOOB;
     };
     settap();
-    auto fetch = [&](f32x4& a, float (&b)[4][NT]) {
+    const bool pre_act = PRE && bn.pre[4] != nullptr;
+    auto fetch = [&](f32x4& a, float (&b)[4][NT], int* cq = nullptr) {
       // valid offsets are below 2^31, so OR-ing bit 31 in (kOOB) is the out-of-range mask: no compare/select per load
       const unsigned cib = (unsigned)(c0 + 4 * hh);
+      if constexpr (PRE) *cq = c0 < g.cin && tap == 0 ? (int)cib : 0;      // (steps past the end multiply zeros)
       a = Act<T>::ld4(rx, (xo + cib * 4u) | (xo & kOOB));
       const unsigned wb = wtap + cib * wrow, wm = wtap & kOOB;
 #pragma unroll
@@ -261,14 +274,37 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
         settap();
       }
     };
-    auto mma = [&](const f32x4& a, const float (&b)[4][NT]) {
+    auto mma = [&](const f32x4& a, const float (&b)[4][NT], int cq = 0) {
+      f32x4 av = a;
+      if constexpr (PRE) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(pre_sm + cq), is = *reinterpret_cast<const f32x4*>(pre_sm + 64 + cq);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(pre_sm + 128 + cq), be = *reinterpret_cast<const f32x4*>(pre_sm + 192 + cq);
+        const f32x4 al = *reinterpret_cast<const f32x4*>(pre_sm + 256 + cq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[j] = pre_bn_act(a[j], m[j], is[j], ga[j], be[j], al[j], pre_act);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = MFMA32(a[j], b[j][t], acc[t]);
+        for (int t = 0; t < NT; ++t) acc[t] = MFMA32(av[j], b[j][t], acc[t]);
     };
     const int nsteps = ntaps * (g.cin >> 3);
-    if constexpr (NT >= 2) {
+    if constexpr (PRE) {
+      // (1x1 over at most 64 channels: at most eight steps, two in flight)
+      f32x4 a0, a1, a2;
+      float b0[4][NT], b1[4][NT], b2[4][NT];
+      int q0, q1, q2;
+      fetch(a0, b0, &q0);
+      fetch(a1, b1, &q1);
+      for (int i = 0; i < nsteps; i += 3) {
+        fetch(a2, b2, &q2);
+        mma(a0, b0, q0);
+        fetch(a0, b0, &q0);
+        if (i + 1 < nsteps) mma(a1, b1, q1);
+        fetch(a1, b1, &q1);
+        if (i + 2 < nsteps) mma(a2, b2, q2);
+      }
+    } else if constexpr (NT >= 2) {
       // wide tiles run at two waves per SIMD (accumulators): two steps of operands in flight instead of one, so that a
       // memory round trip is covered by two steps of MFMA work per wave (three register sets, rotated by full unroll)
       f32x4 a0, a1, a2;
@@ -1487,11 +1523,23 @@ static constexpr int kXvMax = 12, kYvMax = 8;
 // XV / YV: staging slots per thread that this instantiation carries (>= xv_n / yv_n of the launch).  The slots cost
 // registers whether a layer fills them or not, and these launches share the SIMDs with the data-gradient chain of the
 // main stream, so the launcher picks the smallest class that fits the layer.
-template <typename T, int TPW, bool VEC, bool M16, int XV, int YV>
+// PRE (float32, VEC, a 1x1 layer whose channel count divides 1024): the x operand is act(BN(x)) of the raw tensor,
+// applied when a staged element is committed to LDS.  Every slot of a thread then holds the same four channels
+// (256 % (cin / 4) == 0), so the thread keeps their parameters in registers.
+template <typename T, int TPW, bool VEC, bool M16, int XV, int YV, bool PRE = false>
 __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgArgs a, WgLds l, const T* __restrict__ x,
-                                                           const T* __restrict__ dy, float* __restrict__ part) {
+                                                           const T* __restrict__ dy, float* __restrict__ part, PreBn pb = PreBn{}) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
+  f32x4 pm = {0.f, 0.f, 0.f, 0.f}, pis = pm, pga = pm, pbe = pm, pal = pm;
+  bool pact = false;
+  if constexpr (PRE) {
+    const int c = (tid % (g.cin / 4)) * 4;
+    pm = *reinterpret_cast<const f32x4*>(pb.mean + c); pis = *reinterpret_cast<const f32x4*>(pb.invstd + c);
+    pga = *reinterpret_cast<const f32x4*>(pb.gamma + c); pbe = *reinterpret_cast<const f32x4*>(pb.beta + c);
+    pact = pb.alpha != nullptr;
+    if (pact) pal = *reinterpret_cast<const f32x4*>(pb.alpha + c);
+  }
   const int lane = tid & 63, wave = tid >> 6;
   constexpr int TS = M16 ? 16 : 32;      // tile edge
   constexpr int KQ = 64 / TS;            // pixels consumed per MFMA step
@@ -1650,8 +1698,14 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds(Geo g, Sizes sz, WgAr
       if (i < l.xv_n) {
         const int e = tid + i * 256;
         if (e < l.x_elems) {
-          if constexpr (VEC) *reinterpret_cast<f32x4*>(smem + e * 4) = Act<T>::up4(xr[i]);
-          else smem[e] = xs[i];
+          if constexpr (VEC) {
+            f32x4 v = Act<T>::up4(xr[i]);
+            if constexpr (PRE) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) v[j] = pre_bn_act(v[j], pm[j], pis[j], pga[j], pbe[j], pal[j], pact);
+            }
+            *reinterpret_cast<f32x4*>(smem + e * 4) = v;
+          } else smem[e] = xs[i];
         }
       }
     }
@@ -2351,6 +2405,11 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
 
 // part != nullptr: the kernel also writes per-workgroup column sums of y and y^2, part[row][2][cout]; *part_rows = rows.
 // bn.mean != nullptr: inference-phase BatchNormalization + activation applied in the epilogue (bn.x stays nullptr).
+// layers whose forward pass can take act(BN(x)) of a raw input (PRE instantiations of conv_fwd_kernel)
+static bool fwd_prebn_ok(const Geo& g) {
+  return g.kh == 1 && g.kw == 1 && g.stride == 1 && g.cin % 8 == 0 && g.cin <= 64 && g.cout > 32 && g.x_ld % 4 == 0;
+}
+
 template <typename T>
 static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const float* bias, T* y,
                               hipStream_t st, float* part = nullptr, int* part_rows = nullptr, BnBwdArgs bn = BnBwdArgs{},
@@ -2365,12 +2424,29 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
     bn.wpack = g.wfp;
     direct_only = true;
   }
+  const bool pre = bn.pre[0] != nullptr;
+  if (pre) direct_only = true;
   if (!direct_only && launch_gemm_lds<T>(g, sz, 0, x, w, bias, (const T*)nullptr, y, st, &e, part, part_rows, bn)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (pre) {
+    if constexpr (sizeof(T) == 4) {
+      SSMI_REQUIRE(fwd_prebn_ok(g) && vec && part != nullptr, SSMI_E_UNSUPPORTED,
+                   "conv2d_fwd (normalise on load): needs a 1x1 stride-1 layer over 8..64 channels (multiple of 8) with more than 32 "
+                   "output channels, 16-byte aligned rows and the statistics epilogue");
+      set_last_kernel("conv_fwd_kernel<%d, true> prebn", nt);
+      if (nt == 2) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, true, true>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
+      else hipLaunchKernelGGL((conv_fwd_kernel<T, 4, true, true>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
+      SSMI_LAUNCH_CHECK();
+      return SSMI_OK;
+    } else {
+      set_error("conv2d_fwd (normalise on load): float32 tensors only");
+      return SSMI_E_UNSUPPORTED;
+    }
+  }
   // kernel rows through LDS: wide layers only (a 1x1 layer over 32 channels has a single chunk and nothing to share)
   static const bool no_lds_b = getenv("SSMI_NO_LDS_B") != nullptr;
   bn.lds_b = (!no_lds_b && bn.wpack && nt >= 2 && vec && g.cin % 32 == 0 && g.kh * g.kw * g.cin >= 256) ? 1 : 0;
@@ -2948,12 +3024,44 @@ static size_t wg_ws_bytes(const Geo& g) {
   return t.use && t.bytes > b ? t.bytes : b;      // the strip kernels remain the fallback for unaligned pointers
 }
 
+// layers whose weight gradient can take act(BN(x)) of a raw x (PRE instantiations of conv_bwd_weight_lds: one tile per wave,
+// short patch / long dy chunk staging class)
+static bool wg_prebn_ok(const Geo& g, bool with_bias) {
+  if (!(g.kh == 1 && g.kw == 1 && g.stride == 1 && g.cin % 4 == 0 && 256 % (g.cin / 4) == 0)) return false;
+  if (plan_tiled(g, with_bias).use) return false;
+  const WgPlan p = plan_wg(g, with_bias);
+  return p.use_lds && p.vec && p.tpw == 1 && p.l.xv_n <= 2 && p.l.yv_n <= 8;
+}
+
 template <typename T>
 static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, float* dw, float* dbias, void* ws,
-                                     size_t ws_bytes, hipStream_t st) {
+                                     size_t ws_bytes, hipStream_t st, const PreBn* pre = nullptr) {
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  if (pre) {
+    if constexpr (sizeof(T) == 4) {
+      SSMI_REQUIRE(wg_prebn_ok(g, dbias != nullptr) && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SSMI_E_UNSUPPORTED,
+                   "conv2d_bwd_weight (normalise on load): layer shape not supported");
+      const WgPlan p = plan_wg(g, dbias != nullptr);
+      SSMI_REQUIRE(ws != nullptr && ws_bytes >= p.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
+                   ws_bytes, p.bytes);
+      float* part = reinterpret_cast<float*>(ws);
+      dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
+      const size_t lds = (size_t)p.l.lds_words * 4;
+      if (p.m16)
+        hipLaunchKernelGGL((conv_bwd_weight_lds<T, 1, true, true, 2, 8, true>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part, *pre);
+      else
+        hipLaunchKernelGGL((conv_bwd_weight_lds<T, 1, true, false, 2, 8, true>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part, *pre);
+      SSMI_LAUNCH_CHECK();
+      launch_wg_reduce(part, p.a.nstrips, p.a.K, p.a.K_aug, g.cout, dw, dbias, st);
+      SSMI_LAUNCH_CHECK();
+      return SSMI_OK;
+    } else {
+      set_error("conv2d_bwd_weight (normalise on load): float32 tensors only");
+      return SSMI_E_UNSUPPORTED;
+    }
+  }
   const TiledPlan t = plan_tiled(g, dbias != nullptr);
   if (t.use && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
     SSMI_REQUIRE(ws != nullptr && ws_bytes >= t.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
@@ -3117,6 +3225,46 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, con
   if (s) return s;
   return launch_bn_stats_final(part, rows, d->cout, (int64_t)d->n * d->ho * d->wo, eps, momentum, unbiased_moving,
                                moving_mean, moving_var, save_mean, save_invstd, as_stream(stream));
+}
+
+int32_t ssmi_conv2d_prebn_supported(const ssmi_conv_desc* d, int32_t with_bias) {
+  if (check_desc(d) != SSMI_OK || d->dtype != SSMI_F32) return 0;
+  const Geo g = to_geo(d);
+  return fwd_prebn_ok(g) && wg_prebn_ok(g, with_bias != 0);
+}
+
+ssmi_status ssmi_conv2d_fwd_bn_stats_prebn(const ssmi_conv_desc* d, const void* x_raw, const ssmi_bn_params* pre,
+                                           const float* pre_alpha, const float* w, const float* bias, void* y, float eps,
+                                           float momentum, int32_t unbiased_moving, float* moving_mean, float* moving_var,
+                                           float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && y && save_mean && save_invstd,
+               SSMI_E_INVALID_ARG, "conv2d_fwd_bn_stats_prebn: NULL argument");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_fwd_bn_stats_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_fwd_bn_stats_prebn: workspace too small");
+  SSMI_REQUIRE(d->dtype == SSMI_F32, SSMI_E_UNSUPPORTED, "conv2d_fwd_bn_stats_prebn: float32 tensors only");
+  int rows = 0;
+  float* part = reinterpret_cast<float*>(ws);
+  BnBwdArgs bn{};
+  bn.pre[0] = pre->mean; bn.pre[1] = pre->invstd; bn.pre[2] = pre->gamma; bn.pre[3] = pre->beta; bn.pre[4] = pre_alpha;
+  s = launch_fwd<float>(to_geo(d), static_cast<const float*>(x_raw), w, bias, static_cast<float*>(y), as_stream(stream), part, &rows, bn);
+  if (s) return s;
+  return launch_bn_stats_final(part, rows, d->cout, (int64_t)d->n * d->ho * d->wo, eps, momentum, unbiased_moving,
+                               moving_mean, moving_var, save_mean, save_invstd, as_stream(stream));
+}
+
+ssmi_status ssmi_conv2d_bwd_weight_prebn(const ssmi_conv_desc* d, const void* x_raw, const ssmi_bn_params* pre,
+                                         const float* pre_alpha, const void* dy, float* dw, float* dbias, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && dy && dw, SSMI_E_INVALID_ARG,
+               "conv2d_bwd_weight_prebn: NULL argument");
+  SSMI_REQUIRE(d->dtype == SSMI_F32, SSMI_E_UNSUPPORTED, "conv2d_bwd_weight_prebn: float32 tensors only");
+  PreBn pb{pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha};
+  return launch_bwd_weight<float>(to_geo(d), static_cast<const float*>(x_raw), static_cast<const float*>(dy), dw, dbias, ws, ws_bytes,
+                                  as_stream(stream), &pb);
 }
 
 ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,

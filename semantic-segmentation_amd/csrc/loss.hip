@@ -697,7 +697,10 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
                 (4 * esz - 1)) == 0, SSMI_E_INVALID_ARG, "logits_tconv2x2_xent: tensors must be aligned to four elements");
   hipStream_t st = as_stream(stream);
   int64_t nb64 = ceil_div64((int64_t)n * 2 * h * ((w + 1) / 2) * 2, 256);      // work items: two pixels of a row each
-  if (nb64 > kLossBlocks) nb64 = kLossBlocks;
+  // whole rounds of resident workgroups: the gradient form keeps two workgroups per CU (2048 = 4 rounds of 512), the
+  // evaluation form three (1536 = 2 rounds of 768)
+  const int64_t cap = dlogits ? kLossBlocks : 1536;
+  if (nb64 > cap) nb64 = cap;
   const int nb = (int)nb64;
   double* part = reinterpret_cast<double*>(ws);
   const float inv = (float)(1.0 / (double)npix);

@@ -163,6 +163,7 @@ class Conv:
         self.ws_bytes = 0
         self.pack_usage = 0       # bf16 storage: bit 0 / 1 = forward / data gradient can run from a bfloat16 kernel pack
         self.uses_rot = False     # the data gradient can use a pre-rotated kernel matrix (decided by the library in plan())
+        self.prebn_ok = False
         self.wrot = None          # that matrix: a view of the network's rotated arena, refreshed once per step
 
     def plan(self, n, h, w, x_ld=None, y_ld=None):
@@ -189,6 +190,10 @@ class Conv:
                                 L.conv2d_bwd_data_workspace_bytes(C.byref(d)))
             self.bwd_data_ws_bytes = L.conv2d_bwd_data_workspace_bytes(C.byref(d))
             self.uses_rot = bool(L.conv2d_bwd_data_uses_rotated(C.byref(d)))
+            # forward pass and weight gradient can apply the BatchNormalization + PReLU in front of this layer to their
+            # operand themselves (ssmi_conv2d_*_prebn)
+            self.prebn_ok = bool(lib().conv2d_prebn_supported(C.byref(d), 1 if self.has_bias else 0)) and \
+                not os.environ.get("SSMI_NO_PREBN")
             self.pack_usage = int(L.conv2d_pack_usage(C.byref(d))) if not os.environ.get("SSMI_NO_BF16_MFMA") else 0
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
@@ -229,6 +234,17 @@ class Conv:
                                   1 if unbiased else 0, _ptr(bn.mm) if update_moving else None,
                                   _ptr(bn.mv) if update_moving else None, _ptr(bn.mean), _ptr(bn.invstd), _ptr(ws),
                                   ws.numel() * 4, st)
+
+    def fwd_bn_prebn(self, x_raw, pre: "BatchNorm", y, bn: "BatchNorm", update_moving, unbiased, ws, st):
+        """fwd_bn on act(BN_pre(x_raw)) without that tensor being stored (training phase; `prebn_ok` layers)."""
+        lib().conv2d_fwd_bn_stats_prebn(self._dref, _ptr(x_raw), pre._pref, _ptr(pre.alpha), _ptr(self.w), _ptr(self.b), _ptr(y),
+                                        BN_EPS, BN_MOMENTUM, 1 if unbiased else 0, _ptr(bn.mm) if update_moving else None,
+                                        _ptr(bn.mv) if update_moving else None, _ptr(bn.mean), _ptr(bn.invstd), _ptr(ws),
+                                        ws.numel() * 4, st)
+
+    def bwd_weight_prebn(self, x_raw, pre: "BatchNorm", dy, ws, st):
+        lib().conv2d_bwd_weight_prebn(self._dref, _ptr(x_raw), pre._pref, _ptr(pre.alpha), _ptr(dy), _ptr(self.dw), _ptr(self.db),
+                                      _ptr(ws), ws.numel() * 4, st)
 
     def fwd_bn_act_infer(self, x, y, bn: "BatchNorm", st, act=None, slope=0.0):
         """Inference phase: convolution + BatchNormalization (statistics already in bn.mean / bn.invstd) + activation in
@@ -363,13 +379,17 @@ class RunCfg:
         self._pending = []
         self._turn = 0
 
-    def wgrad(self, conv, x, dy):
+    def wgrad(self, conv, x, dy, pre=None):
+        """`pre`: the BatchNorm (+PReLU) whose output is this layer's input when `x` is that BatchNorm's RAW input."""
         if _ABLATE_WGRAD:       # timing experiment only: the step then computes no weight gradients at all
             return
         if self.side is None:
-            conv.bwd_weight(x, dy, self.ws, self.st)
+            if pre is not None:
+                conv.bwd_weight_prebn(x, pre, dy, self.ws, self.st)
+            else:
+                conv.bwd_weight(x, dy, self.ws, self.st)
             return
-        self._pending.append((conv, x, dy))
+        self._pending.append((conv, x, dy, pre))
 
     def flush(self):
         """Launches the weight gradients collected since the last flush on the side stream, behind everything the main
@@ -383,8 +403,11 @@ class RunCfg:
         ev = torch.cuda.Event()
         ev.record(self.main)
         side.wait_event(ev)
-        for conv, x, dy in self._pending:
-            conv.bwd_weight(x, dy, ws2, side.cuda_stream)
+        for conv, x, dy, pre in self._pending:
+            if pre is not None:
+                conv.bwd_weight_prebn(x, pre, dy, ws2, side.cuda_stream)
+            else:
+                conv.bwd_weight(x, dy, ws2, side.cuda_stream)
         self._pending = []
         self._forked = True
 
@@ -643,14 +666,20 @@ class Bottleneck(Block):
             self.conv2.fwd_bn_act_infer(src2, self.a2, self.bn2, st)
         else:
             self.conv2.fwd_bn(src2, self.y2, self.bn2, self.np_out, tr, um, ub, ws, st)
-            self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
+            # training phase: BN2 + PReLU2 are applied by conv3 (and by its weight gradient) to their operand; a2 is not stored
+            self._pre3 = tr and self.conv3.prebn_ok
+            if not self._pre3:
+                self.bn2.act_fwd(self.y2, i, self.a2, self.np_out, st)
         if (not tr and self.mode == 0 and not (cfg.use_dropout and self.drop_mask is not None)
                 and not _NO_FUSED_INFER_MERGE):
             # inference phase, identity skip: BN3, the Add and PReLU3 ride in conv3's epilogue (dropout is the identity)
             self._drop_used = None
             self.conv3.fwd_bn_add_act_infer(self.a2, self.out, self.bn3, x, self.cin, self.alpha3, st)
             return self.out
-        self.conv3.fwd_bn(self.a2, self.y3, self.bn3, self.np_out, tr, um, ub, ws, st)
+        if tr and getattr(self, "_pre3", False):
+            self.conv3.fwd_bn_prebn(self.y2, self.bn2, self.y3, self.bn3, um, ub, ws, st)
+        else:
+            self.conv3.fwd_bn(self.a2, self.y3, self.bn3, self.np_out, tr, um, ub, ws, st)
         if self.mode == 1:
             L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin,
                                  _ptr(self.idx), None, st)
@@ -673,7 +702,10 @@ class Bottleneck(Block):
                     _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
                     _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
         # conv3
-        cfg.wgrad(self.conv3, self.a2, self.dy3)
+        if getattr(self, "_pre3", False):
+            cfg.wgrad(self.conv3, self.y2, self.dy3, pre=self.bn2)
+        else:
+            cfg.wgrad(self.conv3, self.a2, self.dy3)
         self.conv3.bwd_data_bn(self.dy3, self.da2, self.bn2, self.y2, i, self.da2, self.np_out, ws, st)   # da2 -> dy2 (in place)
         # conv2
         if self.conv2a is not None:

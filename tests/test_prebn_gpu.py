@@ -1,0 +1,116 @@
+"""Normalise on load (ssmi_conv2d_fwd_bn_stats_prebn / ssmi_conv2d_bwd_weight_prebn, through the C ABI): the 1x1 expansion of
+a bottleneck (src/models.py:1138-1147, BatchNormalization -> PReLU -> Conv2D 1x1) with the BatchNormalization + PReLU applied
+to the operand inside the convolution kernels.  The contract is bit-identity with the two-call route (ssmi_bn_act_fwd, then the
+plain entry point on the stored tensor): same per-element arithmetic, same kernels otherwise.  The two-call route itself is
+checked against the CPU oracle in test_ops_gpu.py / test_parity_step_gpu.py; the last test here repeats a whole training
+step with the switch off and demands identical losses, matrices and updated weights."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W,prelu", [(16, 64, 2, 16, 16, True), (32, 128, 2, 8, 8, True), (32, 128, 1, 7, 9, True),
+                                                  (16, 64, 3, 5, 33, False), (64, 128, 1, 8, 8, True)])
+def test_prebn_entry_points_equal_the_two_call_route(cin, cout, N, H, W, prelu):
+    eng, libm = pkg("engine"), pkg("_lib")
+    L = libm.lib()
+    rng = np.random.RandomState(cin + cout + H)
+    store = eng.ParamStore()
+    cv = eng.Conv(store, "c", 1, 1, cin, cout, padding="valid", bias=False)
+    pre = eng.BatchNorm(store, "pre", cin)
+    if prelu:
+        pre.add_prelu(store, "pre_prelu")
+    post = eng.BatchNorm(store, "post", cout)
+    store.materialise(torch.device(DEV))
+    store.init_values(3)
+    cv.plan(N, H, W)
+    pre.plan(torch.device(DEV))
+    post.plan(torch.device(DEV))
+    if not cv.prebn_ok:
+        pytest.skip("layer shape not supported by the normalise-on-load kernels")
+    store.views["pre/gamma"].copy_(torch.from_numpy(rng.uniform(0.5, 1.5, cin).astype(np.float32)))
+    store.views["pre/beta"].copy_(torch.from_numpy(rng.uniform(-0.5, 0.5, cin).astype(np.float32)))
+    if prelu:
+        store.views["pre_prelu/alpha"].copy_(torch.from_numpy(rng.uniform(-0.2, 0.4, (1, 1, cin)).astype(np.float32)))
+    pre.mean.copy_(torch.from_numpy(rng.standard_normal(cin).astype(np.float32) * 0.3))
+    pre.invstd.copy_(torch.from_numpy(rng.uniform(0.5, 2.0, cin).astype(np.float32)))
+    npix = N * H * W
+    x = torch.from_numpy(rng.standard_normal((N, H, W, cin)).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(rng.standard_normal((N, H, W, cout)).astype(np.float32)).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(cv.ws_bytes // 4 + 64, device=DEV)
+
+    # two calls: store the normalised tensor, then the plain kernels
+    a = torch.empty_like(x)
+    pre.act_fwd(x, cin, a, npix, st)
+    y0 = torch.empty(N, H, W, cout, device=DEV)
+    cv.fwd_bn(a, y0, post, npix, True, False, False, ws, st)
+    m0, i0 = post.mean.clone(), post.invstd.clone()
+    cv.bwd_weight(a, dy, ws, st)
+    dw0 = cv.dw.clone()
+    torch.cuda.synchronize()
+
+    # one call each
+    post.mean.zero_(); post.invstd.zero_(); cv.dw.zero_()
+    y1 = torch.full_like(y0, 3.0)
+    cv.fwd_bn_prebn(x, pre, y1, post, False, False, ws, st)
+    cv.bwd_weight_prebn(x, pre, dy, ws, st)
+    torch.cuda.synchronize()
+    assert torch.equal(_bits(y1), _bits(y0)), "forward differs: max |d| = {}".format((y1 - y0).abs().max().item())
+    assert torch.equal(_bits(post.mean), _bits(m0)) and torch.equal(_bits(post.invstd), _bits(i0))
+    assert torch.equal(_bits(cv.dw), _bits(dw0)), "weight gradient differs: max |d| = {}".format((cv.dw - dw0).abs().max().item())
+    # and the operand really is the normalised tensor, not the raw one
+    assert (y0 - torch.einsum("nhwc,cd->nhwd", x, cv.w.view(cin, cout))).abs().max().item() > 1e-2
+
+
+def test_unsupported_layers_are_reported():
+    eng, libm = pkg("engine"), pkg("_lib")
+    store = eng.ParamStore()
+    small = eng.Conv(store, "a", 1, 1, 4, 16, padding="valid", bias=False)      # <= 32 output channels: another kernel family
+    wide = eng.Conv(store, "b", 3, 3, 32, 64, bias=True)                          # not 1x1
+    half = eng.Conv(eng.ParamStore(torch.bfloat16), "c", 1, 1, 32, 128, padding="valid", bias=False)
+    store.materialise(torch.device(DEV))
+    half.store.materialise(torch.device(DEV))
+    for cv in (small, wide, half):
+        cv.plan(2, 16, 16)
+        assert not cv.prebn_ok
+
+
+def test_training_step_is_identical_with_and_without_normalise_on_load(monkeypatch):
+    from oracle import enet_oracle as E
+    models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
+    name, NC, B, H, W = "enet-naive-upsampling", 24, 2, 64, 64
+    w0 = E.init_weights(name, NC, seed=5, perturb=True)
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=6, block=8)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("SSMI_NO_PREBN", "1")
+        else:
+            monkeypatch.delenv("SSMI_NO_PREBN", raising=False)
+        m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY).model
+        m.set_weights([w0[k] for k in m.weight_names()])
+        m.compile(optimizer=xo.Adam(lr=1e-3), metrics={'logits': [metrics.segmentation_confusion_matrix(NC, 0, [0])]})
+        with torch.cuda.stream(torch.cuda.Stream()):
+            outs = [m.train_on_batch([images, labels, pw, np.zeros((B, 1), np.int32)]) for _ in range(3)]
+        torch.cuda.synchronize()
+        fused = [b.name for b in m.graph.blocks if getattr(b, "_pre3", False)]
+        assert bool(fused) != off, "normalise on load {} (blocks: {})".format("ran although switched off" if off else "did not run", fused)
+        res.append((outs, [w.copy() for w in m.get_weights()]))
+    (o0, w0_), (o1, w1_) = res
+    for a, b in zip(o0, o1):
+        for u, v in zip(a, b):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    for u, v in zip(w0_, w1_):
+        assert np.array_equal(u, v)
