@@ -139,9 +139,10 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, con
  * statistics and parameters (training phase: save_mean / save_invstd), pre_alpha the PReLU slopes (NULL: no activation).
  *   ssmi_conv2d_fwd_bn_stats_prebn(d, x_raw, ...)  == ssmi_conv2d_fwd_bn_stats(d, ssmi_bn_act_fwd(x_raw), ...)
  *   ssmi_conv2d_bwd_weight_prebn(d, x_raw, ...)    == ssmi_conv2d_bwd_weight(d, ssmi_bn_act_fwd(x_raw), ...)
- * bit for bit (the same arithmetic per element).  float32 tensors, 1x1 stride-1 layers over 8..64 input channels (multiple
- * of 8) with more than 32 output channels whose weight gradient takes one tile per wave: ssmi_conv2d_prebn_supported says
- * whether a layer qualifies; others return SSMI_E_UNSUPPORTED.  The data gradient of the layer is unchanged (it produces
+ * bit for bit (the same arithmetic per element; bfloat16 storage rounds the operand as the stored tensor would have been).
+ * 1x1 stride-1 layers over 8..64 input channels (whole blocks of 8; 16 for bfloat16) with more than 32 output channels whose
+ * weight gradient takes one tile per wave: ssmi_conv2d_prebn_supported says whether a layer qualifies; others return
+ * SSMI_E_UNSUPPORTED.  The data gradient of the layer is unchanged (it produces
  * the gradient of the normalised tensor, which ssmi_conv2d_bwd_data_bn_bwd pushes through the BatchNormalization). */
 int32_t ssmi_conv2d_prebn_supported(const ssmi_conv_desc* d, int32_t with_bias);
 ssmi_status ssmi_conv2d_fwd_bn_stats_prebn(const ssmi_conv_desc* d, const void* x_raw, const ssmi_bn_params* pre,

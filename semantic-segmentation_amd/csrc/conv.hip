@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n, int on) {
 // x when a step is multiplied (bn.pre; parameters of the <= 64 input channels through LDS).  Its own instantiation, so
 // that the plain kernels keep their register counts.
 template <typename T, int NT, bool VEC, bool PRE = false>
-__global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
+__global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 2 ? 4 : 2)))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 3 * NT * 32];
@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
         wtap = tap < ntaps ? (unsigned)tap * tapbytes : kOOB;
       };
       settap();
-      auto fetch = [&](u32x4& a, u32x4 (&b)[NT]) {
+      const bool pre_act = PRE && bn.pre[4] != nullptr;
+      auto fetch = [&](u32x4& a, u32x4 (&b)[NT], int* cq = nullptr) {
         const unsigned cb = (unsigned)(c0 + 8 * hh) * 2u;
+        if constexpr (PRE) *cq = c0 < g.cin && tap == 0 ? c0 + 8 * hh : 0;      // (steps past the end multiply zeros)
         a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo + cb) | (xo & (kOOB >> 1)), 0, 0));
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -222,23 +224,43 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
           settap();
         }
       };
-      auto mma = [&](const u32x4& a, const u32x4 (&b)[NT]) {
+      auto mma = [&](const u32x4& a, const u32x4 (&b)[NT], int cq = 0) {
+        u32x4 av = a;
+        if constexpr (PRE) {
+          // the lane's eight channels: widened, normalised + activated as bn_act_fwd_kernel does, rounded to bfloat16 as its
+          // store would have rounded them
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const float* ps = pre_sm + cq + 4 * h2;
+            const f32x4 m = *reinterpret_cast<const f32x4*>(ps), is = *reinterpret_cast<const f32x4*>(ps + 64);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(ps + 128), be = *reinterpret_cast<const f32x4*>(ps + 192);
+            const f32x4 al = *reinterpret_cast<const f32x4*>(ps + 256);
+            u32x2 raw;
+            raw[0] = a[2 * h2]; raw[1] = a[2 * h2 + 1];
+            f32x4 v = unpack_bf16x4(raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pre_bn_act(v[j], m[j], is[j], ga[j], be[j], al[j], pre_act);
+            const u32x2 pk = pack_bf16x4(v);
+            av[2 * h2] = pk[0]; av[2 * h2 + 1] = pk[1];
+          }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b[t]), acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, b[t]), acc[t], 0, 0, 0);
       };
       // A step is ONE matrix instruction per column tile (32 cycles), far shorter than the memory round trip that feeds
       // it: the loop is as fast as its loads in flight allow, so the operands of PD steps are fetched ahead.
       const int nsteps = ntaps * (g.cin >> 4);
       constexpr int PD = NT == 1 ? 6 : (NT == 2 ? 4 : 3);
       u32x4 pa[PD], pb[PD][NT];
+      int pq[PD];
 #pragma unroll
-      for (int d = 0; d < PD; ++d) fetch(pa[d], pb[d]);
+      for (int d = 0; d < PD; ++d) fetch(pa[d], pb[d], &pq[d]);
       for (int i = 0; i < nsteps; i += PD) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
-          if (i + d < nsteps) mma(pa[d], pb[d]);
-          fetch(pa[d], pb[d]);       // step i + d + PD; past the end: zeros (tap >= ntaps)
+          if (i + d < nsteps) mma(pa[d], pb[d], pq[d]);
+          fetch(pa[d], pb[d], &pq[d]);       // step i + d + PD; past the end: zeros (tap >= ntaps)
         }
       }
     }
@@ -282,6 +304,7 @@ __global__ __launch_bounds__(256, (NT == 1 ? 4 : (NT == 2 ? 4 : 2))) void conv_f
         const f32x4 al = *reinterpret_cast<const f32x4*>(pre_sm + 256 + cq);
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[j] = pre_bn_act(a[j], m[j], is[j], ga[j], be[j], al[j], pre_act);
+        if constexpr (sizeof(T) == 2) av = unpack_bf16x4(pack_bf16x4(av));      // as the stored tensor would have been rounded
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -1798,10 +1821,21 @@ struct WgBf {
   int lds_bytes;
 };
 
-template <int TPW, int XV, int YV>
+// PRE: as in conv_bwd_weight_lds - the x operand is act(BN(x)) of the raw tensor, formed (and rounded to bfloat16, as the
+// stored tensor would have been) when a staged element is committed to LDS.
+template <int TPW, int XV, int YV, bool PRE = false>
 __global__ __launch_bounds__(256) void conv_bwd_weight_lds_bf16(Geo g, Sizes sz, WgArgs a, WgLds l, WgBf q, const bf16* __restrict__ x,
-                                                                const bf16* __restrict__ dy, float* __restrict__ part) {
+                                                                const bf16* __restrict__ dy, float* __restrict__ part, PreBn pb = PreBn{}) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  f32x4 pm = {0.f, 0.f, 0.f, 0.f}, pis = pm, pga = pm, pbe = pm, pal = pm;
+  bool pact = false;
+  if constexpr (PRE) {
+    const int c = (threadIdx.x % (g.cin / 4)) * 4;
+    pm = *reinterpret_cast<const f32x4*>(pb.mean + c); pis = *reinterpret_cast<const f32x4*>(pb.invstd + c);
+    pga = *reinterpret_cast<const f32x4*>(pb.gamma + c); pbe = *reinterpret_cast<const f32x4*>(pb.beta + c);
+    pact = pb.alpha != nullptr;
+    if (pact) pal = *reinterpret_cast<const f32x4*>(pb.alpha + c);
+  }
   typedef short s16x4 __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) char* lds_ptr;
@@ -1925,7 +1959,14 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds_bf16(Geo g, Sizes sz,
         const int e = tid + i * 256;
         if (e < l.x_elems) {
           const int ky = (int)((xm[i] >> 23) & 0xFFu), colp = (int)((xm[i] >> 12) & 0x7FFu), c = (int)(xm[i] & 0xFFFu);
-          *reinterpret_cast<u32x2*>(base + ((ky * q.Wq + colp) * g.cin + c) * 2) = xr[i];
+          u32x2 xv = xr[i];
+          if constexpr (PRE) {
+            f32x4 v = unpack_bf16x4(xv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pre_bn_act(v[j], pm[j], pis[j], pga[j], pbe[j], pal[j], pact);
+            xv = pack_bf16x4(v);
+          }
+          *reinterpret_cast<u32x2*>(base + ((ky * q.Wq + colp) * g.cin + c) * 2) = xv;
         }
       }
     }
@@ -2433,18 +2474,15 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
   if (pre) {
-    if constexpr (sizeof(T) == 4) {
-      SSMI_REQUIRE(fwd_prebn_ok(g) && vec && part != nullptr, SSMI_E_UNSUPPORTED,
+    {
+      SSMI_REQUIRE(fwd_prebn_ok(g) && vec && part != nullptr && (sizeof(T) == 4 || g.cin % 16 == 0), SSMI_E_UNSUPPORTED,
                    "conv2d_fwd (normalise on load): needs a 1x1 stride-1 layer over 8..64 channels (multiple of 8) with more than 32 "
                    "output channels, 16-byte aligned rows and the statistics epilogue");
-      set_last_kernel("conv_fwd_kernel<%d, true> prebn", nt);
+      set_last_kernel(bn.wpack ? "conv_fwd_kernel<%d, true> prebn bf16 mfma" : "conv_fwd_kernel<%d, true> prebn", nt);
       if (nt == 2) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, true, true>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
       else hipLaunchKernelGGL((conv_fwd_kernel<T, 4, true, true>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
       SSMI_LAUNCH_CHECK();
       return SSMI_OK;
-    } else {
-      set_error("conv2d_fwd (normalise on load): float32 tensors only");
-      return SSMI_E_UNSUPPORTED;
     }
   }
   // kernel rows through LDS: wide layers only (a 1x1 layer over 32 channels has a single chunk and nothing to share)
@@ -3026,10 +3064,10 @@ static size_t wg_ws_bytes(const Geo& g) {
 
 // layers whose weight gradient can take act(BN(x)) of a raw x (PRE instantiations of conv_bwd_weight_lds: one tile per wave,
 // short patch / long dy chunk staging class)
-static bool wg_prebn_ok(const Geo& g, bool with_bias) {
+static bool wg_prebn_ok(const Geo& g, bool with_bias, bool bf16_mfma = false) {
   if (!(g.kh == 1 && g.kw == 1 && g.stride == 1 && g.cin % 4 == 0 && 256 % (g.cin / 4) == 0)) return false;
   if (plan_tiled(g, with_bias).use) return false;
-  const WgPlan p = plan_wg(g, with_bias);
+  const WgPlan p = plan_wg(g, with_bias, bf16_mfma);
   return p.use_lds && p.vec && p.tpw == 1 && p.l.xv_n <= 2 && p.l.yv_n <= 8;
 }
 
@@ -3040,6 +3078,21 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
   if (pre) {
+    if constexpr (sizeof(T) == 2) {
+      SSMI_REQUIRE(wg_prebn_ok(g, dbias != nullptr, true) && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SSMI_E_UNSUPPORTED,
+                   "conv2d_bwd_weight (normalise on load): layer shape not supported");
+      const WgPlan p = plan_wg(g, dbias != nullptr, true);
+      SSMI_REQUIRE(ws != nullptr && ws_bytes >= p.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
+                   ws_bytes, p.bytes);
+      float* part = reinterpret_cast<float*>(ws);
+      dim3 grid((unsigned)p.blocks_x, (unsigned)p.groups, 1);
+      hipLaunchKernelGGL((conv_bwd_weight_lds_bf16<1, 2, 8, true>), grid, dim3(256), (size_t)p.q.lds_bytes, st, g, sz, p.a, p.l, p.q, x, dy,
+                         part, *pre);
+      SSMI_LAUNCH_CHECK();
+      launch_wg_reduce(part, p.a.nstrips, p.a.K, p.a.K_aug, g.cout, dw, dbias, st);
+      SSMI_LAUNCH_CHECK();
+      return SSMI_OK;
+    }
     if constexpr (sizeof(T) == 4) {
       SSMI_REQUIRE(wg_prebn_ok(g, dbias != nullptr) && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SSMI_E_UNSUPPORTED,
                    "conv2d_bwd_weight (normalise on load): layer shape not supported");
@@ -3057,9 +3110,6 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
       launch_wg_reduce(part, p.a.nstrips, p.a.K, p.a.K_aug, g.cout, dw, dbias, st);
       SSMI_LAUNCH_CHECK();
       return SSMI_OK;
-    } else {
-      set_error("conv2d_bwd_weight (normalise on load): float32 tensors only");
-      return SSMI_E_UNSUPPORTED;
     }
   }
   const TiledPlan t = plan_tiled(g, dbias != nullptr);
@@ -3228,9 +3278,12 @@ ssmi_status ssmi_conv2d_fwd_bn_stats(const ssmi_conv_desc* d, const void* x, con
 }
 
 int32_t ssmi_conv2d_prebn_supported(const ssmi_conv_desc* d, int32_t with_bias) {
-  if (check_desc(d) != SSMI_OK || d->dtype != SSMI_F32) return 0;
+  if (check_desc(d) != SSMI_OK) return 0;
   const Geo g = to_geo(d);
-  return fwd_prebn_ok(g) && wg_prebn_ok(g, with_bias != 0);
+  if (d->dtype == SSMI_F32) return fwd_prebn_ok(g) && wg_prebn_ok(g, with_bias != 0);
+  // bfloat16: whole 16-channel blocks (the bfloat16 matrix instructions), the weight gradient on the same instructions
+  static const bool no_mfma = getenv("SSMI_NO_BF16_WGRAD") != nullptr || getenv("SSMI_NO_BF16_MFMA") != nullptr;
+  return !no_mfma && fwd_prebn_ok(g) && g.cin % 16 == 0 && wg_prebn_ok(g, with_bias != 0, true);
 }
 
 ssmi_status ssmi_conv2d_fwd_bn_stats_prebn(const ssmi_conv_desc* d, const void* x_raw, const ssmi_bn_params* pre,
@@ -3243,12 +3296,14 @@ ssmi_status ssmi_conv2d_fwd_bn_stats_prebn(const ssmi_conv_desc* d, const void* 
                SSMI_E_INVALID_ARG, "conv2d_fwd_bn_stats_prebn: NULL argument");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_fwd_bn_stats_workspace_bytes(d), SSMI_E_WORKSPACE,
                "conv2d_fwd_bn_stats_prebn: workspace too small");
-  SSMI_REQUIRE(d->dtype == SSMI_F32, SSMI_E_UNSUPPORTED, "conv2d_fwd_bn_stats_prebn: float32 tensors only");
   int rows = 0;
   float* part = reinterpret_cast<float*>(ws);
   BnBwdArgs bn{};
   bn.pre[0] = pre->mean; bn.pre[1] = pre->invstd; bn.pre[2] = pre->gamma; bn.pre[3] = pre->beta; bn.pre[4] = pre_alpha;
-  s = launch_fwd<float>(to_geo(d), static_cast<const float*>(x_raw), w, bias, static_cast<float*>(y), as_stream(stream), part, &rows, bn);
+  s = dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_fwd<T>(to_geo(d), static_cast<const T*>(x_raw), w, bias, static_cast<T*>(y), as_stream(stream), part, &rows, bn);
+  });
   if (s) return s;
   return launch_bn_stats_final(part, rows, d->cout, (int64_t)d->n * d->ho * d->wo, eps, momentum, unbiased_moving,
                                moving_mean, moving_var, save_mean, save_invstd, as_stream(stream));
@@ -3261,10 +3316,12 @@ ssmi_status ssmi_conv2d_bwd_weight_prebn(const ssmi_conv_desc* d, const void* x_
   if (s) return s;
   SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && dy && dw, SSMI_E_INVALID_ARG,
                "conv2d_bwd_weight_prebn: NULL argument");
-  SSMI_REQUIRE(d->dtype == SSMI_F32, SSMI_E_UNSUPPORTED, "conv2d_bwd_weight_prebn: float32 tensors only");
   PreBn pb{pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha};
-  return launch_bwd_weight<float>(to_geo(d), static_cast<const float*>(x_raw), static_cast<const float*>(dy), dw, dbias, ws, ws_bytes,
-                                  as_stream(stream), &pb);
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return launch_bwd_weight<T>(to_geo(d), static_cast<const T*>(x_raw), static_cast<const T*>(dy), dw, dbias, ws, ws_bytes,
+                                as_stream(stream), &pb);
+  });
 }
 
 ssmi_status ssmi_conv2d_bwd_data(const ssmi_conv_desc* d, const void* dy, const float* w, const void* add, void* dx,

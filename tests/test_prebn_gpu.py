@@ -17,16 +17,18 @@ DEV = "cuda"
 
 
 def _bits(t):
-    return t.contiguous().view(torch.int32)
+    return t.contiguous().view(torch.int32 if t.dtype == torch.float32 else torch.int16)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 @pytest.mark.parametrize("cin,cout,N,H,W,prelu", [(16, 64, 2, 16, 16, True), (32, 128, 2, 8, 8, True), (32, 128, 1, 7, 9, True),
                                                   (16, 64, 3, 5, 33, False), (64, 128, 1, 8, 8, True)])
-def test_prebn_entry_points_equal_the_two_call_route(cin, cout, N, H, W, prelu):
+def test_prebn_entry_points_equal_the_two_call_route(cin, cout, N, H, W, prelu, dtype):
     eng, libm = pkg("engine"), pkg("_lib")
     L = libm.lib()
     rng = np.random.RandomState(cin + cout + H)
-    store = eng.ParamStore()
+    adt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    store = eng.ParamStore(adt)
     cv = eng.Conv(store, "c", 1, 1, cin, cout, padding="valid", bias=False)
     pre = eng.BatchNorm(store, "pre", cin)
     if prelu:
@@ -46,15 +48,15 @@ def test_prebn_entry_points_equal_the_two_call_route(cin, cout, N, H, W, prelu):
     pre.mean.copy_(torch.from_numpy(rng.standard_normal(cin).astype(np.float32) * 0.3))
     pre.invstd.copy_(torch.from_numpy(rng.uniform(0.5, 2.0, cin).astype(np.float32)))
     npix = N * H * W
-    x = torch.from_numpy(rng.standard_normal((N, H, W, cin)).astype(np.float32)).to(DEV)
-    dy = torch.from_numpy(rng.standard_normal((N, H, W, cout)).astype(np.float32)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal((N, H, W, cin)).astype(np.float32)).to(DEV).to(adt)
+    dy = torch.from_numpy(rng.standard_normal((N, H, W, cout)).astype(np.float32)).to(DEV).to(adt)
     st = torch.cuda.current_stream().cuda_stream
     ws = torch.empty(cv.ws_bytes // 4 + 64, device=DEV)
 
     # two calls: store the normalised tensor, then the plain kernels
     a = torch.empty_like(x)
     pre.act_fwd(x, cin, a, npix, st)
-    y0 = torch.empty(N, H, W, cout, device=DEV)
+    y0 = torch.empty(N, H, W, cout, device=DEV, dtype=adt)
     cv.fwd_bn(a, y0, post, npix, True, False, False, ws, st)
     m0, i0 = post.mean.clone(), post.invstd.clone()
     cv.bwd_weight(a, dy, ws, st)
@@ -67,11 +69,11 @@ def test_prebn_entry_points_equal_the_two_call_route(cin, cout, N, H, W, prelu):
     cv.fwd_bn_prebn(x, pre, y1, post, False, False, ws, st)
     cv.bwd_weight_prebn(x, pre, dy, ws, st)
     torch.cuda.synchronize()
-    assert torch.equal(_bits(y1), _bits(y0)), "forward differs: max |d| = {}".format((y1 - y0).abs().max().item())
+    assert torch.equal(_bits(y1), _bits(y0)), "forward differs: max |d| = {}".format((y1.float() - y0.float()).abs().max().item())
     assert torch.equal(_bits(post.mean), _bits(m0)) and torch.equal(_bits(post.invstd), _bits(i0))
     assert torch.equal(_bits(cv.dw), _bits(dw0)), "weight gradient differs: max |d| = {}".format((cv.dw - dw0).abs().max().item())
     # and the operand really is the normalised tensor, not the raw one
-    assert (y0 - torch.einsum("nhwc,cd->nhwd", x, cv.w.view(cin, cout))).abs().max().item() > 1e-2
+    assert (y0.float() - torch.einsum("nhwc,cd->nhwd", x.float(), cv.w.view(cin, cout))).abs().max().item() > 1e-2
 
 
 def test_unsupported_layers_are_reported():
@@ -79,7 +81,7 @@ def test_unsupported_layers_are_reported():
     store = eng.ParamStore()
     small = eng.Conv(store, "a", 1, 1, 4, 16, padding="valid", bias=False)      # <= 32 output channels: another kernel family
     wide = eng.Conv(store, "b", 3, 3, 32, 64, bias=True)                          # not 1x1
-    half = eng.Conv(eng.ParamStore(torch.bfloat16), "c", 1, 1, 32, 128, padding="valid", bias=False)
+    half = eng.Conv(eng.ParamStore(torch.bfloat16), "c", 1, 1, 8, 64, padding="valid", bias=False)      # bf16: whole 16-channel blocks only
     store.materialise(torch.device(DEV))
     half.store.materialise(torch.device(DEV))
     for cv in (small, wide, half):
@@ -87,7 +89,8 @@ def test_unsupported_layers_are_reported():
         assert not cv.prebn_ok
 
 
-def test_training_step_is_identical_with_and_without_normalise_on_load(monkeypatch):
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_training_step_is_identical_with_and_without_normalise_on_load(monkeypatch, dtype):
     from oracle import enet_oracle as E
     models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
     name, NC, B, H, W = "enet-naive-upsampling", 24, 2, 64, 64
@@ -99,7 +102,8 @@ def test_training_step_is_identical_with_and_without_normalise_on_load(monkeypat
             monkeypatch.setenv("SSMI_NO_PREBN", "1")
         else:
             monkeypatch.delenv("SSMI_NO_PREBN", raising=False)
-        m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY).model
+        m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY,
+                             dtype=dtype).model
         m.set_weights([w0[k] for k in m.weight_names()])
         m.compile(optimizer=xo.Adam(lr=1e-3), metrics={'logits': [metrics.segmentation_confusion_matrix(NC, 0, [0])]})
         with torch.cuda.stream(torch.cuda.Stream()):
