@@ -195,6 +195,56 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__
   }
 }
 
+// Four channels per thread for the three kernels above / below (channel counts and pixel strides that are multiples of four,
+// tensors aligned to four elements, fewer than 2^31 elements): 16-byte accesses, 32-bit index arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_fwd_vec(const T* __restrict__ x, int h, int w, int c, T* __restrict__ y, int y_ld,
+                                                        unsigned total4) {
+  const unsigned c4n = (unsigned)c >> 2, W = 2u * (unsigned)w, H = 2u * (unsigned)h;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+    const unsigned pix = i / c4n, ch = (i - pix * c4n) * 4u;
+    const unsigned q1 = pix / W, ox = pix - q1 * W;
+    const unsigned n_ = q1 / H, oy = q1 - n_ * H;
+    const size_t src = ((size_t)(n_ * (unsigned)h + (oy >> 1)) * (unsigned)w + (ox >> 1)) * (unsigned)c + ch;
+    Act<T>::gst4(y + (size_t)pix * y_ld + ch, Act<T>::gld4(x + src));      // a copy: widening and re-rounding is exact
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_vec(const T* __restrict__ dy, int dy_ld, int h, int w, int c, T* __restrict__ dx,
+                                                        unsigned total4) {
+  const unsigned c4n = (unsigned)c >> 2, W = 2u * (unsigned)w;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+    const unsigned q0 = i / c4n, ch = (i - q0 * c4n) * 4u;
+    const unsigned q1 = q0 / (unsigned)w, x_ = q0 - q1 * (unsigned)w;
+    const unsigned n_ = q1 / (unsigned)h, y_ = q1 - n_ * (unsigned)h;
+    const T* b = dy + ((size_t)(n_ * 2u * (unsigned)h + 2u * y_) * W + 2u * x_) * dy_ld + ch;
+    const f32x4 v0 = Act<T>::gld4(b), v1 = Act<T>::gld4(b + dy_ld), v2 = Act<T>::gld4(b + (size_t)W * dy_ld),
+                v3 = Act<T>::gld4(b + (size_t)W * dy_ld + dy_ld);
+    Act<T>::gst4(dx + (size_t)i * 4, ((v0 + v1) + v2) + v3);      // the order of the scalar kernel's sum
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void copy_ld_vec(const T* __restrict__ src, int src_ld, T* __restrict__ dst, int dst_ld, int c,
+                                                   int accumulate, unsigned total4) {
+  const unsigned c4n = (unsigned)c >> 2;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total4; i += gridDim.x * 256u) {
+    const unsigned p = i / c4n, ch = (i - p * c4n) * 4u;
+    f32x4 v = Act<T>::gld4(src + (size_t)p * src_ld + ch);
+    T* d = dst + (size_t)p * dst_ld + ch;
+    if (accumulate) v = Act<T>::gld4(d) + v;
+    Act<T>::gst4(d, v);
+  }
+}
+
+template <typename T>
+static bool vec4_ok(const T* a, const T* b, int c, int ld_a, int ld_b, int64_t total) {
+  const size_t m = sizeof(T) * 4 - 1;
+  return c % 4 == 0 && ld_a % 4 == 0 && ld_b % 4 == 0 && total < 0x7FFFFFFFLL && (reinterpret_cast<uintptr_t>(a) & m) == 0 &&
+         (reinterpret_cast<uintptr_t>(b) & m) == 0;
+}
+
 // dst[p, 0:c] (=|+=) src[p, 0:c] with independent pixel strides: concat slices and their gradients
 template <typename T>
 __global__ __launch_bounds__(256) void copy_ld_kernel(const T* __restrict__ src, int src_ld, T* __restrict__ dst,
@@ -331,7 +381,11 @@ template <typename T>
 static ssmi_status upsample_fwd_impl(const T* x, int32_t n, int32_t h, int32_t w, int32_t c, T* y, int32_t y_ld, void* stream) {
   SSMI_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && c > 0 && y_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_fwd: bad argument");
   const int64_t total = (int64_t)n * h * w * c * 4;
-  hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, y_ld, total);
+  if (vec4_ok(x, y, c, c, y_ld, (int64_t)n * 4 * h * w * y_ld))
+    hipLaunchKernelGGL(upsample_fwd_vec<T>, dim3(grid_for(total / 4)), dim3(256), 0, as_stream(stream), x, h, w, c, y, y_ld,
+                       (unsigned)(total / 4));
+  else
+    hipLaunchKernelGGL(upsample_fwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), x, n, h, w, c, y, y_ld, total);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
@@ -340,7 +394,11 @@ template <typename T>
 static ssmi_status upsample_bwd_impl(const T* dy, int32_t dy_ld, int32_t n, int32_t h, int32_t w, int32_t c, T* dx, void* stream) {
   SSMI_REQUIRE(dy && dx && n > 0 && h > 0 && w > 0 && c > 0 && dy_ld >= c, SSMI_E_INVALID_ARG, "upsample_nn2x_bwd: bad argument");
   const int64_t total = (int64_t)n * h * w * c;
-  hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, n, h, w, c, dx, total);
+  if (vec4_ok(dy, dx, c, dy_ld, c, (int64_t)n * 4 * h * w * dy_ld))
+    hipLaunchKernelGGL(upsample_bwd_vec<T>, dim3(grid_for(total / 4)), dim3(256), 0, as_stream(stream), dy, dy_ld, h, w, c, dx,
+                       (unsigned)(total / 4));
+  else
+    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), dy, dy_ld, n, h, w, c, dx, total);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
@@ -350,8 +408,12 @@ static ssmi_status copy_ld_impl(const T* src, int32_t src_ld, T* dst, int32_t ds
                                 void* stream) {
   SSMI_REQUIRE(src && dst && npix > 0 && c > 0 && src_ld >= c && dst_ld >= c, SSMI_E_INVALID_ARG, "copy_ld: bad argument");
   const int64_t total = npix * c;
-  hipLaunchKernelGGL(copy_ld_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld, c,
-                     accumulate, total);
+  if (vec4_ok(src, static_cast<const T*>(dst), c, src_ld, dst_ld, npix * (src_ld > dst_ld ? src_ld : dst_ld)))
+    hipLaunchKernelGGL(copy_ld_vec<T>, dim3(grid_for(total / 4)), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld, c,
+                       accumulate, (unsigned)(total / 4));
+  else
+    hipLaunchKernelGGL(copy_ld_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), src, src_ld, dst, dst_ld, c,
+                       accumulate, total);
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
