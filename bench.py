@@ -319,12 +319,18 @@ def measure_roofline(model, stream, steps=3):
     # on the chip at a time); the trace names carry the storage type as first template argument, the records do not
     traffic = None
     import re
-    for fname in ("r02_traffic.json", "r01_traffic.json"):
+    want_bf16 = getattr(model.graph.store, "act_dtype", torch.float32) == torch.bfloat16
+    base = kernel.replace(" bf16 mfma", "")
+    for fname in (("r02_traffic_bf16.json",) if want_bf16 else ("r02_traffic.json", "r01_traffic.json")):
         tpath = os.path.join(ROOT, "profiles", fname)
         if traffic is None and os.path.exists(tpath):
             with open(tpath) as f:
-                table = {re.sub(r"<(float|__bf16), ", "<", k): v for k, v in json.load(f).items()}
-            traffic = table.get(kernel, {}).get("hbm_bytes_per_launch")
+                raw = json.load(f)
+            # trace names: storage type first, then the record's arguments, then (newer builds) the normalise-on-load flag
+            for k, v in raw.items():
+                m = re.match(r"^(\w+)<(float|__bf16), (.*?)(, false)?>$", k)
+                if m and (m.group(2) == "__bf16") == want_bf16 and "{}<{}>".format(m.group(1), m.group(3)) == base:
+                    traffic = v.get("hbm_bytes_per_launch")
     common = {"kernel": "ssmi::" + kernel, "launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
               "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
               "arithmetic_intensity_flop_per_byte": round(ai, 2), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),

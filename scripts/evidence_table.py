@@ -54,6 +54,10 @@ for k, (n, us, ms) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
     t = traffic.get(k)
     mb = t["hbm_bytes_per_launch"] / 1e6 if t else None
     rec = recs.get(k)
+    if rec is None:      # trace names of the forward kernel carry the normalise-on-load flag, the library's records a suffix
+        m = re.match(r"^(conv_fwd_kernel<\d+, (?:true|false)), (true|false)>$", k)
+        if m:
+            rec = recs.get(m.group(1) + ">" + (" prebn" if m.group(2) == "true" else ""))
     gf = rec["flops_per_step"] / max(rec["launches_per_step"], 1) / 1e9 if rec else None
     c = pmc.get(k)
     busy = issued = None
