@@ -235,20 +235,23 @@ __global__ __launch_bounds__(256) void head2x2_xent_kernel(const T* __restrict__
     for (int m = 0; m < C / 4; ++m) za[m] = zb[m] = *reinterpret_cast<const f32x4*>(bl + 4 * m);
     // kernel words of input channel ci + 1 are fetched while channel ci is multiplied; the scheduling barrier keeps the
     // compiler from hoisting all 96 LDS reads in front of the first multiply (which took 500 registers)
-    f32x4 wv[2][C / 4];
+    constexpr int HB = GRAD ? 2 : 1;      // half-channel blocks of kernel words in flight (the gradient form is short of registers)
+    f32x4 wv[2][C / 4 / HB];
 #pragma unroll
-    for (int m = 0; m < C / 4; ++m) wv[0][m] = *reinterpret_cast<const f32x4*>(wt + 4 * m);
+    for (int m = 0; m < C / 4 / HB; ++m) wv[0][m] = *reinterpret_cast<const f32x4*>(wt + 4 * m);
 #pragma unroll
-    for (int ci = 0; ci < CIN; ++ci) {
-      if (ci + 1 < CIN) {
+    for (int s = 0; s < CIN * HB; ++s) {
+      const int ci = s / HB, h0 = (s % HB) * (C / 4 / HB);
+      if (s + 1 < CIN * HB) {
+        const int cn = (s + 1) / HB, hn = ((s + 1) % HB) * (C / 4 / HB);
 #pragma unroll
-        for (int m = 0; m < C / 4; ++m) wv[(ci + 1) & 1][m] = *reinterpret_cast<const f32x4*>(wt + (ci + 1) * C + 4 * m);
+        for (int m = 0; m < C / 4 / HB; ++m) wv[(s + 1) & 1][m] = *reinterpret_cast<const f32x4*>(wt + cn * C + 4 * (hn + m));
       }
       const f32x4 sa = {xa[ci], xa[ci], xa[ci], xa[ci]}, sb = {xb[ci], xb[ci], xb[ci], xb[ci]};
 #pragma unroll
-      for (int m = 0; m < C / 4; ++m) {
-        za[m] = __builtin_elementwise_fma(sa, wv[ci & 1][m], za[m]);
-        zb[m] = __builtin_elementwise_fma(sb, wv[ci & 1][m], zb[m]);
+      for (int m = 0; m < C / 4 / HB; ++m) {
+        za[h0 + m] = __builtin_elementwise_fma(sa, wv[s & 1][m], za[h0 + m]);
+        zb[h0 + m] = __builtin_elementwise_fma(sb, wv[s & 1][m], zb[h0 + m]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -697,9 +700,8 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
                 (4 * esz - 1)) == 0, SSMI_E_INVALID_ARG, "logits_tconv2x2_xent: tensors must be aligned to four elements");
   hipStream_t st = as_stream(stream);
   int64_t nb64 = ceil_div64((int64_t)n * 2 * h * ((w + 1) / 2) * 2, 256);      // work items: two pixels of a row each
-  // whole rounds of resident workgroups: the gradient form keeps two workgroups per CU (2048 = 4 rounds of 512), the
-  // evaluation form three (1536 = 2 rounds of 768)
-  const int64_t cap = dlogits ? kLossBlocks : 1536;
+  // whole rounds of resident workgroups: two or three workgroups per CU fit (512 or 768 in all), 1536 is 3 or 2 rounds
+  const int64_t cap = 1536;
   if (nb64 > cap) nb64 = cap;
   const int nb = (int)nb64;
   double* part = reinterpret_cast<double*>(ws);
