@@ -153,6 +153,32 @@ ssmi_status ssmi_conv2d_bwd_weight_prebn(const ssmi_conv_desc* d, const void* x_
                                          const float* pre_alpha, const void* dy, float* dw, float* dbias, void* ws,
                                          size_t ws_bytes, void* stream);
 
+/* The gradient a bottleneck's merge backward hands to its 1x1 expansion, left unformed: ssmi_merge_bwd_deferred stops
+ * after the reduction (dsum + the three coefficient vectors k1, m1, m2 in `coef`, 3 * c floats), and a consumer forms
+ *   dmain = k1 * (dsum * drop - m1 - ((main - mean) * invstd) * m2)          (the arithmetic of ssmi_merge_bwd)
+ * from these operands itself.  drop: [n, c] table or NULL; hw: pixels per image. */
+typedef struct ssmi_premerge {
+  const void* dsum;
+  const void* main;
+  const float* mean;
+  const float* invstd;
+  const float* coef;
+  const float* drop;
+  int64_t hw;
+} ssmi_premerge;
+/* ssmi_conv2d_bwd_data_bn_bwd_rot for the expansion convolution of a bottleneck (src/models.py:1142-1147) whose output
+ * gradient is given in that unformed state: the data-gradient kernel applies the merge backward to its operand, so the
+ * main chain of the backward pass does not wait for (or read back) the stored tensor.  Results are bit-identical to
+ * ssmi_merge_bwd followed by ssmi_conv2d_bwd_data_bn_bwd_rot.  float32; ssmi_conv2d_bwd_data_premerge_supported(d) says
+ * whether the layer qualifies (1x1, stride 1, forward-form data gradient, at most 32 input and 128 output channels). */
+int32_t ssmi_conv2d_bwd_data_premerge_supported(const ssmi_conv_desc* d);
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd_premerge(const ssmi_conv_desc* d, const ssmi_premerge* pm, const float* w,
+                                                 const float* w_rot, void* da, const void* bn_x, int32_t ld_x,
+                                                 const float* mean, const float* invstd, const float* gamma,
+                                                 const float* beta, int32_t act, const float* alpha, float slope,
+                                                 void* dx_bn, float* dgamma, float* dbeta, float* dalpha, void* ws,
+                                                 size_t ws_bytes, void* stream);
+
 /* Gradient w.r.t. x (tf.gradients through Conv2D).  dx[n,h,w,cin] (pixel stride x_ld) is fully overwritten:
  * dx = conv_bwd_data(dy, w) + (add ? add : 0), where `add` (nullable) has the layout of dx.  The `add` operand
  * carries the gradient of the block's skip branch (src/models.py:1171). */
@@ -308,6 +334,16 @@ ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const void* dout, const voi
                            const float* drop, const void* other, const ssmi_bn_params* bn_other, const int32_t* idx,
                            const float* alpha, void* dmain, void* dsum, void* dother_bn, float* dgamma3,
                            float* dbeta3, float* dalpha, void* ws, size_t ws_bytes, void* stream);
+
+/* ssmi_merge_bwd in two halves: _deferred runs the reduction (dsum, dother_bn, parameter gradients) and leaves the
+ * coefficients of the last pass in `coef` (3 * c floats, caller-owned, must live until the consumers have run);
+ * _apply is that last pass (dmain), for consumers that want the tensor stored after all.  Together they are ssmi_merge_bwd. */
+ssmi_status ssmi_merge_bwd_deferred(const ssmi_merge_desc* d, const void* dout, const void* main, const ssmi_bn_params* bn3,
+                                    const float* drop, const void* other, const ssmi_bn_params* bn_other, const int32_t* idx,
+                                    const float* alpha, void* dsum, void* dother_bn, float* dgamma3, float* dbeta3,
+                                    float* dalpha, float* coef, void* ws, size_t ws_bytes, void* stream);
+ssmi_status ssmi_merge_bwd_apply(const ssmi_merge_desc* d, const void* dsum, const void* main, const ssmi_bn_params* bn3,
+                                 const float* drop, const float* coef, void* dmain, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------
  * Pooling family.

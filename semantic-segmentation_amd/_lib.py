@@ -31,8 +31,13 @@ class BnParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("mean", "invstd", "gamma", "beta")]
 
 
+class Premerge(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("dsum", "main", "mean", "invstd", "coef", "drop")] + [("hw", C.c_int64)]
+
+
 _vp, _i32, _i64, _f32, _u64, _u32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_uint32, C.c_size_t
 _PD = C.POINTER(ConvDesc)
+_PP = C.POINTER(Premerge)
 _PM = C.POINTER(MergeDesc)
 _PB = C.POINTER(BnParams)
 
@@ -93,6 +98,11 @@ _PROTOS = {
                                     _i64, _i32, _vp, _sz, _vp]),
     "ssmi_merge_fwd": (_i32, [_PM, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp]),
     "ssmi_merge_workspace_bytes": (_sz, [_PM]),
+    "ssmi_merge_bwd_deferred": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_merge_bwd_apply": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _vp, _vp]),
+    "ssmi_conv2d_bwd_data_premerge_supported": (_i32, [_PD]),
+    "ssmi_conv2d_bwd_data_bn_bwd_premerge": (_i32, [_PD, _PP, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
+                                             _vp, _vp, _vp, _sz, _vp]),
     "ssmi_merge_bwd": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_maxpool_argmax_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "ssmi_maxpool_argmax_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
@@ -149,7 +159,7 @@ _PROTOS["ssmi_cast_bf16_to_f32"] = (_i32, [_vp, _vp, _i64, _vp])
 F32, BF16 = 0, 1      # ssmi dtype codes of activation tensors
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_conv2d_prebn_supported", "ssmi_logits_tconv2x2_xent_supported", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_conv2d_bwd_data_premerge_supported", "ssmi_conv2d_prebn_supported", "ssmi_logits_tconv2x2_xent_supported", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 

@@ -832,22 +832,26 @@ static ssmi_status merge_fwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, 
 template <typename T>
 static ssmi_status merge_bwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, const ssmi_bn_params* bn3, const float* drop,
                                   const int32_t* idx, const T* dout, T* dmain, T* dsum, T* dother_bn, float* dgamma3,
-                                  float* dbeta3, float* dalpha, void* ws, void* stream) {
+                                  float* dbeta3, float* dalpha, void* ws, void* stream, float* coef_out = nullptr) {
+  // coef_out != nullptr: the coefficients of the apply pass go to the caller's buffer and the pass itself is left to the
+  // caller (ssmi_merge_bwd_apply, or a consumer that applies them to its operand)
   hipStream_t st = as_stream(stream);
   const int c = d->c, c4n = c / 4;
   const int64_t npix = (int64_t)d->n * d->h * d->w;
   const int nb = red_blocks(npix, c4n);
   float* part = reinterpret_cast<float*>(ws);
-  float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
+  float* coef = coef_out ? coef_out : part + (size_t)kMaxRedBlocks * 3 * c;
 #define L(M) hipLaunchKernelGGL((merge_bwd_reduce<T, M>), dim3(nb), dim3(256), 0, st, a, dout, dsum, npix, c4n, part)
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
   SSMI_LAUNCH_CHECK();
   ssmi_status s = launch_bn_bwd_final(part, nb, c, npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
   if (s) return s;
-  hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main), bn3->mean,
-                     bn3->invstd, drop, coef, dmain, npix, c4n, (int64_t)d->h * d->w);
-  SSMI_LAUNCH_CHECK();
+  if (!coef_out) {
+    hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main), bn3->mean,
+                       bn3->invstd, drop, coef, dmain, npix, c4n, (int64_t)d->h * d->w);
+    SSMI_LAUNCH_CHECK();
+  }
   if (d->other_mode >= 2) {
     const int64_t t4 = (int64_t)d->n * (d->h / 2) * (d->w / 2) * c4n;
     if (d->other_mode == 2)
@@ -953,6 +957,39 @@ ssmi_status ssmi_merge_bwd(const ssmi_merge_desc* d, const void* dout, const voi
     using T = decltype(tag);
     return merge_bwd_impl<T>(d, a, bn3, drop, idx, static_cast<const T*>(dout), static_cast<T*>(dmain), static_cast<T*>(dsum),
                              static_cast<T*>(dother_bn), dgamma3, dbeta3, dalpha, ws, stream);
+  });
+}
+
+ssmi_status ssmi_merge_bwd_deferred(const ssmi_merge_desc* d, const void* dout, const void* main, const ssmi_bn_params* bn3,
+                                    const float* drop, const void* other, const ssmi_bn_params* bn_other, const int32_t* idx,
+                                    const float* alpha, void* dsum, void* dother_bn, float* dgamma3, float* dbeta3,
+                                    float* dalpha, float* coef, void* ws, size_t ws_bytes, void* stream) {
+  MergeArgs a;
+  ssmi_status s = fill_merge(d, main, bn3, drop, other, bn_other, idx, alpha, &a);
+  if (s) return s;
+  SSMI_REQUIRE(dout && dsum && coef, SSMI_E_INVALID_ARG, "merge_bwd_deferred: NULL argument");
+  SSMI_REQUIRE(d->other_mode < 2 || dother_bn, SSMI_E_INVALID_ARG, "merge_bwd_deferred: dother_bn required for mode %d", d->other_mode);
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_merge_workspace_bytes(d), SSMI_E_WORKSPACE, "merge_bwd_deferred: workspace too small");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return merge_bwd_impl<T>(d, a, bn3, drop, idx, static_cast<const T*>(dout), static_cast<T*>(nullptr), static_cast<T*>(dsum),
+                             static_cast<T*>(dother_bn), dgamma3, dbeta3, dalpha, ws, stream, coef);
+  });
+}
+
+ssmi_status ssmi_merge_bwd_apply(const ssmi_merge_desc* d, const void* dsum, const void* main, const ssmi_bn_params* bn3,
+                                 const float* drop, const float* coef, void* dmain, void* stream) {
+  SSMI_REQUIRE(d && dsum && main && bn3 && bn3->mean && bn3->invstd && coef && dmain, SSMI_E_INVALID_ARG, "merge_bwd_apply: NULL argument");
+  SSMI_REQUIRE(d->c > 0 && d->c % 4 == 0, SSMI_E_SHAPE, "merge_bwd_apply: channel count must be a multiple of 4");
+  const int c4n = d->c / 4;
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, as_stream(stream), static_cast<const T*>(dsum),
+                       static_cast<const T*>(main), bn3->mean, bn3->invstd, drop, coef, static_cast<T*>(dmain), npix, c4n,
+                       (int64_t)d->h * d->w);
+    SSMI_LAUNCH_CHECK();
+    return SSMI_OK;
   });
 }
 

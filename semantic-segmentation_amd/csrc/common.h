@@ -71,6 +71,15 @@ struct BnBwdArgs {
   // the operand on its way into the matrix core (a 1x1 convolution behind a training-phase BatchNormalization + PReLU:
   // the normalised tensor is never stored).  pre[0..4] = mean, invstd, gamma, beta, alpha (alpha nullptr: no activation)
   const float* pre[5];
+  // forward kernel run as a data gradient, PRE == 2 instantiation only: the operand dy is the gradient a bottleneck's merge
+  // backward would have stored, formed on the fly from what its reduction pass left behind (merge_bwd_apply's arithmetic):
+  //   dy = k1 * (dsum * drop - m1 - ((main - mean3) * invstd3) * m2)
+  // `x` of the launch is dsum; pm_main the raw main-branch tensor (same layout); pm[0..4] = mean3, invstd3, k1, m1, m2 per
+  // channel; pm_drop the [n, c] dropout table (nullptr: ones), pm_hw the pixels per image
+  const void* pm_main;
+  const float* pm[5];
+  const float* pm_drop;
+  unsigned pm_hw;
 };
 
 // Per-channel parameters of a BatchNormalization + PReLU whose output a kernel forms on the fly from the raw tensor

@@ -62,16 +62,20 @@ __device__ __forceinline__ unsigned xcd_tile(unsigned b, unsigned n, int on) {
 // PRE (float32 tensors, VEC, 1x1 stride 1, cin <= 64, statistics epilogue): the operand is act(BN(x)), formed from the raw
 // x when a step is multiplied (bn.pre; parameters of the <= 64 input channels through LDS).  Its own instantiation, so
 // that the plain kernels keep their register counts.
-template <typename T, int NT, bool VEC, bool PRE = false>
-__global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 2 ? 4 : 2)))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
+// PRE == 2 (float32, VEC, NT == 1, 1x1 stride 1, <= 128 input channels, BN-backward sums epilogue): the operand is the
+// gradient a bottleneck's merge backward would have stored, formed from dsum and the raw main-branch tensor (bn.pm*).
+template <typename T, int NT, bool VEC, int PRE = 0>
+__global__ __launch_bounds__(256, ((PRE == 1 && NT == 2) || PRE == 2 ? 3 : (NT == 1 ? 4 : (NT == 2 ? 4 : 2)))) void conv_fwd_kernel(Geo g, Sizes sz, const T* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        T* __restrict__ y, float* __restrict__ part, BnBwdArgs bn) {
   __shared__ float stat_sm[4 * 3 * NT * 32];
-  __shared__ __attribute__((aligned(16))) float pre_sm[PRE ? 5 * 64 : 4];
-  if constexpr (PRE) {      // every wave reaches this barrier (PRE launches always carry the statistics epilogue)
+  constexpr int kPreC = PRE == 2 ? 128 : 64;      // channels the parameter block in LDS covers
+  __shared__ __attribute__((aligned(16))) float pre_sm[PRE ? 5 * kPreC : 4];
+  if constexpr (PRE != 0) {      // every wave reaches this barrier (these launches always carry a statistics epilogue)
     for (int e = threadIdx.x; e < 5 * g.cin; e += 256) {
       const int k = e / g.cin, c = e - k * g.cin;
-      pre_sm[k * 64 + c] = bn.pre[k] ? bn.pre[k][c] : 0.f;
+      const float* src = PRE == 2 ? bn.pm[k] : bn.pre[k];
+      pre_sm[k * kPreC + c] = src ? src[c] : 0.f;
     }
     __syncthreads();
   }
@@ -208,10 +212,10 @@ __global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 
         wtap = tap < ntaps ? (unsigned)tap * tapbytes : kOOB;
       };
       settap();
-      const bool pre_act = PRE && bn.pre[4] != nullptr;
+      const bool pre_act = PRE == 1 && bn.pre[4] != nullptr;
       auto fetch = [&](u32x4& a, u32x4 (&b)[NT], int* cq = nullptr) {
         const unsigned cb = (unsigned)(c0 + 8 * hh) * 2u;
-        if constexpr (PRE) *cq = c0 < g.cin && tap == 0 ? c0 + 8 * hh : 0;      // (steps past the end multiply zeros)
+        if constexpr (PRE == 1) *cq = c0 < g.cin && tap == 0 ? c0 + 8 * hh : 0;      // (steps past the end multiply zeros)
         a = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (xo + cb) | (xo & (kOOB >> 1)), 0, 0));
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 
       };
       auto mma = [&](const u32x4& a, const u32x4 (&b)[NT], int cq = 0) {
         u32x4 av = a;
-        if constexpr (PRE) {
+        if constexpr (PRE == 1) {
           // the lane's eight channels: widened, normalised + activated as bn_act_fwd_kernel does, rounded to bfloat16 as its
           // store would have rounded them
 #pragma unroll
@@ -277,12 +281,18 @@ __global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 
       wtap = tap < ntaps ? (unsigned)(tap * g.cin) * wrow : kOOB;
     };
     settap();
-    const bool pre_act = PRE && bn.pre[4] != nullptr;
-    auto fetch = [&](f32x4& a, float (&b)[4][NT], int* cq = nullptr) {
+    const bool pre_act = PRE == 1 && bn.pre[4] != nullptr;
+    const __amdgpu_buffer_rsrc_t rmain = Act<T>::rsrc(PRE == 2 ? bn.pm_main : (const void*)x, PRE == 2 ? sz.x_bytes : 0u);
+    const unsigned drop_off = PRE == 2 && bn.pm_drop ? n_ * (unsigned)g.cin : 0u;      // the lane's image in the dropout table
+    auto fetch = [&](f32x4& a, float (&b)[4][NT], int* cq = nullptr, f32x4* a2 = nullptr, f32x4* dv = nullptr) {
       // valid offsets are below 2^31, so OR-ing bit 31 in (kOOB) is the out-of-range mask: no compare/select per load
       const unsigned cib = (unsigned)(c0 + 4 * hh);
-      if constexpr (PRE) *cq = c0 < g.cin && tap == 0 ? (int)cib : 0;      // (steps past the end multiply zeros)
+      if constexpr (PRE != 0) *cq = c0 < g.cin && tap == 0 ? (int)cib : 0;      // (steps past the end multiply zeros)
       a = Act<T>::ld4(rx, (xo + cib * 4u) | (xo & kOOB));
+      if constexpr (PRE == 2) {
+        *a2 = Act<T>::ld4(rmain, (xo + cib * 4u) | (xo & kOOB));
+        *dv = bn.pm_drop ? *reinterpret_cast<const f32x4*>(bn.pm_drop + drop_off + (unsigned)*cq) : f32x4{1.f, 1.f, 1.f, 1.f};
+      }
       const unsigned wb = wtap + cib * wrow, wm = wtap & kOOB;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -296,9 +306,19 @@ __global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 
         settap();
       }
     };
-    auto mma = [&](const f32x4& a, const float (&b)[4][NT], int cq = 0) {
+    auto mma = [&](const f32x4& a, const float (&b)[4][NT], int cq = 0, const f32x4* a2 = nullptr, const f32x4* dv = nullptr) {
       f32x4 av = a;
-      if constexpr (PRE) {
+      if constexpr (PRE == 2) {      // merge_bwd_apply's arithmetic
+        const f32x4 m = *reinterpret_cast<const f32x4*>(pre_sm + cq), is = *reinterpret_cast<const f32x4*>(pre_sm + kPreC + cq);
+        const f32x4 k1 = *reinterpret_cast<const f32x4*>(pre_sm + 2 * kPreC + cq), m1 = *reinterpret_cast<const f32x4*>(pre_sm + 3 * kPreC + cq);
+        const f32x4 m2 = *reinterpret_cast<const f32x4*>(pre_sm + 4 * kPreC + cq);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = ((*a2)[j] - m[j]) * is[j];
+          av[j] = k1[j] * (a[j] * (*dv)[j] - m1[j] - xh * m2[j]);
+        }
+      }
+      if constexpr (PRE == 1) {
         const f32x4 m = *reinterpret_cast<const f32x4*>(pre_sm + cq), is = *reinterpret_cast<const f32x4*>(pre_sm + 64 + cq);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(pre_sm + 128 + cq), be = *reinterpret_cast<const f32x4*>(pre_sm + 192 + cq);
         const f32x4 al = *reinterpret_cast<const f32x4*>(pre_sm + 256 + cq);
@@ -312,7 +332,18 @@ __global__ __launch_bounds__(256, ((PRE && NT == 2) ? 3 : (NT == 1 ? 4 : (NT == 
         for (int t = 0; t < NT; ++t) acc[t] = MFMA32(av[j], b[j][t], acc[t]);
     };
     const int nsteps = ntaps * (g.cin >> 3);
-    if constexpr (PRE) {
+    if constexpr (PRE == 2) {
+      f32x4 a0, a1, c0_, c1_, d0, d1;
+      float b0[4][NT], b1[4][NT];
+      int q0, q1;
+      fetch(a0, b0, &q0, &c0_, &d0);
+      for (int i = 0; i < nsteps; i += 2) {
+        fetch(a1, b1, &q1, &c1_, &d1);               // past the end: zeros (tap >= ntaps)
+        mma(a0, b0, q0, &c0_, &d0);
+        fetch(a0, b0, &q0, &c0_, &d0);
+        if (i + 1 < nsteps) mma(a1, b1, q1, &c1_, &d1);
+      }
+    } else if constexpr (PRE == 1) {
       // (1x1 over at most 64 channels: at most eight steps, two in flight)
       f32x4 a0, a1, a2;
       float b0[4][NT], b1[4][NT], b2[4][NT];
@@ -2446,6 +2477,11 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
 
 // part != nullptr: the kernel also writes per-workgroup column sums of y and y^2, part[row][2][cout]; *part_rows = rows.
 // bn.mean != nullptr: inference-phase BatchNormalization + activation applied in the epilogue (bn.x stays nullptr).
+// forward-form launches (the data gradient of a 1x1 layer) that can form a merge backward's output on load (PRE == 2)
+static bool premerge_ok(const Geo& f) {
+  return f.kh == 1 && f.kw == 1 && f.stride == 1 && f.cin % 8 == 0 && f.cin <= 128 && f.cout <= 32 && f.x_ld == f.cin;
+}
+
 // layers whose forward pass can take act(BN(x)) of a raw input (PRE instantiations of conv_fwd_kernel)
 static bool fwd_prebn_ok(const Geo& g) {
   return g.kh == 1 && g.kw == 1 && g.stride == 1 && g.cin % 8 == 0 && g.cin <= 64 && g.cout > 32 && g.x_ld % 4 == 0;
@@ -2473,14 +2509,27 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   const int nt = pick_nt(g.cout);
   dim3 grid((unsigned)ceil_div64(M, 128), (unsigned)((g.cout + 32 * nt - 1) / (32 * nt)), 1);
   const bool vec = (g.cin % 8 == 0) && (g.x_ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (bn.pm_main != nullptr) {
+    if constexpr (sizeof(T) == 4) {
+      SSMI_REQUIRE(premerge_ok(g) && vec && nt == 1 && bn.x != nullptr, SSMI_E_UNSUPPORTED,
+                   "conv2d_bwd_data (merge backward on load): layer shape not supported");
+      set_last_kernel("conv_fwd_kernel<1, true> premerge");
+      hipLaunchKernelGGL((conv_fwd_kernel<T, 1, true, 2>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
+      SSMI_LAUNCH_CHECK();
+      return SSMI_OK;
+    } else {
+      set_error("conv2d_bwd_data (merge backward on load): float32 tensors only");
+      return SSMI_E_UNSUPPORTED;
+    }
+  }
   if (pre) {
     {
       SSMI_REQUIRE(fwd_prebn_ok(g) && vec && part != nullptr && (sizeof(T) == 4 || g.cin % 16 == 0), SSMI_E_UNSUPPORTED,
                    "conv2d_fwd (normalise on load): needs a 1x1 stride-1 layer over 8..64 channels (multiple of 8) with more than 32 "
                    "output channels, 16-byte aligned rows and the statistics epilogue");
       set_last_kernel(bn.wpack ? "conv_fwd_kernel<%d, true> prebn bf16 mfma" : "conv_fwd_kernel<%d, true> prebn", nt);
-      if (nt == 2) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, true, true>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
-      else hipLaunchKernelGGL((conv_fwd_kernel<T, 4, true, true>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
+      if (nt == 2) hipLaunchKernelGGL((conv_fwd_kernel<T, 2, true, 1>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
+      else hipLaunchKernelGGL((conv_fwd_kernel<T, 4, true, 1>), grid, dim3(256), 0, st, g, sz, x, w, bias, y, part, bn);
       SSMI_LAUNCH_CHECK();
       return SSMI_OK;
     }
@@ -3413,7 +3462,8 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
                                                const T* bn_x, int32_t ld_x, const float* mean, const float* invstd,
                                                const float* gamma, const float* beta, int32_t act, const float* alpha,
                                                float slope, const float* drop, int64_t hw, T* dx_bn, float* dgamma,
-                                               float* dbeta, float* dalpha, void* ws, size_t ws_bytes, void* stream) {
+                                               float* dbeta, float* dalpha, void* ws, size_t ws_bytes, void* stream,
+                                               const ssmi_premerge* pm = nullptr) {
   const Geo g = to_geo(d);
   const int64_t npix = (int64_t)d->n * d->h * d->w;
   const int c = d->cin;
@@ -3432,6 +3482,11 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
   BnBwdArgs bb{};
   bb.x = bn_x; bb.ld = ld_x; bb.mean = mean; bb.invstd = invstd; bb.gamma = gamma; bb.beta = beta; bb.alpha = alpha;
   bb.slope = slope; bb.act = act; bb.drop = drop; bb.hw = drop ? (unsigned)hw : 1u; bb.part = part;
+  if (pm) {
+    bb.pm_main = pm->main;
+    bb.pm[0] = pm->mean; bb.pm[1] = pm->invstd; bb.pm[2] = pm->coef; bb.pm[3] = pm->coef + d->cout; bb.pm[4] = pm->coef + 2 * d->cout;
+    bb.pm_drop = pm->drop; bb.pm_hw = (unsigned)pm->hw;
+  }
   int rows = 0;
   ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows, wt, w_rot);
   if (s) return s;
@@ -3484,6 +3539,40 @@ ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot(const ssmi_conv_desc* d, const void*
                                           static_cast<const T*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop,
                                           hw, static_cast<T*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream);
   });
+}
+
+int32_t ssmi_conv2d_bwd_data_premerge_supported(const ssmi_conv_desc* d) {
+  if (check_desc(d) != SSMI_OK || d->dtype != SSMI_F32) return 0;
+  static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;
+  const Geo g = to_geo(d);
+  if (no_fuse || !dgrad_as_fwd(g, true) || g.cin % 4 != 0 || g.x_ld % 4 != 0) return 0;
+  Geo f = g;      // the forward-form launch of the data gradient
+  f.h = g.ho; f.w = g.wo; f.cin = g.cout; f.x_ld = g.y_ld;
+  f.ho = g.h; f.wo = g.w; f.cout = g.cin; f.y_ld = g.x_ld;
+  return premerge_ok(f) && pick_nt(f.cout) == 1;
+}
+
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd_premerge(const ssmi_conv_desc* d, const ssmi_premerge* pm, const float* w,
+                                                 const float* w_rot, void* da, const void* bn_x, int32_t ld_x,
+                                                 const float* mean, const float* invstd, const float* gamma,
+                                                 const float* beta, int32_t act, const float* alpha, float slope,
+                                                 void* dx_bn, float* dgamma, float* dbeta, float* dalpha, void* ws,
+                                                 size_t ws_bytes, void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(pm && pm->dsum && pm->main && pm->mean && pm->invstd && pm->coef && w && w_rot && da && bn_x && mean && invstd &&
+               gamma && beta && dx_bn, SSMI_E_INVALID_ARG, "conv2d_bwd_data_bn_bwd_premerge: NULL argument");
+  SSMI_REQUIRE(ssmi_conv2d_bwd_data_premerge_supported(d), SSMI_E_UNSUPPORTED,
+               "conv2d_bwd_data_bn_bwd_premerge: layer not supported (float32, 1x1 stride 1, forward-form data gradient, <= 32 input and "
+               "<= 128 output channels)");
+  SSMI_REQUIRE(!pm->drop || (pm->hw > 0 && ((int64_t)d->ho * d->wo) % pm->hw == 0), SSMI_E_SHAPE, "conv2d_bwd_data_bn_bwd_premerge: bad hw");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_bwd_data_bn_bwd_premerge: workspace too small");
+  SSMI_REQUIRE(act >= SSMI_ACT_NONE && act <= SSMI_ACT_LEAKY && (act != SSMI_ACT_PRELU || alpha), SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd_premerge: bad activation");
+  return conv2d_bwd_data_bn_bwd_impl<float>(d, static_cast<const float*>(pm->dsum), w, w_rot, nullptr, static_cast<float*>(da),
+                                            static_cast<const float*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope,
+                                            nullptr, 1, static_cast<float*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream, pm);
 }
 
 size_t ssmi_conv2d_bwd_weight_workspace_bytes(const ssmi_conv_desc* d) {

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from ._lib import BF16, F32, BnParams, ConvDesc, MergeDesc, lib, lib_for
+from ._lib import BF16, F32, BnParams, ConvDesc, MergeDesc, Premerge, lib, lib_for
 
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.1   # src/models.py:1064 (weight of the OLD moving value)
@@ -164,6 +164,7 @@ class Conv:
         self.pack_usage = 0       # bf16 storage: bit 0 / 1 = forward / data gradient can run from a bfloat16 kernel pack
         self.uses_rot = False     # the data gradient can use a pre-rotated kernel matrix (decided by the library in plan())
         self.prebn_ok = False
+        self.premerge_ok = False
         self.wrot = None          # that matrix: a view of the network's rotated arena, refreshed once per step
 
     def plan(self, n, h, w, x_ld=None, y_ld=None):
@@ -194,6 +195,10 @@ class Conv:
             # operand themselves (ssmi_conv2d_*_prebn)
             self.prebn_ok = bool(lib().conv2d_prebn_supported(C.byref(d), 1 if self.has_bias else 0)) and \
                 not os.environ.get("SSMI_NO_PREBN")
+            # the data gradient can form the output of a bottleneck's merge backward on load (ssmi_conv2d_bwd_data_bn_bwd_premerge)
+            # (opt-in through SSMI_PREMERGE=1: measured slower - the data gradient then reads two tensors instead of one while
+            # the stored tensor is still written for the weight gradient)
+            self.premerge_ok = bool(os.environ.get("SSMI_PREMERGE")) and bool(lib().conv2d_bwd_data_premerge_supported(C.byref(d)))
             self.pack_usage = int(L.conv2d_pack_usage(C.byref(d))) if not os.environ.get("SSMI_NO_BF16_MFMA") else 0
         else:
             # the forward convolution this layer is the gradient of: [n, h*s, w*s, cout_t] -> [n, h, w, cin_t]
@@ -292,6 +297,13 @@ class Conv:
                                                 _ptr(bn.alpha), slope, _ptr(drop), hw, _ptr(dx_bn), _ptr(bn.dgamma),
                                                 _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(ws), ws.numel() * 4, st)
 
+    def bwd_data_bn_premerge(self, pm: Premerge, da, bn: "BatchNorm", bn_x, ld_x, dx_bn, ws, st):
+        """bwd_data_bn whose output gradient is a merge backward left unformed (`pm`); needs `wrot` and `premerge_ok`."""
+        lib().conv2d_bwd_data_bn_bwd_premerge(self._dref, C.byref(pm), _ptr(self.w), _ptr(self.wrot), _ptr(da), _ptr(bn_x), ld_x,
+                                              _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta),
+                                              ACT_PRELU if bn.alpha is not None else ACT_NONE, _ptr(bn.alpha), 0.0, _ptr(dx_bn),
+                                              _ptr(bn.dgamma), _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(ws), ws.numel() * 4, st)
+
     def bwd_weight(self, x, dy, ws, st):
         L = self.store.L
         if self.transpose:
@@ -379,17 +391,21 @@ class RunCfg:
         self._pending = []
         self._turn = 0
 
-    def wgrad(self, conv, x, dy, pre=None):
-        """`pre`: the BatchNorm (+PReLU) whose output is this layer's input when `x` is that BatchNorm's RAW input."""
+    def wgrad(self, conv, x, dy, pre=None, before=None):
+        """`pre`: the BatchNorm (+PReLU) whose output is this layer's input when `x` is that BatchNorm's RAW input.
+        `before(stream)`: work that produces `dy` and is needed by nothing else; launched in front of the weight gradient, on
+        the stream it runs on."""
         if _ABLATE_WGRAD:       # timing experiment only: the step then computes no weight gradients at all
             return
         if self.side is None:
+            if before is not None:
+                before(self.st)
             if pre is not None:
                 conv.bwd_weight_prebn(x, pre, dy, self.ws, self.st)
             else:
                 conv.bwd_weight(x, dy, self.ws, self.st)
             return
-        self._pending.append((conv, x, dy, pre))
+        self._pending.append((conv, x, dy, pre, before))
 
     def flush(self):
         """Launches the weight gradients collected since the last flush on the side stream, behind everything the main
@@ -403,7 +419,9 @@ class RunCfg:
         ev = torch.cuda.Event()
         ev.record(self.main)
         side.wait_event(ev)
-        for conv, x, dy, pre in self._pending:
+        for conv, x, dy, pre, before in self._pending:
+            if before is not None:
+                before(side.cuda_stream)
             if pre is not None:
                 conv.bwd_weight_prebn(x, pre, dy, ws2, side.cuda_stream)
             else:
@@ -605,6 +623,7 @@ class Bottleneck(Block):
         # gradients
         self.dy3 = torch.empty_like(self.y3)
         self.dsum = torch.empty_like(self.y3)
+        self.coef3 = torch.empty(3 * c, dtype=torch.float32, device=dev)     # merge backward's coefficients (deferred apply pass)
         self.da2 = torch.empty_like(self.a2)   # reused in place for dy2
         self.da1 = torch.empty_like(self.a1)   # reused in place for dy1
         self.dx = torch.empty(n, h, w, self.cin, **f32)
@@ -698,15 +717,35 @@ class Bottleneck(Block):
         wsb = ws.numel() * 4
         i = self.internal
         other, bn_o, idx = self._merge_other()
-        L.merge_bwd(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o, _ptr(idx),
-                    _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
-                    _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
+        # The merge backward's last pass (dy3 from dsum, y3 and three coefficient vectors) is off the main chain where conv3's
+        # data gradient can apply it to its own operand: dy3 is then stored only for conv3's weight gradient, in front of it
+        # on its stream.
+        premerge = self.conv3.premerge_ok and self.conv3.wrot is not None
+        before3 = None
+        if premerge:
+            L.merge_bwd_deferred(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o,
+                                 _ptr(idx), _ptr(self.alpha3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
+                                 _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(self.coef3), _ptr(ws), wsb, st)
+            drop3 = self._drop_used
+
+            def before3(stream, L=L, drop3=drop3):
+                L.merge_bwd_apply(self._mref, _ptr(self.dsum), _ptr(self.y3), self.bn3._pref, _ptr(drop3), _ptr(self.coef3),
+                                  _ptr(self.dy3), stream)
+        else:
+            L.merge_bwd(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o, _ptr(idx),
+                        _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
+                        _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
         # conv3
         if getattr(self, "_pre3", False):
-            cfg.wgrad(self.conv3, self.y2, self.dy3, pre=self.bn2)
+            cfg.wgrad(self.conv3, self.y2, self.dy3, pre=self.bn2, before=before3)
         else:
-            cfg.wgrad(self.conv3, self.a2, self.dy3)
-        self.conv3.bwd_data_bn(self.dy3, self.da2, self.bn2, self.y2, i, self.da2, self.np_out, ws, st)   # da2 -> dy2 (in place)
+            cfg.wgrad(self.conv3, self.a2, self.dy3, before=before3)
+        if premerge:
+            pm = Premerge(_ptr(self.dsum), _ptr(self.y3), _ptr(self.bn3.mean), _ptr(self.bn3.invstd), _ptr(self.coef3),
+                          _ptr(self._drop_used), self.ho * self.wo)
+            self.conv3.bwd_data_bn_premerge(pm, self.da2, self.bn2, self.y2, i, self.da2, ws, st)      # da2 -> dy2 (in place)
+        else:
+            self.conv3.bwd_data_bn(self.dy3, self.da2, self.bn2, self.y2, i, self.da2, self.np_out, ws, st)   # da2 -> dy2 (in place)
         # conv2
         if self.conv2a is not None:
             cfg.wgrad(self.conv2, self.t, self.da2)

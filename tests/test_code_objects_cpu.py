@@ -116,8 +116,10 @@ def test_weight_gradient_slot_classes_keep_their_register_budget(kernels):
 
 
 def test_direct_convolution_kernels_fit_their_launch_bounds(kernels):
-    """conv_fwd_kernel<T, 1, VEC> is bound to four workgroups per CU: 128 registers."""
+    """conv_fwd_kernel<T, 1, VEC> is bound to four workgroups per CU: 128 registers (its merge-backward-on-load
+    instantiation, <float, 1, true, 2>, to three: 168)."""
     ks = [k for k in _named(kernels, "_ZN4ssmi15conv_fwd_kernelI") if "Li1ELb" in k[".name"][:len("_ZN4ssmi15conv_fwd_kernelI") + 12]]
-    assert len(ks) == 4
+    plain = [k for k in ks if "Li1ELb1ELi2E" not in k[".name"] and "Li1ELb0ELi2E" not in k[".name"]]
+    assert len(ks) == 5 and len(plain) == 4
     for k in ks:
-        assert k[".vgpr_count"] + k[".agpr_count"] <= 128, (k[".name"], k[".vgpr_count"])
+        assert k[".vgpr_count"] + k[".agpr_count"] <= (128 if k in plain else 168), (k[".name"], k[".vgpr_count"])

@@ -89,6 +89,39 @@ def test_unsupported_layers_are_reported():
         assert not cv.prebn_ok
 
 
+def test_deferred_merge_backward_equals_the_stored_route(monkeypatch):
+    """ssmi_merge_bwd_deferred + ssmi_conv2d_bwd_data_bn_bwd_premerge (conv3's data gradient applies the merge backward's last
+    pass to its own operand; the stored tensor is written on the weight-gradient stream only) against ssmi_merge_bwd +
+    ssmi_conv2d_bwd_data_bn_bwd_rot: a whole training step, 3 steps, identical losses, matrices and weights.  With dropout
+    tables in use (the default training step draws them), so the per-image table lookup is exercised."""
+    from oracle import enet_oracle as E
+    models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
+    name, NC, B, H, W = "enet-naive-upsampling", 24, 3, 64, 64
+    w0 = E.init_weights(name, NC, seed=8, perturb=True)
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=9, block=8)
+    res = []
+    for off in (False, True):
+        if off:
+            monkeypatch.delenv("SSMI_PREMERGE", raising=False)
+        else:
+            monkeypatch.setenv("SSMI_PREMERGE", "1")      # opt-in (measured slower than the stored route, so off by default)
+        m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY).model
+        m.set_weights([w0[k] for k in m.weight_names()])
+        m.compile(optimizer=xo.Adam(lr=1e-3), metrics={'logits': [metrics.segmentation_confusion_matrix(NC, 0, [0])]})
+        with torch.cuda.stream(torch.cuda.Stream()):
+            outs = [m.train_on_batch([images, labels, pw, np.zeros((B, 1), np.int32)]) for _ in range(3)]
+        torch.cuda.synchronize()
+        used = [b.name for b in m.graph.blocks if getattr(getattr(b, "conv3", None), "premerge_ok", False) and b.conv3.wrot is not None]
+        assert bool(used) != off, "deferred merge backward {} (blocks: {})".format("ran although switched off" if off else "did not run", used)
+        res.append((outs, [w.copy() for w in m.get_weights()]))
+    (o0, w0_), (o1, w1_) = res
+    for a, b in zip(o0, o1):
+        for u, v in zip(a, b):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
+    for u, v in zip(w0_, w1_):
+        assert np.array_equal(u, v)
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_training_step_is_identical_with_and_without_normalise_on_load(monkeypatch, dtype):
     from oracle import enet_oracle as E
