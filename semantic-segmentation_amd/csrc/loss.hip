@@ -692,7 +692,7 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
   const int64_t total = (int64_t)n * (2 * h) * (2 * w);
   SSMI_REQUIRE(npix <= total && npix_metrics >= 0 && npix_metrics <= total, SSMI_E_INVALID_ARG,
                "logits_tconv2x2_xent: npix / npix_metrics exceed the %lld output pixels", (long long)total);
-  SSMI_REQUIRE(total * num_classes < 0x7FFFFFFFLL / 2 * 2 && x_ld >= cin && x_ld % 4 == 0, SSMI_E_UNSUPPORTED,
+  SSMI_REQUIRE(total * num_classes < 0x7FFFFFFFLL && x_ld >= cin && x_ld % 4 == 0, SSMI_E_UNSUPPORTED,
                "logits_tconv2x2_xent: tensor too large for 32-bit pixel indices, or row stride %d not a multiple of 4", x_ld);
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_softmax_xent_workspace_bytes(npix), SSMI_E_WORKSPACE, "logits_tconv2x2_xent: workspace too small");
   const size_t esz = dtype == SSMI_BF16 ? 2 : 4;
