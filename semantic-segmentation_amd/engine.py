@@ -365,18 +365,21 @@ class BatchNorm:
 
 
 _ABLATE_WGRAD = os.environ.get("SSMI_ABLATE_WGRAD") is not None
+_WGRAD_LAG = int(os.environ.get("SSMI_WGRAD_LAG", "1"))      # blocks between a fork point and the launches behind it (0: at once)
+_WGRAD_FORK_PER_CONV = os.environ.get("SSMI_WGRAD_FORK", "conv") == "conv"      # one fork point per layer instead of one per block
 
 
 class RunCfg:
     """Per-call switches threaded through the blocks.
 
     Weight gradients never feed the rest of the backward pass, so they run on a second HIP stream (`side`) with their
-    own workspace: `wgrad()` collects them, `flush()` (called after every block) launches the collected ones on the side
-    stream behind what the main stream has queued so far, `join()` makes the main stream wait for the side stream.
+    own workspace: `wgrad()` marks the layer's fork point on the main stream (its operands are ready) and collects it,
+    `flush()` (called after every block) launches the collected ones on the side stream, each behind its fork point,
+    `join()` makes the main stream wait for the side stream.
     Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the latency-bound
     main chain (small BN / merge kernels) is running.  Without a side stream wgrad() launches in place."""
     __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws", "main", "side", "ws2",
-                 "_forked", "_pending", "_sides", "_turn")
+                 "_forked", "_pending", "_sides", "_turn", "_deferred")
 
     def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws, main=None, side=None, ws2=None):
         self.training, self.update_moving, self.unbiased_moving = training, update_moving, unbiased_moving
@@ -389,6 +392,7 @@ class RunCfg:
         self.main, self.side, self.ws2 = main, side, ws2
         self._forked = False
         self._pending = []
+        self._deferred = []
         self._turn = 0
 
     def wgrad(self, conv, x, dy, pre=None, before=None):
@@ -405,32 +409,58 @@ class RunCfg:
             else:
                 conv.bwd_weight(x, dy, self.ws, self.st)
             return
-        self._pending.append((conv, x, dy, pre, before))
+        ev = None
+        if _WGRAD_FORK_PER_CONV:      # the layer's own fork point: its operands are ready now
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+        self._pending.append((conv, x, dy, pre, before, ev))
 
     def flush(self):
-        """Launches the weight gradients collected since the last flush on the side stream, behind everything the main
-        stream has queued so far (one fork per block instead of one per convolution)."""
-        if self.side is None or not self._pending:
+        """Puts the weight gradients collected since the last flush on the side stream, each behind its own fork point (or,
+        with SSMI_WGRAD_FORK=block, behind everything the main stream has queued so far).  The launches themselves are
+        issued at the NEXT flush (or join), after the main stream has queued the kernels of one more block.
+        The dependencies are the same either way, but under graph capture the order in which a node's dependents are
+        created is the order of its edges, and the HIP runtime keeps a node's FIRST dependent on the node's own hardware
+        queue and moves the others to the next queue: launched at once, the side branch would inherit the main chain's queue
+        at every fork and the main chain would hop from queue to queue, ending up queued behind weight gradients of
+        earlier blocks."""
+        if self.side is None:
             return
+        self._launch_deferred(max(_WGRAD_LAG - 1, 0))
+        if not self._pending:
+            return
+        ev = torch.cuda.Event()
+        ev.record(self.main)
+        self._deferred.append((ev, self._pending))
+        self._pending = []
+        if _WGRAD_LAG == 0:
+            self._launch_deferred(0)
+
+    def _launch_deferred(self, keep):
+        while len(self._deferred) > keep:
+            self._launch_group(*self._deferred.pop(0))
+
+    def _launch_group(self, ev, items):
         side, ws2 = self.side, self.ws2
         if self._sides:      # blocks take turns (alternating per convolution instead measured slower)
             side, ws2 = self._sides[self._turn % len(self._sides)]
             self._turn += 1
-        ev = torch.cuda.Event()
-        ev.record(self.main)
-        side.wait_event(ev)
-        for conv, x, dy, pre, before in self._pending:
+        if not _WGRAD_FORK_PER_CONV:
+            side.wait_event(ev)
+        for conv, x, dy, pre, before, own in items:
+            if own is not None:
+                side.wait_event(own)
             if before is not None:
                 before(side.cuda_stream)
             if pre is not None:
                 conv.bwd_weight_prebn(x, pre, dy, ws2, side.cuda_stream)
             else:
                 conv.bwd_weight(x, dy, ws2, side.cuda_stream)
-        self._pending = []
         self._forked = True
 
     def join(self):
         self.flush()
+        self._launch_deferred(0)
         if self.side is not None and self._forked:
             for side in ([sd for sd, _ in self._sides] if self._sides else [self.side]):
                 ev = torch.cuda.Event()
@@ -1070,12 +1100,15 @@ class GraphBase:
             else self.ws
         if self.side_stream is None and dev.type == "cuda" and self.overlap_weight_gradients:
             self.side_stream = torch.cuda.Stream(device=dev)
-        # Several weight-gradient streams, used by the blocks in turn: a strip kernel keeps one latency-bound workgroup per CU,
-        # so a few of them beside the data-gradient chain fill the chip better than one.  Measured (ENet 512x512 batch 16,
-        # float32 / bf16 storage, ms per step): 1 stream 10.41 / 9.22, 2: 9.84 / 8.46, 3: 10.42 / 9.15, 4: 9.72 / 8.30,
-        # 5: 10.19 / 8.82, 6: 9.80 / 8.38, 8: 9.73 / 8.30 - odd counts put the two heavy layers of consecutive blocks on the
-        # same stream.  SSMI_WGRAD_STREAMS overrides for measurements.
-        nside = int(os.environ.get("SSMI_WGRAD_STREAMS", "4"))
+        # ONE weight-gradient stream.  Under graph replay the HIP runtime does not keep captured streams apart: it walks the
+        # graph depth-first, keeps a node's first dependent on the node's hardware queue and gives every further dependent
+        # the next queue.  One side chain whose launches are created after the main chain's next kernel (RunCfg.flush)
+        # leaves the main chain on one queue and all weight gradients on the second.  Measured (ENet 512x512 batch 16,
+        # float32 / bf16 storage, ms per step, one box): 1 stream 8.89 / 6.65, 2: 9.94 / 7.46, 4: 10.5 / 7.9; with the
+        # launches created at their fork point (side branch = first dependent, the main chain hops from queue to queue and
+        # lands behind weight gradients of earlier blocks): 4 streams 9.25 / 7.03, 1 stream 10.2 / 7.6.
+        # SSMI_WGRAD_STREAMS overrides for measurements.
+        nside = int(os.environ.get("SSMI_WGRAD_STREAMS", "1"))
         self.side_streams = self.side_wss = None
         if nside > 1 and self.side_stream is not None:
             self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=dev) for _ in range(nside - 1)]
