@@ -200,3 +200,39 @@ def test_thirty_step_loss_trajectory_matches_the_oracle_and_falls():
     assert np.all(rel <= 5e-3), (rel.max(), own.max())
     assert got[-1] < 0.9 * got[0] and np.mean(got[-5:]) < np.mean(got[:5])
     assert r64[-1] < 0.9 * r64[0]
+
+
+def test_weight_gradient_schedule_does_not_change_results(monkeypatch):
+    """Where the weight gradients are forked from the main stream and when their launches are created (engine.RunCfg:
+    per-layer fork points, launches issued one block later) is scheduling only: the step with one fork per block and
+    immediate launches, and the step with everything on the main stream, give the same bits; nothing stays queued."""
+    import numpy as np
+    import torch
+    from conftest import pkg
+    from oracle import enet_oracle as E
+    eng = pkg("engine")
+    models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
+    name, NC, B, H, W = "enet-max-unpooling", 24, 2, 64, 64
+    w0 = E.init_weights(name, NC, seed=21, perturb=True)
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=22, block=8)
+    res = []
+    for lag, per_conv, overlap in ((1, True, True), (0, False, True), (2, True, True), (1, True, False)):
+        monkeypatch.setattr(eng, "_WGRAD_LAG", lag)
+        monkeypatch.setattr(eng, "_WGRAD_FORK_PER_CONV", per_conv)
+        m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY).model
+        m.graph.overlap_weight_gradients = overlap
+        m.set_weights([w0[k] for k in m.weight_names()])
+        m.compile(optimizer=xo.Adam(lr=1e-3), metrics={'logits': [metrics.segmentation_confusion_matrix(NC, 0, [0])]})
+        with torch.cuda.stream(torch.cuda.Stream()):
+            outs = [m.train_on_batch([images, labels, pw, np.zeros((B, 1), np.int32)]) for _ in range(3)]
+        torch.cuda.synchronize()
+        cfg = m.graph._cfg
+        assert not cfg._pending and not cfg._deferred, "weight gradients left unlaunched"
+        assert (cfg.side is not None) == overlap
+        res.append((outs, [w.copy() for w in m.get_weights()]))
+    for outs, ws in res[1:]:
+        for a, b in zip(res[0][0], outs):
+            for u, v in zip(a, b):
+                assert np.array_equal(np.asarray(u), np.asarray(v))
+        for u, v in zip(res[0][1], ws):
+            assert np.array_equal(u, v)
