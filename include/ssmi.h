@@ -61,6 +61,12 @@ ssmi_status ssmi_profile_get(int32_t index, char* name, int32_t name_len, float*
  * kernel trace (rocprofv3 reports the kernel's own begin/end timestamps). */
 float ssmi_profile_bracket_overhead_ms(void);
 int32_t ssmi_version(void);
+/* A one-thread kernel that stores the device's constant-rate wall clock (ticks; ssmi_device_timestamp_khz() ticks per
+ * millisecond, 0 if unknown) into *out when the stream reaches it.  Unlike an event it can be captured into a HIP graph
+ * and read after every replay: the only way to time points INSIDE a captured step (where the main chain ends, where a
+ * segment starts).  Profiling aid, no reference counterpart. */
+ssmi_status ssmi_device_timestamp(int64_t* out, void* stream);
+int32_t ssmi_device_timestamp_khz(void);
 
 /* ------------------------------------------------------------------------------------------------------
  * Convolutions.  Kernel layout HWIO = [kh][kw][cin][cout] (Keras Conv2D).  Cross-correlation.

@@ -143,6 +143,8 @@ _PROTOS = {
     "ssmi_predict_accumulate": (_i32, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "ssmi_predict_topk": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "ssmi_profile_bracket_overhead_ms": (_f32, []),
+    "ssmi_device_timestamp": (_i32, [_vp, _vp]),
+    "ssmi_device_timestamp_khz": (_i32, []),
     "ssmi_graph_begin_capture": (_i32, [_vp]),
     "ssmi_graph_end_capture": (_i32, [_vp, C.POINTER(_vp)]),
     "ssmi_graph_launch": (_i32, [_vp, _vp]),
@@ -159,7 +161,7 @@ _PROTOS["ssmi_cast_bf16_to_f32"] = (_i32, [_vp, _vp, _i64, _vp])
 F32, BF16 = 0, 1      # ssmi dtype codes of activation tensors
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_conv2d_bwd_data_premerge_supported", "ssmi_conv2d_prebn_supported", "ssmi_logits_tconv2x2_xent_supported", "ssmi_profile_bracket_overhead_ms", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_conv2d_bwd_data_premerge_supported", "ssmi_conv2d_prebn_supported", "ssmi_logits_tconv2x2_xent_supported", "ssmi_profile_bracket_overhead_ms", "ssmi_device_timestamp_khz", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 

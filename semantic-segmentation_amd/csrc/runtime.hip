@@ -273,6 +273,27 @@ ssmi_status ssmi_profile_get(int32_t index, char* name, int32_t name_len, float*
 float ssmi_profile_bracket_overhead_ms(void) { return g_bracket_overhead_ms; }
 int32_t ssmi_version(void) { return 100; }
 
+}  // extern "C"
+
+namespace ssmi {
+__global__ void timestamp_kernel(int64_t* __restrict__ out) { *out = (int64_t)wall_clock64(); }
+}  // namespace ssmi
+
+extern "C" {
+
+ssmi_status ssmi_device_timestamp(int64_t* out, void* stream) {
+  SSMI_REQUIRE(out, SSMI_E_INVALID_ARG, "device_timestamp: NULL output");
+  hipLaunchKernelGGL(ssmi::timestamp_kernel, dim3(1), dim3(1), 0, as_stream(stream), out);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+int32_t ssmi_device_timestamp_khz(void) {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+  return khz;
+}
+
 ssmi_status ssmi_adam_step(float* params, const float* grads, float* m, float* v, float* vhat, int64_t count,
                            int64_t* step, float lr, float beta_1, float beta_2, float epsilon, float decay,
                            float grad_scale, const float* lr_scale, void* stream) {

@@ -777,3 +777,23 @@ def test_maxpool_fuzz(n, h, w, c):
 @pytest.mark.parametrize("C_,npix", _rand_cases(20, 7, lambda r: (int(r.randint(2, 65)), int(r.randint(1, 4000)))))
 def test_softmax_xent_fuzz(C_, npix):
     test_softmax_xent_loss_grad_cm(C_, npix)
+
+
+def test_device_timestamp_orders_stream_work():
+    """ssmi_device_timestamp: stamps taken on one stream are ordered, the rate is reported, NULL is rejected."""
+    import time
+    libm = pkg("_lib")
+    L = libm.lib()
+    t = torch.zeros(2, dtype=torch.int64, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    L.device_timestamp(t.data_ptr(), st)
+    torch.cuda.synchronize()
+    time.sleep(0.02)
+    L.device_timestamp(t.data_ptr() + 8, st)
+    torch.cuda.synchronize()
+    khz = L.device_timestamp_khz()
+    assert khz > 0
+    ms = float(t[1] - t[0]) / khz
+    assert 15.0 < ms < 2000.0, ms
+    with pytest.raises(libm.SsmiError):
+        L.device_timestamp(None, st)
