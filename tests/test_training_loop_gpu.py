@@ -212,7 +212,8 @@ def test_weight_gradient_schedule_does_not_change_results(monkeypatch):
     from oracle import enet_oracle as E
     eng = pkg("engine")
     models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
-    name, NC, B, H, W = "enet-max-unpooling", 24, 2, 64, 64
+    # large enough that kernels of both streams are in flight together (a dependency lost in the schedule would show)
+    name, NC, B, H, W = "enet-max-unpooling", 24, 4, 256, 256
     w0 = E.init_weights(name, NC, seed=21, perturb=True)
     images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=22, block=8)
     res = []
