@@ -3,7 +3,8 @@ synthetic data resident in HBM.  One step = dropout tables + forward + fused los
 + (N>1: bucketed RCCL all-reduce) + Adam, replayed from HIP graphs.
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N>1: either under a launcher - python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -
+     or plain: with WORLD_SIZE unset the script starts the N ranks itself as child processes, launch_ranks())
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline     : algorithmic bytes / measured duration of the dominant kernel family against the HBM peak
@@ -77,6 +78,35 @@ F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32 matrix peak (MI355X_MICROARCH.md, MF
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak (same table; the headline figures with 2:1 sparsity are twice that)
 
 
+def launch_ranks(n):
+    """Runs this script under `python -m torch.distributed.run --nproc-per-node n` (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port) as a child process, passes the ranks' stderr through, prints the one JSON line rank 0 wrote
+    and returns the launcher's exit code.  Everything else the children print to stdout goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if line is None and out.startswith("{") and '"metric"' in out:
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +132,10 @@ def main():
                          "device pre-pass (generators.PinnedBatchFeeder), the next batch in flight during the step")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process starts the N ranks itself, as fresh children, before anything
+        # here has touched a GPU, and relays rank 0's line and the launcher's exit code
+        raise SystemExit(launch_ranks(args.gpus))
     import torch.distributed as dist
     if os.environ.get("SSMI_BENCH_WATCHDOG"):      # dump every thread's stack and exit if the run stalls
         import faulthandler
@@ -109,8 +143,7 @@ def main():
     trainers = pkg("trainers")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node {}".format(args.gpus))
+        raise SystemExit("--gpus {} does not match WORLD_SIZE={} of the launcher".format(args.gpus, world))
     cfg = {"input_shape": [None, None, 3], "optimizer": {"name": "adam", "learning_rate": 5e-4}, "ignore_classes": [0],
            "random_seed": 14874, "num_labeled_per_batch": args.batch}
     tr = trainers.SegmentationTrainer("segmentation_supervised", args.model, "bench", config=cfg, num_classes=24)

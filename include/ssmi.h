@@ -420,7 +420,10 @@ ssmi_status ssmi_logits_tconv2x2_xent_fwd_bwd(int32_t dtype, const void* x, int3
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, results and
  * arithmetic (bit-identical) as ssmi_softmax_xent_fwd_bwd, but the per-block partial sums of the loss go through a
  * 16 KiB device array that is part of the library's code object (one copy per GPU, held until the process ends) instead
- * of `ws`.  The call allocates nothing; the first call on a device looks the array's address up once.  At most
+ * of `ws`.  The call allocates nothing; the first call on a device looks the array's address up once (hipGetSymbolAddress,
+ * a runtime call that is not stream work): that first call must happen outside stream capture, or the capture must have
+ * been begun with ssmi_graph_begin_capture, which does the lookup for the current device before recording starts; a
+ * first call under any other capture returns SSMI_E_UNSUPPORTED and records nothing.  At most
  * ssmi_softmax_xent_static_max_pixels() pixels (max(npix, npix_metrics)); larger inputs are rejected with
  * SSMI_E_UNSUPPORTED.  All calls on one GPU share that GPU's array: calls that may overlap on one GPU (different
  * streams) race on it and must be serialised by the caller.  Nothing in the array has to be zero beforehand. */

@@ -70,11 +70,12 @@ class StepwiseLearningRateScheduler(Callback):
 
     The reference applies the beta_2 schedule only `if isinstance(optimizer, keras.optimizers.Adam)`
     (stepwise_learning_rate_scheduler.py:62), which its own Adam (a subclass of Optimizer) never satisfies, so beta_2 was
-    never rescheduled there; `apply_b2_schedule=False` reproduces that, the default applies the schedule as written in
-    the configuration."""
+    never rescheduled there.  The default (`apply_b2_schedule=False`) reproduces that: beta_2 stays what the optimizer was
+    built with; True applies the schedule as written in the configuration (trainer config key
+    stepwise_learning_rate_scheduler.apply_b2_schedule)."""
 
     def __init__(self, lr_schedule: Callable[[int], float], initial_step=0, b2_schedule=None, last_scheduled_step=None,
-                 verbose=False, apply_b2_schedule=True):
+                 verbose=False, apply_b2_schedule=False):
         assert lr_schedule is not None
         self.lr_schedule, self.b2_schedule = lr_schedule, b2_schedule
         self.step_index = int(initial_step)

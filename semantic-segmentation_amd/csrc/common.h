@@ -10,6 +10,9 @@
 namespace ssmi {
 
 void set_error(const char* fmt, ...);
+// Looks up, for the CURRENT device, the address of every file-scope device array the library uses as scratch (loss.hip).
+// Called by ssmi_graph_begin_capture in front of the capture, so that no such lookup happens while a stream is capturing.
+bool resolve_static_scratch();
 // Records which kernel variant the calling thread's last convolution entry point dispatched (profiling aid).
 void set_last_kernel(const char* fmt, ...);
 

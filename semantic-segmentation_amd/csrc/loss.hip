@@ -758,6 +758,12 @@ static double* xent_scratch_for_current_device() {
   return g_xent_scratch_ptr[dev];
 }
 
+}  // extern "C"
+namespace ssmi {
+bool resolve_static_scratch() { return xent_scratch_for_current_device() != nullptr; }
+}  // namespace ssmi
+extern "C" {
+
 int64_t ssmi_softmax_xent_static_max_pixels(void) { return (int64_t)1 << 28; }
 
 ssmi_status ssmi_softmax_xent_fwd_bwd_static(const float* logits, const int32_t* labels, const float* weights, int64_t npix,
@@ -768,6 +774,20 @@ ssmi_status ssmi_softmax_xent_fwd_bwd_static(const float* logits, const int32_t*
   SSMI_REQUIRE(span <= ssmi_softmax_xent_static_max_pixels(), SSMI_E_UNSUPPORTED,
                "softmax_xent_static: %lld pixels exceed the maximum of %lld for the allocation-free entry point",
                (long long)span, (long long)ssmi_softmax_xent_static_max_pixels());
+  // The address lookup is not stream-ordered work and must not run while `stream` is recording: a capture begun through
+  // ssmi_graph_begin_capture has resolved it already; under any other capture the first call on a device is refused.
+  int dev = -1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream != nullptr && hipStreamIsCapturing(as_stream(stream), &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+    bool known = false;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDevices) {
+      std::lock_guard<std::mutex> lk(g_xent_scratch_mu);
+      known = g_xent_scratch_ptr[dev] != nullptr;
+    }
+    SSMI_REQUIRE(known, SSMI_E_UNSUPPORTED,
+                 "softmax_xent_static: the first call on a device must happen outside stream capture (or begin the capture "
+                 "with ssmi_graph_begin_capture, which prepares the device)");
+  }
   double* scratch = xent_scratch_for_current_device();
   if (scratch == nullptr) return SSMI_E_HIP;
   // every partial-sum slot the final kernel reads is overwritten by this call's blocks first: nothing to clear

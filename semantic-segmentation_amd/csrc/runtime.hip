@@ -366,6 +366,8 @@ ssmi_status ssmi_dropout_mask(float* mask, int64_t count, float rate, uint64_t s
 
 ssmi_status ssmi_graph_begin_capture(void* stream) {
   SSMI_REQUIRE(stream != nullptr, SSMI_E_INVALID_ARG, "graph capture needs a non-default stream");
+  // symbol lookups are runtime calls that are not stream-ordered: do them before the stream starts recording
+  if (!resolve_static_scratch()) return SSMI_E_HIP;
   SSMI_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
   return SSMI_OK;
 }

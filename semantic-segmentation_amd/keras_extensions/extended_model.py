@@ -90,6 +90,7 @@ class ExtendedModel(object):
         self._keep_logits = False
         self.use_hip_graph = True
         self.grad_sync = None          # trainers.GradientBucketReducer when data-parallel
+        self.log_sync = None           # trainers.EpochLogSync when data-parallel: epoch / validation logs summed over the ranks
         self._timed_steps = None       # list of per-step event records while segment_timing(True)
         self._step_marks = None
         self._bufs_shape = None
@@ -743,6 +744,32 @@ class ExtendedModel(object):
     # ------------------------------------------------------------------------------------------------
     # generator loops (host side; extended_model.py:947-1093, 1223-1298)
     # ------------------------------------------------------------------------------------------------
+    def _streaming_values(self, cm: np.ndarray) -> Dict[str, object]:
+        """Values of the streaming metrics for a (possibly rank-summed) confusion matrix."""
+        return {"logits_" + fn.__name__: fn.value_from_cm(cm) for fn in self._metric_fns}
+
+    def _epoch_logs(self, totals: Dict[str, float], seen: int, last: Dict[str, object], prefix: str = "") -> Dict[str, object]:
+        """Epoch values as the reference's ExtendedBaseLogger reports them (src/keras_extensions/extended_callbacks.py:35-63):
+        streaming metrics keep their last (cumulative) value, every other output is the mean over the samples seen.  With a
+        data-parallel `log_sync` (trainers.EpochLogSync) the sums, the sample count and the confusion matrix are summed over
+        the ranks first, so that every rank hands identical numbers to its callbacks."""
+        sync = getattr(self, "log_sync", None)
+        cm = self._cm.cpu().numpy() if self._cm is not None else None
+        if sync is not None:
+            totals, seen, cm = sync.reduce(totals, seen, cm)
+        logs = {}
+        for nm in self.metrics_names:
+            if nm in self.metrics_streaming:
+                if nm in last:
+                    logs[prefix + nm] = last[nm]
+            elif nm in totals:
+                logs[prefix + nm] = totals[nm] / max(seen, 1)
+        if sync is not None and cm is not None:
+            for nm, v in self._streaming_values(cm).items():
+                if nm in self.metrics_streaming:
+                    logs[prefix + nm] = v
+        return logs
+
     def fit_generator(self, generator, steps_per_epoch, epochs=1, verbose=1, callbacks=None, validation_data=None,
                       validation_steps=None, initial_epoch=0, trainer=None, random_seed=None, **kwargs):
         from ..callbacks import CallbackList
@@ -755,19 +782,27 @@ class ExtendedModel(object):
         for epoch in range(initial_epoch, epochs):
             self.reset_metrics()
             cbs.on_epoch_begin(epoch)
-            logs = {}
+            totals, seen, last = {}, 0, {}
             for b in range(steps_per_epoch):
                 batch = get() if get else generator.get_batch(epoch, b)
                 x, y = batch[0], batch[1]
-                cbs.on_batch_begin(b, {"batch": b, "size": int(x[0].shape[0])})
+                size = int(x[0].shape[0])
+                cbs.on_batch_begin(b, {"batch": b, "size": size})
                 if trainer is not None:
                     x, y = trainer.modify_batch_data(step_index, x, y, validation=False)
                 outs = self.train_on_batch(x, y)
-                logs = dict(zip(self.metrics_names, outs))
-                cbs.on_batch_end(b, {k: v for k, v in logs.items() if k not in self.metrics_excluded_from_callbacks})
+                last = dict(zip(self.metrics_names, outs))
+                seen += size
+                for nm, v in last.items():
+                    if nm not in self.metrics_streaming:
+                        totals[nm] = totals.get(nm, 0.0) + float(v) * size
+                blogs = {k: v for k, v in last.items() if k not in self.metrics_excluded_from_callbacks}
+                blogs.update(batch=b, size=size)
+                cbs.on_batch_end(b, blogs)
                 if trainer is not None:
                     trainer.on_batch_end(step_index)
                 step_index += 1
+            logs = self._epoch_logs(totals, seen, last)
             if validation_data is not None:
                 val = self.evaluate_generator(validation_data, validation_steps, trainer=trainer, validation=True)
                 logs.update({"val_" + k: v for k, v in zip(self.metrics_names, val)})
@@ -787,21 +822,21 @@ class ExtendedModel(object):
 
     def evaluate_generator(self, generator, steps, trainer=None, validation=False, **kwargs):
         """Aggregation of extended_model.py:1279-1298: streaming metrics take the last batch's (cumulative) value,
-        the others a batch-size weighted average."""
+        the others a batch-size weighted average.  Data parallel (`log_sync` set): every rank evaluates its own batches and
+        the sums / the confusion matrix are reduced over the ranks, so the result is the same on all of them."""
         self.reset_metrics()
         get = generator.__next__ if hasattr(generator, "__next__") else None
-        all_outs, sizes = [], []
+        totals, seen, last = {}, 0, {}
         for b in range(steps):
             batch = get() if get else generator.get_batch(0, b)
             x, y = batch[0], batch[1]
             if trainer is not None:
                 x, y = trainer.modify_batch_data(b, x, y, validation=validation)
-            all_outs.append(self.test_on_batch(x, y))
-            sizes.append(int(x[0].shape[0]))
-        res = []
-        for i, nm in enumerate(self.metrics_names):
-            if nm in self.metrics_streaming:
-                res.append(all_outs[-1][i])
-            else:
-                res.append(float(np.average([o[i] for o in all_outs], weights=sizes)))
-        return res
+            last = dict(zip(self.metrics_names, self.test_on_batch(x, y)))
+            size = int(x[0].shape[0])
+            seen += size
+            for nm, v in last.items():
+                if nm not in self.metrics_streaming:
+                    totals[nm] = totals.get(nm, 0.0) + float(v) * size
+        logs = self._epoch_logs(totals, seen, last)
+        return [logs.get(nm) for nm in self.metrics_names]

@@ -16,7 +16,15 @@ from typing import Callable
 
 import numpy as np
 
-_BIN = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: operator.truediv,
+def _py2_div(a, b):
+    """`/` as the reference's interpreter (Python 2, no `from __future__ import division`) evaluates it: floor division
+    when both operands are integers, true division otherwise."""
+    if isinstance(a, (int, np.integer)) and isinstance(b, (int, np.integer)) and not isinstance(a, bool) and not isinstance(b, bool):
+        return a // b
+    return a / b
+
+
+_BIN = {ast.Add: operator.add, ast.Sub: operator.sub, ast.Mult: operator.mul, ast.Div: _py2_div,
         ast.FloorDiv: operator.floordiv, ast.Mod: operator.mod, ast.Pow: operator.pow}
 _UN = {ast.UAdd: operator.pos, ast.USub: operator.neg, ast.Not: operator.not_}
 _CMP = {ast.Lt: operator.lt, ast.LtE: operator.le, ast.Gt: operator.gt, ast.GtE: operator.ge, ast.Eq: operator.eq,
@@ -56,8 +64,14 @@ def _ev(node, env):
     if isinstance(node, ast.UnaryOp) and type(node.op) in _UN:
         return _UN[type(node.op)](_ev(node.operand, env))
     if isinstance(node, ast.BoolOp):
-        vals = (_ev(v, env) for v in node.values)
-        return all(vals) if isinstance(node.op, ast.And) else any(vals)
+        # Python's and / or: the value of the operand that decides, not a bool
+        is_and = isinstance(node.op, ast.And)
+        val = None
+        for v in node.values:
+            val = _ev(v, env)
+            if bool(val) != is_and:
+                return val
+        return val
     if isinstance(node, ast.Compare):
         left = _ev(node.left, env)
         for op, right in zip(node.ops, node.comparators):

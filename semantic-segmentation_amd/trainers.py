@@ -81,6 +81,44 @@ class GradientBucketReducer:
         return t
 
 
+class EpochLogSync:
+    """Makes the numbers the callbacks act on identical on every rank: the per-epoch sums of the non-streaming outputs
+    (value x batch size), the sample count and the int64 confusion matrix are summed over the process group before the
+    engine turns them into epoch logs.  ReduceLROnPlateau, EarlyStopping and the checkpoint names then take the same
+    decision on every rank (a rank that stopped or lowered its rate alone would leave the others waiting in the next
+    gradient all-reduce, or let the replicas drift apart)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def reduce(self, totals: Dict[str, float], seen: int, cm: Optional[np.ndarray]):
+        keys = sorted(totals)
+        t = torch.tensor([float(totals[k]) for k in keys] + [float(seen)], dtype=torch.float64)
+        t = _all_reduce_host(t, self.group)
+        out = {k: float(v) for k, v in zip(keys, t[:-1].tolist())}
+        if cm is not None:
+            cm = _all_reduce_host(torch.from_numpy(np.ascontiguousarray(cm, dtype=np.int64)), self.group).numpy()
+        return out, int(round(float(t[-1]))), cm
+
+
+def _all_reduce_host(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum of a small host tensor over the group, whatever the backend (RCCL reduces device tensors only)."""
+    if dist.get_backend(group) == "nccl":
+        d = t.to(torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+        return d.cpu()
+    t = t.clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def broadcast_object_from_rank0(obj, group=None):
+    """Rank 0's value of a small picklable object on every rank."""
+    box = [obj]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return box[0]
+
+
 def all_reduce_evaluation(cm: torch.Tensor, loss_sum: float, count: int, group=None):
     """Sums a rank's int64 confusion matrix and its (loss * images, images) pair over the process group (no-op without
     one).  Returns (matrix as numpy int64, mean loss, images).  Integer sums are exact, so the matrix is the one a
@@ -227,6 +265,7 @@ class SegmentationTrainer(object):
             st = self.model.graph.store
             self.reducer.broadcast_([st.theta, st.state], src=0)
             self.model.grad_sync = self.reducer
+            self.model.log_sync = EpochLogSync(self.reducer.group)
         if self.using_mean_teacher_method:
             # src/trainers.py:1460-1520: the teacher has the student's topology without the lambda loss, starts from the
             # student's weights and is never trained; compile gives it the supervised loss + metrics for validation.
@@ -400,7 +439,10 @@ class SegmentationTrainer(object):
             out.append(cb.StepwiseLearningRateScheduler(
                 lr_schedule=self._schedule(sw.get('lr_schedule')) if sw.get('lr_schedule') is not None else None,
                 b2_schedule=self._schedule(sw.get('b2_schedule')) if sw.get('b2_schedule') is not None else None,
-                last_scheduled_step=sw.get('last_scheduled_step'), initial_step=initial_step, verbose=sw.get('verbose')))
+                last_scheduled_step=sw.get('last_scheduled_step'), initial_step=initial_step, verbose=sw.get('verbose'),
+                # the reference never applies b2_schedule (its own Adam fails the isinstance test in
+                # stepwise_learning_rate_scheduler.py:62); "apply_b2_schedule": true in this block opts in
+                apply_b2_schedule=bool(sw.get('apply_b2_schedule', False))))
         oc = cfg.get('optimizer_checkpoint_file_path')
         if oc is not None:
             out.append(cb.OptimizerCheckpoint(self._populate_path_template(oc), enabled=writer))
@@ -519,9 +561,13 @@ class SegmentationTrainer(object):
                 initial_epoch = self._load_latest_weights_for_model(self.model, folder) if path else 0
                 if initial_epoch and self.config.get('continue_from_optimizer_checkpoint', True):
                     self.model_wrapper.load_optimizer_weights(path)
-                if initial_epoch and self.reducer is not None:      # every rank continues from rank 0's state
-                    st = self.model.graph.store
-                    self.reducer.broadcast_([st.theta, st.state], src=0)
+            if self.reducer is not None:
+                # Every rank continues from rank 0's view: the epoch first (a rank that saw no checkpoint on its file system
+                # must not train other epochs than the rest), then - unconditionally, so that no rank skips a collective -
+                # weights, moving statistics, optimizer slots and the iteration counter.
+                initial_epoch = int(broadcast_object_from_rank0(initial_epoch, self.reducer.group))
+                st, opt = self.model.graph.store, self.model.optimizer
+                self.reducer.broadcast_([st.theta, st.state] + list(opt.slot_tensors().values()) + [opt.step_block], src=0)
             callbacks = self._get_training_callbacks(initial_step=initial_epoch * steps_per_epoch)
         self.initial_epoch = initial_epoch
         return self.model.fit_generator(generator, steps_per_epoch, epochs=self.num_epochs, callbacks=callbacks,

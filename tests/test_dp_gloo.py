@@ -148,6 +148,45 @@ def test_two_gloo_ranks_share_the_gpu_and_finish_the_data_parallel_step():
 
 
 @pytest.mark.gpu
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how a plain command line invokes it): the script itself starts two
+    fresh rank processes under torch.distributed.run and relays rank 0's single line and the exit code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSMI_DIST_BACKEND="gloo", SSMI_BENCH_WATCHDOG="100")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
+           "--size", "64"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=140, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["data_parallel"]["rccl_ranks"] == 2 and d["value"] > 0
+
+
+def test_bench_launcher_relays_failure_of_the_ranks(tmp_path):
+    """The self-launch path on CPU: with no GPU the ranks fail; the parent must return their non-zero exit code and print no
+    result line (instead of hanging or reporting success)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available():
+        pytest.skip("needs a host without a GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SSMI_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--batch", "1",
+                        "--size", "32", "--no-cpu-baseline", "--no-roofline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=200, text=True)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_c_abi_collectives_one_rank():
     """ssmi_comm_* (RCCL behind the C ABI) with a communicator of one rank: sums and the broadcast are the identity, the
     calls are stream-ordered with the kernels around them, the handle reports rank and size.  Run in a child process: the

@@ -129,7 +129,7 @@ def _trainer(tmp_path, folder, epochs):
            "keras_csv_log_file_path": "{log_folder_path}/per-epoch-data.csv",
            "optimizer_checkpoint_file_path": str(tmp_path / "{model_folder}" / "optimizer" / "optimizer-checkpoint.json"),
            "stepwise_learning_rate_scheduler": {"lr_schedule": "lambda x: 1e-3 * min(1.0, float(x + 1) / 4.0)",
-                                                "b2_schedule": "lambda x: 0.99 if x < 3 else 0.999"},
+                                                "b2_schedule": "lambda x: 0.99 if x < 3 else 0.999", "apply_b2_schedule": True},
            "reduce_lr_on_plateau": {"factor": 0.5, "patience": 1}, "early_stopping": {"patience": 50}}
     return trainers.SegmentationTrainer("segmentation_supervised", "enet-naive-upsampling", folder, config=cfg, num_classes=NC)
 

@@ -61,3 +61,41 @@ def test_static_rejects_oversized_input():
     with pytest.raises(_lib.SsmiError, match="exceed the maximum"):
         L.softmax_xent_fwd_bwd_static(t.data_ptr(), li.data_ptr(), t.data_ptr(), L.softmax_xent_static_max_pixels() + 1, 24,
                                       1.0, None, t.data_ptr(), None, 0, 0, None, None, torch.cuda.current_stream().cuda_stream)
+
+
+def test_static_entry_point_under_graph_capture_replays():
+    """The entry point recorded into a HIP graph (capture begun through the C ABI, which looks the array's address up before
+    recording starts) and replayed twice on changing logits gives the same bits as the workspace entry point run eagerly."""
+    import ctypes as C
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    npix, ncls = 70000, 24
+    g = torch.Generator(device="cpu").manual_seed(9)
+    labels = torch.randint(0, ncls, (npix,), generator=g, dtype=torch.int32).to(dev)
+    weights = (torch.rand(npix, generator=g) + 0.25).to(dev)
+    logits = torch.zeros(npix, ncls, device=dev)
+    dl = torch.zeros(npix, ncls, device=dev)
+    loss = torch.zeros(1, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    h = C.c_void_p()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        L.graph_begin_capture(s.cuda_stream)
+        try:
+            L.softmax_xent_fwd_bwd_static(logits.data_ptr(), labels.data_ptr(), weights.data_ptr(), npix, ncls, 1.0, dl.data_ptr(),
+                                          loss.data_ptr(), None, 0, 0, None, bad.data_ptr(), s.cuda_stream)
+        finally:
+            L.graph_end_capture(s.cuda_stream, C.byref(h))
+        ws = torch.empty(L.softmax_xent_workspace_bytes(npix) // 4 + 16, device=dev)
+        for seed in (1, 2):
+            logits.copy_((torch.randn(npix, ncls, generator=g) * 3).to(dev))
+            L.graph_launch(h, s.cuda_stream)
+            s.synchronize()
+            got = (loss.clone(), dl.clone())
+            dl2, loss2 = torch.zeros_like(dl), torch.zeros_like(loss)
+            L.softmax_xent_fwd_bwd(logits.data_ptr(), labels.data_ptr(), weights.data_ptr(), npix, ncls, 1.0, dl2.data_ptr(),
+                                   loss2.data_ptr(), None, 0, 0, None, bad.data_ptr(), ws.data_ptr(), ws.numel() * 4, s.cuda_stream)
+            s.synchronize()
+            assert torch.equal(got[0], loss2) and torch.equal(got[1], dl2) and float(loss2) > 0
+    L.graph_destroy(h)
