@@ -145,6 +145,8 @@ ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t np
                                   int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, hipStream_t stream) {
   SSMI_REQUIRE((int64_t)rows * 2 * c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn statistics: partial-sum table too large");
+  static const bool ablate = getenv("SSMI_ABLATE_BN_FINAL") != nullptr;      // timing experiment only: results are meaningless
+  if (ablate) return SSMI_OK;
 #define LF(CH) hipLaunchKernelGGL((bn_stats_final<CH>), dim3((c + CH - 1) / CH), dim3(256), 0, stream, part, rows, c, npix, \
                                   eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean, save_invstd)
   if (rows <= 512) LF(8); else if (rows <= 1024) LF(4); else if (rows <= 2048) LF(2); else LF(1);
@@ -604,6 +606,8 @@ static ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64
                                        const float* invstd, float* dgamma, float* dbeta, float* dalpha, float* coef,
                                        hipStream_t st) {
   SSMI_REQUIRE((int64_t)rows * 3 * c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn backward: partial-sum table too large");
+  static const bool ablate = getenv("SSMI_ABLATE_BN_FINAL") != nullptr;      // timing experiment only: results are meaningless
+  if (ablate) return SSMI_OK;
 #define LF(CH) hipLaunchKernelGGL((bn_bwd_final<CH>), dim3((c + CH - 1) / CH), dim3(256), 0, st, part, rows, c, npix, gamma, \
                                   invstd, dgamma, dbeta, dalpha, coef)
   if (rows <= 512) LF(8); else if (rows <= 1024) LF(4); else if (rows <= 2048) LF(2); else LF(1);
