@@ -364,6 +364,25 @@ class BatchNorm:
                          self.c, _ptr(ws), ws.numel() * 4, st)
 
 
+def check_queue_budget(side_streams: int, env=None) -> None:
+    """A captured step with weight-gradient side streams is a HIP graph with 1 + side_streams concurrent branches.  The
+    runtime's graph executor segfaults (host side, at the first launch; exit code 139, nothing printed) when it is asked
+    for more concurrent branches than the process has hardware queues: measured with four side streams under
+    GPU_MAX_HW_QUEUES=2, and with DEBUG_HIP_FORCE_GRAPH_QUEUES above GPU_MAX_HW_QUEUES.  One side stream (the default)
+    runs under every setting tried (GPU_MAX_HW_QUEUES=2, forced graph queues 1-8).  Such a configuration is refused here,
+    before anything is captured, instead of crashing later."""
+    env = os.environ if env is None else env
+    hwq = int(env.get("GPU_MAX_HW_QUEUES", "4"))          # HIP's default is 4 hardware queues per process
+    forced = env.get("DEBUG_HIP_FORCE_GRAPH_QUEUES")
+    if 1 + side_streams > hwq:
+        raise RuntimeError("{} weight-gradient side streams + the main stream need {} hardware queues, GPU_MAX_HW_QUEUES allows {}: "
+                           "lower SSMI_WGRAD_STREAMS (1 is the default and the fastest setting) or raise GPU_MAX_HW_QUEUES".format(
+                               side_streams, 1 + side_streams, hwq))
+    if forced is not None and side_streams > 1 and int(forced) > hwq:
+        raise RuntimeError("DEBUG_HIP_FORCE_GRAPH_QUEUES={} exceeds GPU_MAX_HW_QUEUES={} while {} side streams are captured: the "
+                           "graph executor crashes in this configuration".format(forced, hwq, side_streams))
+
+
 _ABLATE_WGRAD = os.environ.get("SSMI_ABLATE_WGRAD") is not None
 _WGRAD_LAG = int(os.environ.get("SSMI_WGRAD_LAG", "1"))      # blocks between a fork point and the launches behind it (0: at once)
 _WGRAD_FORK_PER_CONV = os.environ.get("SSMI_WGRAD_FORK", "conv") == "conv"      # one fork point per layer instead of one per block
@@ -1109,6 +1128,8 @@ class GraphBase:
         # lands behind weight gradients of earlier blocks): 4 streams 9.25 / 7.03, 1 stream 10.2 / 7.6.
         # SSMI_WGRAD_STREAMS overrides for measurements.
         nside = int(os.environ.get("SSMI_WGRAD_STREAMS", "1"))
+        if self.side_stream is not None:
+            check_queue_budget(nside)
         self.side_streams = self.side_wss = None
         if nside > 1 and self.side_stream is not None:
             self.side_streams = [self.side_stream] + [torch.cuda.Stream(device=dev) for _ in range(nside - 1)]

@@ -331,3 +331,19 @@ def test_latest_checkpoint_discovery(tmp_path):
     assert f(str(tmp_path / "missing" / "x.hdf5")) is None
     (tmp_path / "empty").mkdir()
     assert f(str(tmp_path / "empty")) is None
+
+
+def test_side_stream_count_is_checked_against_the_hardware_queue_budget():
+    """More concurrent graph branches than hardware queues crash the HIP graph executor (segmentation fault at the first
+    launch); the engine refuses such a configuration at planning time."""
+    eng = pkg("engine")
+    eng.check_queue_budget(1, {})                                   # default: main + one side stream under 4 queues
+    eng.check_queue_budget(1, {"GPU_MAX_HW_QUEUES": "2"})
+    eng.check_queue_budget(1, {"DEBUG_HIP_FORCE_GRAPH_QUEUES": "8"})
+    eng.check_queue_budget(3, {})
+    with pytest.raises(RuntimeError, match="hardware queues"):
+        eng.check_queue_budget(4, {"GPU_MAX_HW_QUEUES": "2"})
+    with pytest.raises(RuntimeError, match="hardware queues"):
+        eng.check_queue_budget(4, {})
+    with pytest.raises(RuntimeError, match="DEBUG_HIP_FORCE_GRAPH_QUEUES"):
+        eng.check_queue_budget(3, {"DEBUG_HIP_FORCE_GRAPH_QUEUES": "6"})
