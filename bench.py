@@ -350,7 +350,7 @@ def measure_roofline(model, stream, steps=3):
     tfs = fl / (ms * 1e-3) / 1e12
     # HBM bytes per launch from the committed counter passes (scripts/clean_evidence.sh: FETCH_SIZE / WRITE_SIZE with one kernel
     # on the chip at a time); the trace names carry the storage type as first template argument, the records do not
-    traffic = None
+    traffic = traffic_source = None
     import re
     want_bf16 = getattr(model.graph.store, "act_dtype", torch.float32) == torch.bfloat16
     base = kernel.replace(" bf16 mfma", "")
@@ -364,11 +364,14 @@ def measure_roofline(model, stream, steps=3):
                 m = re.match(r"^(\w+)<(float|__bf16), (.*?)(, false)?>$", k)
                 if m and (m.group(2) == "__bf16") == want_bf16 and "{}<{}>".format(m.group(1), m.group(3)) == base:
                     traffic = v.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/" + fname
     common = {"kernel": "ssmi::" + kernel, "launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
               "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
               "arithmetic_intensity_flop_per_byte": round(ai, 2), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),
               "kernel_ms_per_step": round(ms / steps, 3), "all_conv_fwd_bwd_data_ms_per_step": round(conv_ms, 3),
-              "event_bracket_overhead_us": round(overhead_ms * 1e3, 2), "traffic": traffic}
+              "event_bracket_overhead_us": round(overhead_ms * 1e3, 2), "traffic": traffic,
+              # HBM bytes per launch come from committed rocprofv3 counter passes of this kernel, not from this run
+              "traffic_source": traffic_source}
     # a variant that multiplies on the bf16 matrix instructions is priced against THEIR dense peak (ridge 312 FLOP/B)
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if kernel.endswith("bf16 mfma") else F32_MFMA_PEAK_TFLOPS
     if ai < mfma_peak * 1e3 / HBM_PEAK_GBS:

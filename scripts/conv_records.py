@@ -1,5 +1,5 @@
 """Per-launch records of the convolution kernels in one eager training step (variant, duration net of the event bracket,
-algorithmic MB, GFLOP, GB/s), grouped by (variant, bytes, flops):  python scripts/conv_records.py [model] [batch] [json]
+algorithmic MB, GFLOP, GB/s), grouped by (variant, bytes, flops):  python scripts/conv_records.py [model] [batch] [json] [f32|bf16]
 With a third argument the per-variant sums (launches, algorithmic bytes and flops per step) are also written as JSON."""
 import ctypes as C
 import importlib
@@ -20,6 +20,8 @@ def main():
     trainers = bench.pkg("trainers")
     cfg = {"input_shape": [None, None, 3], "optimizer": {"name": "adam", "learning_rate": 5e-4}, "ignore_classes": [0],
            "random_seed": 14874, "num_labeled_per_batch": batch}
+    if len(sys.argv) > 4 and sys.argv[4] == "bf16":
+        cfg["activation_dtype"] = "bf16"
     tr = trainers.SegmentationTrainer("segmentation_supervised", model_name, "bench", config=cfg, num_classes=24)
     model = tr.model
     images, labels, weights = bench.synthetic_batch(batch, 512, 512, 24, 14874, torch.device(tr.device))

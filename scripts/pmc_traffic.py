@@ -7,25 +7,16 @@ import csv
 import glob
 import json
 import re
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kernel_names import short  # noqa: E402
 
 out = sys.argv[1]
 
 
-def short(name):
-    name = re.sub(r"^void\s+", "", name)
-    name = name.replace("ssmi::", "")
-    depth, cut = 0, len(name)
-    for i, ch in enumerate(name):      # drop the argument list (the first '(' outside template brackets)
-        if ch == "<":
-            depth += 1
-        elif ch == ">":
-            depth -= 1
-        elif ch == "(" and depth == 0:
-            cut = i
-            break
-    return name[:cut].strip()
 
 
 def collect(sub, counter):

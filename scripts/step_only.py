@@ -1,5 +1,7 @@
-"""N graph-replayed training steps of one model in one activation dtype and nothing else (a clean target for
-rocprofv3 --kernel-trace): step_only.py [model] [f32|bf16] [batch] [steps]"""
+"""N training steps of one model in ONE activation dtype and nothing else (a clean target for rocprofv3: no second dtype in
+the same process, no roofline brackets, no CPU baseline): step_only.py [model] [f32|bf16] [batch] [steps]
+SSMI_NO_OVERLAP=1: weight gradients on the main stream (one kernel on the chip at a time); SSMI_EAGER=1: direct launches
+instead of graph replay (counter passes)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -16,6 +18,8 @@ tr = bench.pkg("trainers").SegmentationTrainer("segmentation_supervised", model_
 m = tr.model
 if os.environ.get("SSMI_NO_OVERLAP"):
     m.graph.overlap_weight_gradients = False
+if os.environ.get("SSMI_EAGER"):
+    m.use_hip_graph = False
 im, lab, w = bench.synthetic_batch(batch, 512, 512, 24, 1, torch.device("cuda"))
 s = torch.cuda.Stream()
 with torch.cuda.stream(s):
