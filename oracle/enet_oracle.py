@@ -369,7 +369,7 @@ def enet_forward(model_name: str, params: Dict[str, torch.Tensor], images: torch
     ctx.acts the named intermediate tensors when collect=True."""
     model_name, encoder_only = split_name(model_name)
     if model_name in VGG_STYLE:
-        c = _Ctx(params, training, drop_masks, collect)
+        c = _Ctx(params, training, drop_masks, collect, forced)
         return V.forward(model_name, c, images, encoder_only), c
     variant = {"enet-naive-upsampling": "naive", "enet-max-unpooling": "unpool",
                "enet-naive-upsampling-enhanced": "enhanced"}.get(model_name)

@@ -104,7 +104,10 @@ def _conv_block(c, x, name, act):
     y = c.conv(name, x, padding="same")
     y = c.bn(name + "_normalization", y)
     if act:
-        y = c.keep(name + "_activation", K.leaky_relu(y, LEAKY_ALPHA))
+        # c.forced[name + "_activation"]: sign per element (+1 / -1 / 0) of the LeakyReLU input as another evaluation saw it;
+        # the branch is then taken from there instead of from y (tests that replay the branches a device step took)
+        fk = name + "_activation"
+        y = c.keep(fk, K.prelu_forced(y, LEAKY_ALPHA, c.forced[fk]) if fk in c.forced else K.leaky_relu(y, LEAKY_ALPHA))
     return c.keep(name + "_dropout", c.sdrop(name + "_dropout", y))
 
 
@@ -117,7 +120,8 @@ def forward(model_name: str, c, images, encoder_only: bool = False):
         for i in range(n):
             x = _conv_block(c, x, "{}_conv{}".format(prefix, i + 1), True)
         skips.append(x)
-        x = c.keep(prefix + "_pool", K.max_pool_2x2(x))
+        fk = prefix + "_pool/argmax"      # forced selection: per-image flat NHWC indices of the window maxima
+        x = c.keep(prefix + "_pool", K.max_pool_forced(x, c.forced[fk]) if fk in c.forced else K.max_pool_2x2(x))
     if encoder_only:      # AveragePooling2D(pool4's spatial size) -> Flatten -> Dense (src/models.py:985-993)
         pooled = c.keep("avg_pool2d", x.mean(dim=(1, 2)))
         return pooled @ c.p["logits/kernel"] + c.p["logits/bias"]

@@ -22,9 +22,9 @@ pytestmark = pytest.mark.gpu
 NC = 24
 
 
-def _build(name, seed=3):
+def _build(name, seed=3, dtype="f32"):
     models, losses, metrics, opt = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
-    mb = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY)
+    mb = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, dtype=dtype)
     m = mb.model
     m.graph.store.init_values(seed)
     m.compile(optimizer=opt.Adam(lr=5e-4), loss={'loss': losses.dummy_loss, 'logits': lambda t, p: 0 * p},
@@ -50,10 +50,14 @@ def _restore(m, snap, opt_snap):
     m.reset_metrics()
 
 
-@pytest.mark.parametrize("name,B", [("enet-naive-upsampling", 16), ("enet-max-unpooling", 16), ("segnet", 4), ("unet", 4)])
-def test_full_size_training_step_properties(name, B):
+@pytest.mark.parametrize("name,B,dtype", [("enet-naive-upsampling", 16, "f32"), ("enet-max-unpooling", 16, "f32"), ("segnet", 4, "f32"),
+                                          ("unet", 4, "f32"), ("enet-naive-upsampling", 16, "bf16"),
+                                          ("enet-max-unpooling", 16, "bf16"), ("segnet", 4, "bf16")])
+def test_full_size_training_step_properties(name, B, dtype):
+    """bf16 storage: the same exact properties hold - rounding to bfloat16 is deterministic and commutes with a power-of-two
+    scale, and the pooling indices are first maxima of the ROUNDED tensor the kernel pooled."""
     H, W = 512, 512
-    m = _build(name)
+    m = _build(name, dtype=dtype)
     cw = np.ones(NC, dtype=np.float32)
     cw[0] = 0
     cw[1:] = 0.5 + np.arange(1, NC) / 23.0
@@ -92,8 +96,8 @@ def test_full_size_training_step_properties(name, B):
     assert cm.dtype == np.int64 and int(cm.sum()) == int((labels != 0).sum()) and int(cm[0].sum()) == 0
     assert np.array_equal(cm.sum(axis=1), np.bincount(labels.reshape(-1), minlength=NC) * (np.arange(NC) != 0))
     if name == "enet-max-unpooling":
-        L = pkg("_lib").lib()
         g = m.graph
+        L = pkg("_lib").lib()
         for bname in ("en_bn_1.0", "en_bn_2.0"):
             blk = g.by_name[bname]
             xin, pooled = blk.x, blk.pooled          # [B, 2h, 2w, C] block input, [B, h, w, C] pooled skip branch
@@ -114,6 +118,8 @@ def test_full_size_training_step_properties(name, B):
             expect = ((2 * ar_y + k // 2) * win + 2 * ar_x + k % 2) * c + ar_c
             assert torch.equal(idx, expect), "argmax indices of {} are not the first maximum of their window".format(bname)
             # unpooling puts every pooled value back at exactly that position and zeros everywhere else
+            # (the stand-alone unpooling entry points are float32; a bf16 network's pooled values are widened for them)
+            pooled = pooled.float().contiguous()
             up = torch.full((n, hin, win, c), 7.0, device="cuda")
             L.maxunpool_local_fwd(pooled.data_ptr(), blk.idx.data_ptr(), n, h2, w2, c, up.data_ptr(),
                                   torch.cuda.current_stream().cuda_stream)
@@ -127,15 +133,68 @@ def test_full_size_training_step_properties(name, B):
             del up, up2
 
 
-def test_full_size_inference_is_batch_independent():
+def test_bf16_storage_against_float32_at_the_benchmark_size():
+    """The same network (identical weights, batch, dropout draws) with float32 and with bfloat16 activation storage at
+    512x512, batch 16.  The loss must agree within 2e-2 (the tolerance the bf16 path is held to; measured 5e-5).  Whole-
+    network TENSORS cannot: this randomly initialised, training-phase network amplifies any perturbation several hundred
+    times on the way to the logits - rounding nothing but the IMAGES to bfloat16 and running the float32 kernels moves the
+    logits by 25 % (relative L2), one float32 ulp of input noise by 4e-5 (scripts/sensitivity_probe.py).  So the bound on
+    the logits is set against that yardstick, measured in the same test: bfloat16 storage of every tensor on the path may
+    move the logits at most three times as far as bfloat16 rounding of the input alone does in the float32 network
+    (measured 1.8x).  Printed: both distances, the fraction of labeled pixels classified alike."""
+    name, B, H, W = "enet-naive-upsampling", 16, 512, 512
+    cw = np.ones(NC, dtype=np.float32)
+    cw[0] = 0
+    images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=78, block=32, class_weights=cw)
+    xi = torch.from_numpy(images).cuda()
+    res = {}
+    for dtype in ("f32", "bf16"):
+        m = _build(name, seed=5, dtype=dtype)
+        m.keep_logits = True
+
+        def fwd(inp):
+            lg = m.graph.forward(inp.contiguous(), training=True, update_moving=False, use_dropout=False)
+            torch.cuda.synchronize()
+            return lg.float().clone()
+        r = dict(fwd=fwd(xi))
+        if dtype == "f32":
+            r["fwd_rounded_input"] = fwd(xi.bfloat16().float())
+        x = [xi, torch.from_numpy(labels).cuda(), torch.from_numpy(pw).cuda(), np.zeros((B, 1), np.int32)]
+        with torch.cuda.stream(torch.cuda.Stream()):
+            outs = m.train_on_batch(x, None)
+        torch.cuda.synchronize()
+        r.update(loss=outs[0], cm=outs[6].copy())
+        res[dtype] = r
+        m.close()
+        del m
+    a, b = res["f32"], res["bf16"]
+
+    def rel(u, v):
+        return float((u - v).double().norm() / u.double().norm())
+    rel_loss = abs(a["loss"] - b["loss"]) / abs(a["loss"])
+    d_input, d_storage = rel(a["fwd"], a["fwd_rounded_input"]), rel(a["fwd"], b["fwd"])
+    keep = torch.from_numpy(labels != 0).cuda()
+    agree = float((a["fwd"].argmax(-1) == b["fwd"].argmax(-1))[keep].float().mean())
+    agree_in = float((a["fwd"].argmax(-1) == a["fwd_rounded_input"].argmax(-1))[keep].float().mean())
+    print("bf16 vs f32 storage at 512x512 batch 16: loss {:.6f} vs {:.6f} (rel {:.2e}); logits rel L2: bf16 storage {:.3e}, "
+          "float32 kernels on bf16-rounded images {:.3e} (ratio {:.2f}); same class on {:.2%} / {:.2%} of labeled pixels".format(
+              a["loss"], b["loss"], rel_loss, d_storage, d_input, d_storage / d_input, agree, agree_in))
+    assert rel_loss <= 2e-2
+    assert d_storage <= 3.0 * d_input
+    assert int(a["cm"].sum()) == int(b["cm"].sum()) == int((labels != 0).sum())
+
+
+@pytest.mark.parametrize("B", [4, 10])
+def test_full_size_inference_is_batch_independent(B):
+    """B = 10 is the validation batch of the reference's configuration (configs/segmentation/config-segmentation-supervised.json:40-42)."""
     m = _build("enet-naive-upsampling", seed=9)
-    B, H, W = 4, 1024, 1024
+    H, W = 1024, 1024
     images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=5, block=64)
     xb = torch.from_numpy(images).cuda()
     full = m.predict_on_batch_device(xb).clone()
     torch.cuda.synchronize()
     assert tuple(full.shape) == (B, H, W, NC) and bool(torch.isfinite(full).all())
-    for i in (0, 3):
+    for i in (0, B - 1):
         one = m.predict_on_batch_device(xb[i:i + 1]).clone()
         assert torch.equal(one[0], full[i]), "image {} differs between batch sizes".format(i)
     # evaluation: the matrix over the batch equals the matrix recomputed from the logits, and the loss is the mean over pixels

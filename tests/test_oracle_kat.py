@@ -1,6 +1,7 @@
 """Known-answer tests that pin the CPU oracle (the reference ships no test vectors for this path, so these
 hand-computable cases plus the reference's own numpy definitions are what anchors the restated TF/Keras semantics)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import tf_keras_ops as K
@@ -274,3 +275,27 @@ def test_encoder_only_oracle_shapes():
         with torch.no_grad():
             logits, _ = E.enet_forward(name, params, torch.zeros(2, 32, 32, 3, dtype=torch.float64), training=False)
         assert tuple(logits.shape) == (2, 7)
+
+
+@pytest.mark.parametrize("name", ["segnet", "unet"])
+def test_forcing_the_oracles_own_branches_changes_nothing(name):
+    """U-Net / SegNet oracle with LeakyReLU signs and max-pool selections forced to the ones it takes by itself: loss and
+    every gradient identical (the forcing hooks used by the GPU step-parity tests select, they do not alter)."""
+    w0 = E.init_weights(name, 24, seed=15, perturb=True)
+    im, lab, pw = E.synthetic_batch(2, 32, 32, 24, seed=1, block=8)
+    masks = E.make_dropout_masks(name, 2, 3)
+    r = E.train_step(name, w0, im, lab, pw, masks, collect=True)
+    forced = {k: np.sign(v) for k, v in r["acts"].items() if k.endswith("_activation")}
+    from oracle import unet_segnet_oracle as V
+    for prefix, n, _ in V.topology(name)[0]:
+        x = np.asarray(r["acts"]["{}_conv{}_dropout".format(prefix, n)])
+        forced[prefix + "_pool/argmax"] = K.max_pool_with_argmax_np(x)[1]
+    r2 = E.train_step(name, w0, im, lab, pw, masks, forced=forced)
+    assert r2["loss"] == r["loss"]
+    for k, g in r["grads"].items():
+        assert np.array_equal(r2["grads"][k], g), k
+    # a flipped sign does change the result (the hook is live)
+    k0 = sorted(forced)[0]
+    flipped = dict(forced)
+    flipped[k0] = -forced[k0]
+    assert E.train_step(name, w0, im, lab, pw, masks, forced=flipped)["loss"] != r["loss"]
