@@ -4,7 +4,7 @@
 set -u
 cd "$GRAFT_REPO_ROOT"
 export MASTER_ADDR=127.0.0.1 MASTER_PORT=29551
-C="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --dtype f32"
+C="--steps 20 --warmup 5 --no-cpu-baseline --no-roofline --dtype f32"
 for m in "enet-naive-upsampling --batch 16" "segnet --batch 4" "unet --batch 4"; do
   tag=$(echo $m | cut -d' ' -f1)
   timeout -k 10 200 python bench.py --model $m $C > gpurun_out/dpc_${tag}_plain.json 2> gpurun_out/dpc_${tag}_plain.err || { echo "plain $tag failed"; tail -5 gpurun_out/dpc_${tag}_plain.err; exit 1; }
@@ -18,4 +18,4 @@ for m in ("enet-naive-upsampling", "segnet", "unet"):
     print(m, "plain ms", a["ms_per_step"], "loss", a["config"]["final_loss"], "| one-rank RCCL ms", b["ms_per_step"], "loss", b["config"]["final_loss"])
     print("   ", json.dumps(b["data_parallel"]))
 PY
-bash scripts/dp_rehearsal.sh r02 100
+bash scripts/dp_rehearsal.sh r03 100
