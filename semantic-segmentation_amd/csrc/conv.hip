@@ -3105,11 +3105,216 @@ static WgPlan plan_wg(const Geo& g, bool with_bias, bool bf16_mfma = false) {
   return p;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a 1x1, stride-1 convolution without bias, float32 storage, channel counts 16 / 32 / 64 / 128:
+//   dW[ci][co] = sum over pixels p of x[p][ci] * dy[p][co]
+// A 1x1 layer has no halo and no tap reuse, so nothing is gained by staging its operands in LDS: both are loaded straight
+// into the operand layout of v_mfma_f32_16x16x4_f32, which sums over FOUR pixels per instruction.  Lane (i = l & 15,
+// kk = l >> 4) of a wave loads, for pixel 4 * group + kk, the CI = cin / 16 consecutive input channels i * CI .. and the
+// CO = cout / 16 consecutive output-gradient channels i * CO ..: the 16 lanes of one pixel read its whole channel vector
+// with 4- to 16-byte loads.  Matrix instruction (mt, nt) takes element mt of the x registers as A and element nt of the
+// dy registers as B, i.e. tile (mt, nt) holds the rows ci = 16-row index * CI + mt and the columns co = column * CO + nt
+// of dW (a permutation of the rows and columns that only the final store has to know).  A wave owns every tile
+// (CI * CO accumulators of four registers) and walks its share of the workgroup's pixels U groups at a time through two
+// register sets (the next round's loads in flight under the current round's products); the four waves' sums are combined through LDS in a fixed order and the
+// workgroup writes ONE partial matrix for the strip reduction.  PRE: x is the raw input of a BatchNormalization + PReLU
+// whose output is the convolution's input; the lane applies it to its CI channels (arithmetic of bn_act_fwd_kernel).
+// Pixels past the workgroup's range contribute nothing: both loads return zero through the buffer bounds check.
+// ------------------------------------------------------------------------------------------------
+template <int N> struct VecLoad;
+template <> struct VecLoad<1> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* v) { v[0] = bload(r, off); }
+};
+template <> struct VecLoad<2> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* v) {
+    const u32x2 w = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    // (the elements go through scalars: a bit cast applied directly to a vector-element expression, bit_cast(float, w[1]),
+    // is compiled by hipcc 7.2 as if it named element 0, and the load shrinks to one dword)
+    const unsigned lo = w[0], hi = w[1];
+    v[0] = __builtin_bit_cast(float, lo); v[1] = __builtin_bit_cast(float, hi);
+  }
+};
+template <> struct VecLoad<4> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* v) {
+    const f32x4 w = bload4(r, off);
+    v[0] = w[0]; v[1] = w[1]; v[2] = w[2]; v[3] = w[3];
+  }
+};
+template <> struct VecLoad<8> {
+  static __device__ __forceinline__ void ld(__amdgpu_buffer_rsrc_t r, unsigned off, float* v) {
+    const f32x4 w0 = bload4(r, off), w1 = bload4(r, off + 16u);
+    v[0] = w0[0]; v[1] = w0[1]; v[2] = w0[2]; v[3] = w0[3]; v[4] = w1[0]; v[5] = w1[1]; v[6] = w1[2]; v[7] = w1[3];
+  }
+};
+
+template <int CI, int CO, bool PRE, int U>
+__global__ __launch_bounds__(256) void conv_bwd_weight_1x1(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ part, int npix, int x_ld, int y_ld,
+                                                           int groups_per_wg, PreBn pb) {
+  extern __shared__ f32x4 wg1_sm[];                 // [CI * CO][64] accumulators of one wave at a time
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kk = lane >> 4;
+  // groups of four pixels: this workgroup owns [g0, g1), wave w takes g0 + w, g0 + w + 4, ...  Both buffer descriptors END at
+  // the workgroup's last pixel, so a round that reaches past it reads zeros without any per-lane test (a `valid ? offset :
+  // out-of-range` select in front of a 4-byte load is compiled into a branch with a full memory-counter drain per load).
+  const int ngroups = (npix + 3) >> 2;
+  const int g0 = blockIdx.x * groups_per_wg;
+  int g1 = g0 + groups_per_wg;
+  if (g1 > ngroups) g1 = ngroups;
+  const int pend = 4 * g1 < npix ? 4 * g1 : npix;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(x, (unsigned)((int64_t)pend * x_ld * 4));
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(dy, (unsigned)((int64_t)pend * y_ld * 4));
+  float pm[CI], pis[CI], pg[CI], pbt[CI], pa[CI];
+  bool act = false;
+  if constexpr (PRE) {
+    act = pb.alpha != nullptr;
+#pragma unroll
+    for (int t = 0; t < CI; ++t) {
+      const int c = i * CI + t;
+      pm[t] = pb.mean[c]; pis[t] = pb.invstd[c]; pg[t] = pb.gamma[c]; pbt[t] = pb.beta[c];
+      pa[t] = act ? pb.alpha[c] : 0.f;
+    }
+  }
+  f32x4 acc[CI][CO];
+#pragma unroll
+  for (int m = 0; m < CI; ++m)
+#pragma unroll
+    for (int n = 0; n < CO; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // two register sets: the loads of round r + 1 are in flight while round r is multiplied (one wave per SIMD is the usual
+  // occupancy of these launches, so nothing else would hide the memory latency)
+  float xa[U][CI], da[U][CO], xb[U][CI], db[U][CO];
+  auto issue = [&](float (&xv)[U][CI], float (&dv)[U][CO], int gb) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned p = (unsigned)(4 * (gb + 4 * u) + kk);
+      VecLoad<CI>::ld(rx, (p * (unsigned)x_ld + (unsigned)(i * CI)) * 4u, xv[u]);
+      VecLoad<CO>::ld(rd, (p * (unsigned)y_ld + (unsigned)(i * CO)) * 4u, dv[u]);
+    }
+  };
+  auto consume = [&](float (&xv)[U][CI], float (&dv)[U][CO]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if constexpr (PRE) {
+#pragma unroll
+        for (int t = 0; t < CI; ++t) xv[u][t] = pre_bn_act(xv[u][t], pm[t], pis[t], pg[t], pbt[t], pa[t], act);
+      }
+#pragma unroll
+      for (int m = 0; m < CI; ++m)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u][m], dv[u][n], acc[m][n], 0, 0, 0);
+    }
+  };
+  int gb = g0 + wave;
+  issue(xa, da, gb);
+  for (; gb < g1; gb += 8 * U) {
+    issue(xb, db, gb + 4 * U);          // groups past g1 read nothing (out-of-range offsets)
+    consume(xa, da);
+    issue(xa, da, gb + 8 * U);
+    consume(xb, db);
+  }
+  // waves 1..3 hand their sums to wave 0, one after the other (fixed order of additions)
+  for (int w = 1; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < CI; ++m)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) wg1_sm[(m * CO + n) * 64 + lane] = acc[m][n];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int m = 0; m < CI; ++m)
+#pragma unroll
+        for (int n = 0; n < CO; ++n) acc[m][n] += wg1_sm[(m * CO + n) * 64 + lane];
+    }
+    __syncthreads();
+  }
+  if (wave != 0) return;
+  constexpr int cout = 16 * CO;
+  float* pbase = part + (size_t)blockIdx.x * (16 * CI) * cout;
+#pragma unroll
+  for (int m = 0; m < CI; ++m)
+#pragma unroll
+    for (int n = 0; n < CO; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ci = (4 * kk + r) * CI + m, co = i * CO + n;
+        pbase[ci * cout + co] = acc[m][n][r];
+      }
+}
+
+struct Wg1x1Plan {
+  bool use;
+  int ci, co, groups_per_wg, nstrips;
+  size_t bytes;
+};
+static Wg1x1Plan plan_wg_1x1(const Geo& g, bool with_bias) {
+  Wg1x1Plan p{};
+  static const bool off = getenv("SSMI_NO_WG_1X1") != nullptr;      // measurement switch
+  auto okc = [](int c) { return c == 16 || c == 32 || c == 64 || c == 128; };
+  p.use = !off && !with_bias && g.kh == 1 && g.kw == 1 && g.stride == 1 && okc(g.cin) && okc(g.cout) && g.x_ld % 4 == 0 &&
+          g.y_ld % 4 == 0 && g.ho == g.h && g.wo == g.w && !(g.cin == 128 && g.cout == 128);
+  if (!p.use) return p;
+  p.ci = g.cin / 16;
+  p.co = g.cout / 16;
+  static const int strips_env = [] { const char* e = getenv("SSMI_WG1X1_STRIPS"); return e ? atoi(e) : 0; }();
+  // one workgroup per CU: with two, the partial sums double and the main chain beside these launches loses more than
+  // they gain (ENet step 8.83 ms with 256, 8.95 with 384, 8.91-8.96 with 512)
+  const int target = strips_env ? strips_env : 256;
+  const int64_t npix = (int64_t)g.n * g.h * g.w;
+  const int ngroups = (int)((npix + 3) / 4);
+  int gpw = (ngroups + target - 1) / target;
+  gpw = (gpw + 3) & ~3;                 // whole rounds of the four waves
+  if (gpw < 4) gpw = 4;
+  p.groups_per_wg = gpw;
+  p.nstrips = (ngroups + gpw - 1) / gpw;
+  p.bytes = (size_t)p.nstrips * g.cin * g.cout * sizeof(float);
+  return p;
+}
+
+static bool launch_wg_1x1(const Geo& g, const Wg1x1Plan& p, const float* x, const float* dy, float* part, hipStream_t st,
+                          const PreBn* pre) {
+  const int npix = g.n * g.h * g.w;
+  const size_t lds = (size_t)p.ci * p.co * 64 * sizeof(f32x4);
+  const PreBn pb = pre ? *pre : PreBn{};
+#define L1(CI, CO, U)                                                                                                           \
+  do {                                                                                                                          \
+    if (pre) hipLaunchKernelGGL((conv_bwd_weight_1x1<CI, CO, true, U>), dim3(p.nstrips), dim3(256), lds, st, x, dy, part, npix, \
+                                g.x_ld, g.y_ld, p.groups_per_wg, pb);                                                           \
+    else hipLaunchKernelGGL((conv_bwd_weight_1x1<CI, CO, false, U>), dim3(p.nstrips), dim3(256), lds, st, x, dy, part, npix,    \
+                            g.x_ld, g.y_ld, p.groups_per_wg, pb);                                                               \
+    return true;                                                                                                                \
+  } while (0)
+  const int key = p.ci * 16 + p.co;
+  switch (key) {
+    case 1 * 16 + 1: L1(1, 1, 8);
+    case 1 * 16 + 2: L1(1, 2, 8);
+    case 1 * 16 + 4: L1(1, 4, 8);
+    case 1 * 16 + 8: L1(1, 8, 4);
+    case 2 * 16 + 1: L1(2, 1, 8);
+    case 2 * 16 + 2: L1(2, 2, 8);
+    case 2 * 16 + 4: L1(2, 4, 4);
+    case 2 * 16 + 8: L1(2, 8, 4);
+    case 4 * 16 + 1: L1(4, 1, 8);
+    case 4 * 16 + 2: L1(4, 2, 4);
+    case 4 * 16 + 4: L1(4, 4, 4);
+    case 4 * 16 + 8: L1(4, 8, 2);
+    case 8 * 16 + 1: L1(8, 1, 4);
+    case 8 * 16 + 2: L1(8, 2, 4);
+    case 8 * 16 + 4: L1(8, 4, 2);
+    default: return false;
+  }
+#undef L1
+}
+
 static size_t wg_ws_bytes(const Geo& g) {
   const TiledPlan t = plan_tiled(g, true);
   const size_t b0 = plan_wg(g, false).bytes, b1 = plan_wg(g, true).bytes;
   const size_t b2 = plan_wg(g, true, true).bytes;      // the bf16 matrix-instruction variant tiles (and so strips) differently
-  const size_t b = std::max(b0, std::max(b1, b2));
+  const size_t b3 = plan_wg_1x1(g, false).bytes;      // direct 1x1 kernel (float32 storage, no bias)
+  const size_t b = std::max(std::max(b0, b3), std::max(b1, b2));
   return t.use && t.bytes > b ? t.bytes : b;      // the strip kernels remain the fallback for unaligned pointers
 }
 
@@ -3128,6 +3333,21 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
   Sizes sz;
   ssmi_status e = make_sizes(g, &sz);
   if (e) return e;
+  if constexpr (sizeof(T) == 4) {
+    // 1x1 layers: operands straight from global memory in the matrix instruction's layout
+    const Wg1x1Plan q = plan_wg_1x1(g, dbias != nullptr);
+    if (q.use && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && !plan_tiled(g, false).use) {
+      SSMI_REQUIRE(ws != nullptr && ws_bytes >= q.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
+                   ws_bytes, q.bytes);
+      float* part = reinterpret_cast<float*>(ws);
+      if (launch_wg_1x1(g, q, x, dy, part, st, pre)) {
+        SSMI_LAUNCH_CHECK();
+        launch_wg_reduce(part, q.nstrips, g.cin, g.cin, g.cout, dw, nullptr, st);
+        SSMI_LAUNCH_CHECK();
+        return SSMI_OK;
+      }
+    }
+  }
   if (pre) {
     if constexpr (sizeof(T) == 2) {
       SSMI_REQUIRE(wg_prebn_ok(g, dbias != nullptr, true) && (reinterpret_cast<uintptr_t>(x) & 15) == 0, SSMI_E_UNSUPPORTED,

@@ -384,6 +384,9 @@ def check_queue_budget(side_streams: int, env=None) -> None:
 
 
 _ABLATE_WGRAD = os.environ.get("SSMI_ABLATE_WGRAD") is not None
+# timing experiments only (results meaningless): skip the weight gradients of one class of layers - "head" (the logits layer),
+# "1x1" (every 1x1 convolution), "spatial" (everything else)
+_ABLATE_WGRAD_KIND = os.environ.get("SSMI_ABLATE_WGRAD_KIND", "")
 _WGRAD_LAG = int(os.environ.get("SSMI_WGRAD_LAG", "1"))      # blocks between a fork point and the launches behind it (0: at once)
 _WGRAD_FORK_PER_CONV = os.environ.get("SSMI_WGRAD_FORK", "conv") == "conv"      # one fork point per layer instead of one per block
 
@@ -420,6 +423,10 @@ class RunCfg:
         the stream it runs on."""
         if _ABLATE_WGRAD:       # timing experiment only: the step then computes no weight gradients at all
             return
+        if _ABLATE_WGRAD_KIND:
+            kind = "head" if conv.name == "logits" else ("1x1" if conv.kh == 1 and conv.kw == 1 else "spatial")
+            if kind in _ABLATE_WGRAD_KIND.split(","):
+                return
         if self.side is None:
             if before is not None:
                 before(self.st)

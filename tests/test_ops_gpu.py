@@ -53,6 +53,16 @@ CONV_CASES = [
     (1, 1, 256, 64, 1, 1, "valid", True, 1, 7, 9),
     (3, 3, 48, 192, 1, 2, "same", True, 1, 10, 6),     # cout = 3 x 64, dilated taps
     (3, 3, 136, 128, 1, 1, "same", True, 3, 5, 7),     # k-tile spanning two taps (cin not a multiple of the tile)
+    # 1x1 layers of the direct weight-gradient kernel (operands in the matrix instruction's layout): every channel pair class,
+    # pixel counts that are no multiple of the four-pixel groups, several workgroups and several rounds per wave
+    (1, 1, 128, 64, 1, 1, "valid", False, 2, 37, 29),
+    (1, 1, 128, 16, 1, 1, "valid", False, 3, 21, 23),
+    (1, 1, 64, 64, 1, 1, "valid", False, 1, 50, 41),
+    (1, 1, 32, 32, 1, 1, "valid", False, 2, 19, 17),
+    (1, 1, 16, 16, 1, 1, "valid", False, 1, 45, 47),
+    (1, 1, 64, 128, 1, 1, "valid", False, 1, 33, 31),
+    (1, 1, 32, 128, 1, 1, "valid", False, 4, 64, 64),
+    (1, 1, 128, 32, 1, 1, "valid", False, 4, 64, 64),
 ]
 
 
