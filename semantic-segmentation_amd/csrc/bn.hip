@@ -3,6 +3,7 @@
 // so consecutive lanes touch consecutive 16-byte chunks.  Per-channel reductions use a fixed (thread, block) ->
 // partial-sum mapping followed by a double-precision finalize kernel (deterministic).
 #include "common.h"
+#include <initializer_list>
 
 namespace ssmi {
 
@@ -177,86 +178,195 @@ __device__ __forceinline__ float act_grad(float z, float a) {
   return z > 0.f ? 1.f : (z < 0.f ? a : 0.f);
 }
 
-// Elementwise kernels: thread (c4 = tid % c4n, pl = tid / c4n) owns channel group c4 of the pixels pl, pl + stride, ...
-// so its per-channel parameters are loaded ONCE (re-loading five or more 16-byte parameter vectors for every 16-byte
-// payload load made the address unit, not HBM, the limit), and it handles four pixels per round with all payload loads
-// issued before the first store.
-template <typename T, int ACT>
+// Elementwise kernels: thread (cg = tid % cgn, pl = tid / cgn) owns channel group cg - VW consecutive channels - of the
+// pixels pl, pl + stride, ..., so its per-channel parameters are loaded ONCE (re-loading five or more 16-byte parameter
+// vectors for every 16-byte payload load made the address unit, not HBM, the limit), and it handles four pixels per round
+// with all payload loads issued before the first store.  VW = 4 elements per access for float32 storage and 8 for
+// bfloat16 storage (16 bytes either way: 8-byte accesses run at 0.55-0.7 of the 16-byte rate and leave half-written
+// lines behind); bfloat16 tensors whose channel count or strides are no multiple of eight keep VW = 4.
+template <int VW>
+struct fvec {
+  float e[VW];
+  __device__ __forceinline__ float& operator[](int i) { return e[i]; }
+  __device__ __forceinline__ const float& operator[](int i) const { return e[i]; }
+};
+template <int VW>
+__device__ __forceinline__ fvec<VW> fsplat(float v) {
+  fvec<VW> r;
+#pragma unroll
+  for (int j = 0; j < VW; ++j) r[j] = v;
+  return r;
+}
+// VW consecutive float32 parameters (16-byte aligned)
+template <int VW>
+__device__ __forceinline__ fvec<VW> ldp(const float* p) {
+  fvec<VW> r;
+#pragma unroll
+  for (int h = 0; h < VW / 4; ++h) {
+    const f32x4 v = ld4(p + 4 * h);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[4 * h + j] = v[j];
+  }
+  return r;
+}
+// VW consecutive activation elements: plain pointers (gld / gst) and buffer loads with a float32-unit byte offset (bld)
+template <typename T, int VW> struct VAcc;
+template <typename T> struct VAcc<T, 4> {
+  static __device__ __forceinline__ fvec<4> gld(const T* p) {
+    const f32x4 v = Act<T>::gld4(p);
+    return fvec<4>{{v[0], v[1], v[2], v[3]}};
+  }
+  static __device__ __forceinline__ void gst(T* p, const fvec<4>& v) { Act<T>::gst4(p, f32x4{v[0], v[1], v[2], v[3]}); }
+  static __device__ __forceinline__ fvec<4> bld(__amdgpu_buffer_rsrc_t r, unsigned off4) {
+    const f32x4 v = Act<T>::ld4(r, off4);
+    return fvec<4>{{v[0], v[1], v[2], v[3]}};
+  }
+};
+template <> struct VAcc<bf16, 8> {
+  static __device__ __forceinline__ fvec<8> widen(u32x4 w) {
+    fvec<8> r;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const unsigned q = w[h];
+      r[2 * h] = __builtin_bit_cast(float, q << 16);
+      r[2 * h + 1] = __builtin_bit_cast(float, q & 0xFFFF0000u);
+    }
+    return r;
+  }
+  static __device__ __forceinline__ fvec<8> gld(const bf16* p) { return widen(*reinterpret_cast<const u32x4*>(p)); }
+  static __device__ __forceinline__ void gst(bf16* p, const fvec<8>& v) {
+    u32x4 w;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) w[h] = pack_bf16x2(v[2 * h], v[2 * h + 1]);
+    *reinterpret_cast<u32x4*>(p) = w;
+  }
+  static __device__ __forceinline__ fvec<8> bld(__amdgpu_buffer_rsrc_t r, unsigned off4) {
+    return widen(__builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off4 >> 1, 0, 0)));
+  }
+};
+
+// block-level reduction of NV accumulator vectors over the threads that share a channel group: sm holds
+// NV * (VW / 4) * 256 float4; the result for channel group cg is returned by thread tid == cg (tid < cgn).
+template <int NV, int VW>
+__device__ __forceinline__ void block_reduce_v(fvec<VW> (&v)[NV], f32x4* sm, int cgn, int ppi, bool active) {
+  const int tid = threadIdx.x;
+  constexpr int H = VW / 4;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int h = 0; h < H; ++h)
+      sm[(k * H + h) * 256 + tid] = active ? f32x4{v[k][4 * h], v[k][4 * h + 1], v[k][4 * h + 2], v[k][4 * h + 3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if (tid < cgn) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < ppi; ++q) s += sm[(k * H + h) * 256 + q * cgn + tid];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[k][4 * h + j] = s[j];
+      }
+  }
+}
+// thread tid < cgn writes its NV reduced vectors as rows blockIdx.x * NV + k of part[rows][c]
+template <int NV, int VW>
+__device__ __forceinline__ void store_partial_rows(const fvec<VW> (&v)[NV], float* __restrict__ part, int cgn) {
+  const int cc = cgn * VW;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+#pragma unroll
+    for (int h = 0; h < VW / 4; ++h)
+      st4(part + ((int64_t)blockIdx.x * NV + k) * cc + threadIdx.x * VW + 4 * h,
+          f32x4{v[k][4 * h], v[k][4 * h + 1], v[k][4 * h + 2], v[k][4 * h + 3]});
+}
+
+template <typename T, int ACT, int VW>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const T* __restrict__ x, int ld, const float* __restrict__ mean,
                                                          const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ alpha,
                                                          float slope, const float* __restrict__ drop, int64_t hw,
-                                                         T* __restrict__ y, int y_ld, int64_t npix, int c4n) {
-  const unsigned ppi = 256u / (unsigned)c4n;
-  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+                                                         T* __restrict__ y, int y_ld, int64_t npix, int cgn) {
+  typedef fvec<VW> V;
+  constexpr int NP = VW == 8 ? 2 : 4;      // pixels per round: 16-byte accesses carry twice the elements, half the pixels keep the registers
+  const unsigned ppi = 256u / (unsigned)cgn;
+  const unsigned cg = threadIdx.x % (unsigned)cgn, pl = threadIdx.x / (unsigned)cgn;
   if (pl >= ppi) return;
-  const int c = (int)c4 * 4;
-  const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
-  f32x4 a = {slope, slope, slope, slope};
-  if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
-  auto one = [&](const f32x4& xv, unsigned p) {
-    f32x4 o;
+  const int c = (int)cg * VW;
+  const V m = ldp<VW>(mean + c), is = ldp<VW>(invstd + c), g = ldp<VW>(gamma + c), b = ldp<VW>(beta + c);
+  V a = fsplat<VW>(slope);
+  if (ACT == SSMI_ACT_PRELU) a = ldp<VW>(alpha + c);
+  auto one = [&](const V& xv, unsigned p) {
+    V o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
-    if (drop) o = o * ld4(drop + (p / (unsigned)hw) * (unsigned)(c4n * 4) + c);
+    for (int j = 0; j < VW; ++j) o[j] = act_fwd<ACT>(g[j] * ((xv[j] - m[j]) * is[j]) + b[j], a[j]);
+    if (drop) {
+      const V dv = ldp<VW>(drop + (p / (unsigned)hw) * (unsigned)(cgn * VW) + c);
+#pragma unroll
+      for (int j = 0; j < VW; ++j) o[j] = o[j] * dv[j];
+    }
     return o;
   };
   const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;      // npix * ld < 2^29
   unsigned p = blockIdx.x * ppi + pl;
-  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
-    f32x4 xv[4];
+  for (; (uint64_t)p + (uint64_t)(NP - 1) * stride < (uint64_t)n; p += (unsigned)NP * stride) {
+    V xv[NP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = Act<T>::gld4(x + (p + (unsigned)u * stride) * (unsigned)ld + c);
+    for (int u = 0; u < NP; ++u) xv[u] = VAcc<T, VW>::gld(x + (p + (unsigned)u * stride) * (unsigned)ld + c);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) xv[u] = one(xv[u], p + (unsigned)u * stride);
+    for (int u = 0; u < NP; ++u) xv[u] = one(xv[u], p + (unsigned)u * stride);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Act<T>::gst4(y + (p + (unsigned)u * stride) * (unsigned)y_ld + c, xv[u]);
+    for (int u = 0; u < NP; ++u) VAcc<T, VW>::gst(y + (p + (unsigned)u * stride) * (unsigned)y_ld + c, xv[u]);
   }
-  for (; p < n; p += stride) Act<T>::gst4(y + p * (unsigned)y_ld + c, one(Act<T>::gld4(x + p * (unsigned)ld + c), p));
+  for (; p < n; p += stride) VAcc<T, VW>::gst(y + p * (unsigned)y_ld + c, one(VAcc<T, VW>::gld(x + p * (unsigned)ld + c), p));
 }
 
 // backward pass 1: per-channel sums of dz, dz*xhat and (PReLU) dy*min(z,0)
-template <typename T, int ACT>
+template <typename T, int ACT, int VW>
 __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const T* __restrict__ dy, const T* __restrict__ x, int ld,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ alpha, float slope,
                                                          const float* __restrict__ drop, int64_t hw, int dy_ld,
-                                                         int64_t npix, int c4n, float* __restrict__ part) {
-  __shared__ f32x4 sm[3 * 256];
-  const int ppi = 256 / c4n;
-  const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+                                                         int64_t npix, int cgn, float* __restrict__ part) {
+  typedef fvec<VW> V;
+  constexpr int NP = VW == 8 ? 2 : 4;      // pixels per round: 16-byte accesses carry twice the elements, half the pixels keep the registers
+  __shared__ f32x4 sm[3 * (VW / 4) * 256];
+  const int ppi = 256 / cgn;
+  const int cg = threadIdx.x % cgn, pl = threadIdx.x / cgn;
   const bool active = pl < ppi;
-  const int c = c4 * 4;
-  f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int c = cg * VW;
+  V v[3] = {fsplat<VW>(0.f), fsplat<VW>(0.f), fsplat<VW>(0.f)};
   if (active) {
-    const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
-    f32x4 a = {slope, slope, slope, slope};
-    if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
+    const V m = ldp<VW>(mean + c), is = ldp<VW>(invstd + c), g = ldp<VW>(gamma + c), b = ldp<VW>(beta + c);
+    V a = fsplat<VW>(slope);
+    if (ACT == SSMI_ACT_PRELU) a = ldp<VW>(alpha + c);
     // four pixels per round, their eight loads in flight together
     const __amdgpu_buffer_rsrc_t rx = Act<T>::rsrc(x, (unsigned)(npix * ld * 4));
     const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(dy, (unsigned)(npix * dy_ld * 4));
     const int64_t stride = (int64_t)gridDim.x * ppi;
-    for (int64_t p0 = (int64_t)blockIdx.x * ppi + pl; p0 < npix; p0 += stride * 4) {
-      f32x4 xv[4], d[4];
+    for (int64_t p0 = (int64_t)blockIdx.x * ppi + pl; p0 < npix; p0 += stride * NP) {
+      V xv[NP], d[NP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NP; ++u) {
         const int64_t p = p0 + u * stride;
         const bool ok = p < npix;
-        xv[u] = Act<T>::ld4(rx, ok ? (unsigned)((p * ld + c) * 4) : kOOB);
-        d[u] = Act<T>::ld4(rd, ok ? (unsigned)((p * dy_ld + c) * 4) : kOOB);   // zero gradient for pixels past the end
+        xv[u] = VAcc<T, VW>::bld(rx, ok ? (unsigned)((p * ld + c) * 4) : kOOB);
+        d[u] = VAcc<T, VW>::bld(rd, ok ? (unsigned)((p * dy_ld + c) * 4) : kOOB);   // zero gradient for pixels past the end
       }
       if (drop) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NP; ++u) {
           const int64_t p = p0 + u * stride;
-          d[u] = d[u] * ld4(drop + ((p < npix ? p : npix - 1) / hw) * (c4n * 4) + c);
+          const V dv = ldp<VW>(drop + ((p < npix ? p : npix - 1) / hw) * (cgn * VW) + c);
+#pragma unroll
+          for (int j = 0; j < VW; ++j) d[u][j] = d[u][j] * dv[j];
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NP; ++u) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < VW; ++j) {
           const float xh = (xv[u][j] - m[j]) * is[j];
           const float z = g[j] * xh + b[j];
           const float dz = d[u][j] * act_grad<ACT>(z, a[j]);
@@ -267,12 +377,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce(const T* __restrict__ d
       }
     }
   }
-  block_reduce_groups<3>(v, sm, c4n, ppi, active);
-  if (threadIdx.x < c4n) {
-    const int cc = c4n * 4;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st4(part + ((int64_t)blockIdx.x * 3 + k) * cc + threadIdx.x * 4, v[k]);
-  }
+  block_reduce_v<3, VW>(v, sm, cgn, ppi, active);
+  if (threadIdx.x < cgn) store_partial_rows<3, VW>(v, part, cgn);
 }
 
 // finalize: parameter gradients + coefficients for the apply pass: coef[0]=gamma*invstd, coef[1]=mean(dz), coef[2]=mean(dz*xhat)
@@ -293,28 +399,34 @@ __global__ __launch_bounds__(256) void bn_bwd_final(const float* __restrict__ pa
   coef[2 * c + ch] = (float)(r[1] / (double)npix);
 }
 
-template <typename T, int ACT>
+template <typename T, int ACT, int VW>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply(const T* __restrict__ dy, const T* __restrict__ x, int ld,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         const float* __restrict__ alpha, float slope,
                                                         const float* __restrict__ drop, int64_t hw, int dy_ld,
                                                         const float* __restrict__ coef, T* dx,
-                                                        int64_t npix, int c4n) {
-  const int cc = c4n * 4;
-  const unsigned ppi = 256u / (unsigned)c4n;
-  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+                                                        int64_t npix, int cgn) {
+  typedef fvec<VW> V;
+  constexpr int NP = VW == 8 ? 2 : 4;      // pixels per round: 16-byte accesses carry twice the elements, half the pixels keep the registers
+  const int cc = cgn * VW;
+  const unsigned ppi = 256u / (unsigned)cgn;
+  const unsigned cg = threadIdx.x % (unsigned)cgn, pl = threadIdx.x / (unsigned)cgn;
   if (pl >= ppi) return;
-  const int c = (int)c4 * 4;
-  const f32x4 m = ld4(mean + c), is = ld4(invstd + c), g = ld4(gamma + c), b = ld4(beta + c);
-  const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
-  f32x4 a = {slope, slope, slope, slope};
-  if (ACT == SSMI_ACT_PRELU) a = ld4(alpha + c);
-  auto one = [&](const f32x4& xv, f32x4 d, unsigned p) {
-    if (drop) d = d * ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
-    f32x4 o;
+  const int c = (int)cg * VW;
+  const V m = ldp<VW>(mean + c), is = ldp<VW>(invstd + c), g = ldp<VW>(gamma + c), b = ldp<VW>(beta + c);
+  const V k1 = ldp<VW>(coef + c), m1 = ldp<VW>(coef + cc + c), m2 = ldp<VW>(coef + 2 * cc + c);
+  V a = fsplat<VW>(slope);
+  if (ACT == SSMI_ACT_PRELU) a = ldp<VW>(alpha + c);
+  auto one = [&](const V& xv, V d, unsigned p) {
+    if (drop) {
+      const V dv = ldp<VW>(drop + (p / (unsigned)hw) * (unsigned)cc + c);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < VW; ++j) d[j] = d[j] * dv[j];
+    }
+    V o;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
       const float xh = (xv[j] - m[j]) * is[j];
       const float z = g[j] * xh + b[j];
       const float dz = d[j] * act_grad<ACT>(z, a[j]);
@@ -324,21 +436,22 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply(const T* __restrict__ dy
   };
   const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;
   unsigned p = blockIdx.x * ppi + pl;
-  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
-    f32x4 xv[4], d[4];
+  for (; (uint64_t)p + (uint64_t)(NP - 1) * stride < (uint64_t)n; p += (unsigned)NP * stride) {
+    V xv[NP], d[NP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < NP; ++u) {
       const unsigned q = p + (unsigned)u * stride;
-      xv[u] = Act<T>::gld4(x + q * (unsigned)ld + c);
-      d[u] = Act<T>::gld4(dy + q * (unsigned)dy_ld + c);
+      xv[u] = VAcc<T, VW>::gld(x + q * (unsigned)ld + c);
+      d[u] = VAcc<T, VW>::gld(dy + q * (unsigned)dy_ld + c);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) d[u] = one(xv[u], d[u], p + (unsigned)u * stride);
+    for (int u = 0; u < NP; ++u) d[u] = one(xv[u], d[u], p + (unsigned)u * stride);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Act<T>::gst4(dx + (p + (unsigned)u * stride) * (unsigned)ld + c, d[u]);   // dx may alias dy: all loads are done
+    for (int u = 0; u < NP; ++u) VAcc<T, VW>::gst(dx + (p + (unsigned)u * stride) * (unsigned)ld + c, d[u]);   // dx may alias dy: all loads are done
   }
   for (; p < n; p += stride)
-    Act<T>::gst4(dx + p * (unsigned)ld + c, one(Act<T>::gld4(x + p * (unsigned)ld + c), Act<T>::gld4(dy + p * (unsigned)dy_ld + c), p));
+    VAcc<T, VW>::gst(dx + p * (unsigned)ld + c,
+                     one(VAcc<T, VW>::gld(x + p * (unsigned)ld + c), VAcc<T, VW>::gld(dy + p * (unsigned)dy_ld + c), p));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -356,136 +469,143 @@ struct MergeArgs {
 };
 
 // per-channel parameters of a thread's channel group, loaded once
+template <int VW>
 struct MergeParams {
-  f32x4 m, is, g, b;         // BN3
-  f32x4 mo, iso, go, bo;     // BN of the skip branch (modes 2, 3)
+  fvec<VW> m, is, g, b;         // BN3
+  fvec<VW> mo, iso, go, bo;     // BN of the skip branch (modes 2, 3)
 };
-template <int MODE>
-__device__ __forceinline__ MergeParams merge_params(const MergeArgs& a, int c) {
-  MergeParams q;
-  q.m = ld4(a.mean3 + c); q.is = ld4(a.invstd3 + c); q.g = ld4(a.gamma3 + c); q.b = ld4(a.beta3 + c);
-  q.mo = q.iso = q.go = q.bo = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (MODE >= 2) { q.mo = ld4(a.mean_o + c); q.iso = ld4(a.invstd_o + c); q.go = ld4(a.gamma_o + c); q.bo = ld4(a.beta_o + c); }
+template <int MODE, int VW>
+__device__ __forceinline__ MergeParams<VW> merge_params(const MergeArgs& a, int c) {
+  MergeParams<VW> q;
+  q.m = ldp<VW>(a.mean3 + c); q.is = ldp<VW>(a.invstd3 + c); q.g = ldp<VW>(a.gamma3 + c); q.b = ldp<VW>(a.beta3 + c);
+  q.mo = q.iso = q.go = q.bo = fsplat<VW>(0.f);
+  if (MODE >= 2) { q.mo = ldp<VW>(a.mean_o + c); q.iso = ldp<VW>(a.invstd_o + c); q.go = ldp<VW>(a.gamma_o + c); q.bo = ldp<VW>(a.beta_o + c); }
   return q;
 }
 
-// Raw operands of element group (p, c..c+3): the main-branch value, the skip-branch value and (mode 3) the argmax indices.
+// Raw operands of element group (p, c..c+VW-1): the main-branch value, the skip-branch value and (mode 3) the argmax indices.
 // Loads only, so that a caller can issue several pixels' loads back to back.
-template <typename T, int MODE>
+template <int VW>
 struct MergeRaw {
-  f32x4 mv, ov, dropv;
-  int4 iv;
+  fvec<VW> mv, ov, dropv;
+  int iv[VW];
   int flat;
   bool has_other;
 };
-template <typename T, int MODE>
-__device__ __forceinline__ MergeRaw<T, MODE> merge_load(const MergeArgs& a, unsigned p, int c) {
-  MergeRaw<T, MODE> r;
+template <typename T, int MODE, int VW>
+__device__ __forceinline__ MergeRaw<VW> merge_load(const MergeArgs& a, unsigned p, int c) {
+  MergeRaw<VW> r;
   const unsigned hw = (unsigned)(a.h * a.w);     // every tensor is below 2 GiB: 32-bit element arithmetic
   const unsigned n_ = p / hw;
   const T* main_ = static_cast<const T*>(a.main);
   const T* other_ = static_cast<const T*>(a.other);
-  r.mv = Act<T>::gld4(main_ + p * a.c + c);
-  r.dropv = f32x4{1.f, 1.f, 1.f, 1.f};
-  if (a.drop) r.dropv = ld4(a.drop + n_ * (unsigned)a.c + c);
-  r.ov = f32x4{0.f, 0.f, 0.f, 0.f};
-  r.iv = int4{0, 0, 0, 0};
+  r.mv = VAcc<T, VW>::gld(main_ + p * a.c + c);
+  r.dropv = fsplat<VW>(1.f);
+  if (a.drop) r.dropv = ldp<VW>(a.drop + n_ * (unsigned)a.c + c);
+  r.ov = fsplat<VW>(0.f);
+#pragma unroll
+  for (int j = 0; j < VW; ++j) r.iv[j] = 0;
   r.flat = 0;
   r.has_other = true;
   if (MODE == 0) {
-    r.ov = Act<T>::gld4(other_ + p * a.c + c);
+    r.ov = VAcc<T, VW>::gld(other_ + p * a.c + c);
   } else if (MODE == 1) {
     r.has_other = c < a.c_other;
-    if (r.has_other) r.ov = Act<T>::gld4(other_ + p * a.c_other + c);
+    if (r.has_other) r.ov = VAcc<T, VW>::gld(other_ + p * a.c_other + c);
   } else {
     const unsigned rem = p - n_ * hw;
     const int y = (int)(rem / (unsigned)a.w), x = (int)(rem - (unsigned)y * (unsigned)a.w);
     const int h2 = a.h >> 1, w2 = a.w >> 1;
     const unsigned q = (n_ * (unsigned)h2 + (unsigned)(y >> 1)) * (unsigned)w2 + (unsigned)(x >> 1);
-    r.ov = Act<T>::gld4(other_ + q * a.c + c);
+    r.ov = VAcc<T, VW>::gld(other_ + q * a.c + c);
     if (MODE == 3) {
-      r.iv = *reinterpret_cast<const int4*>(a.idx + q * a.c + c);
+#pragma unroll
+      for (int h = 0; h < VW / 4; ++h) {
+        const int4 t = *reinterpret_cast<const int4*>(a.idx + q * a.c + c + 4 * h);
+        r.iv[4 * h] = t.x; r.iv[4 * h + 1] = t.y; r.iv[4 * h + 2] = t.z; r.iv[4 * h + 3] = t.w;
+      }
       r.flat = (y * a.w + x) * a.c + c;
     }
   }
   return r;
 }
 // pre-activation sum s and the BN3 intermediate xhat3 from the raw operands
-template <typename T, int MODE>
-__device__ __forceinline__ f32x4 merge_sum(const MergeParams& q, const MergeRaw<T, MODE>& r, f32x4& xh3) {
-  f32x4 s;
+template <int MODE, int VW>
+__device__ __forceinline__ fvec<VW> merge_sum(const MergeParams<VW>& q, const MergeRaw<VW>& r, fvec<VW>& xh3) {
+  fvec<VW> s;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < VW; ++j) {
     xh3[j] = (r.mv[j] - q.m[j]) * q.is[j];
     s[j] = (q.g[j] * xh3[j] + q.b[j]) * r.dropv[j];
   }
   if (MODE <= 1) {
-    s += r.ov;            // zeros where the pooled skip tensor has no such channel
-  } else {
-    f32x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = q.go[j] * ((r.ov[j] - q.mo[j]) * q.iso[j]) + q.bo[j];
-    if (MODE == 3) {
-      o[0] = (r.iv.x == r.flat) ? o[0] : 0.f;
-      o[1] = (r.iv.y == r.flat + 1) ? o[1] : 0.f;
-      o[2] = (r.iv.z == r.flat + 2) ? o[2] : 0.f;
-      o[3] = (r.iv.w == r.flat + 3) ? o[3] : 0.f;
+    for (int j = 0; j < VW; ++j) s[j] += r.ov[j];            // zeros where the pooled skip tensor has no such channel
+  } else {
+#pragma unroll
+    for (int j = 0; j < VW; ++j) {
+      float o = q.go[j] * ((r.ov[j] - q.mo[j]) * q.iso[j]) + q.bo[j];
+      if (MODE == 3) o = (r.iv[j] == r.flat + j) ? o : 0.f;
+      s[j] += o;
     }
-    s += o;
   }
   return s;
 }
 
-template <typename T, int MODE>
-__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, T* __restrict__ out, int64_t npix, int c4n) {
-  const unsigned ppi = 256u / (unsigned)c4n;
-  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+template <typename T, int MODE, int VW>
+__global__ __launch_bounds__(256) void merge_fwd_kernel(MergeArgs a, T* __restrict__ out, int64_t npix, int cgn) {
+  typedef fvec<VW> V;
+  constexpr int NP = VW == 8 ? 2 : 4;      // pixels per round: 16-byte accesses carry twice the elements, half the pixels keep the registers
+  const unsigned ppi = 256u / (unsigned)cgn;
+  const unsigned cg = threadIdx.x % (unsigned)cgn, pl = threadIdx.x / (unsigned)cgn;
   if (pl >= ppi) return;
-  const int c = (int)c4 * 4;
-  const MergeParams q = merge_params<MODE>(a, c);
-  const f32x4 al = ld4(a.alpha + c);
-  auto finish = [&](const MergeRaw<T, MODE>& r) {
-    f32x4 xh3;
-    const f32x4 s = merge_sum<T, MODE>(q, r, xh3);
-    f32x4 o;
+  const int c = (int)cg * VW;
+  const MergeParams<VW> q = merge_params<MODE, VW>(a, c);
+  const V al = ldp<VW>(a.alpha + c);
+  auto finish = [&](const MergeRaw<VW>& r) {
+    V xh3;
+    const V s = merge_sum<MODE, VW>(q, r, xh3);
+    V o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = s[j] > 0.f ? s[j] : al[j] * s[j];
+    for (int j = 0; j < VW; ++j) o[j] = s[j] > 0.f ? s[j] : al[j] * s[j];
     return o;
   };
   const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;
   unsigned p = blockIdx.x * ppi + pl;
-  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
-    MergeRaw<T, MODE> r[4];
+  for (; (uint64_t)p + (uint64_t)(NP - 1) * stride < (uint64_t)n; p += (unsigned)NP * stride) {
+    MergeRaw<VW> r[NP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) r[u] = merge_load<T, MODE>(a, p + (unsigned)u * stride, c);
-    f32x4 o[4];
+    for (int u = 0; u < NP; ++u) r[u] = merge_load<T, MODE, VW>(a, p + (unsigned)u * stride, c);
+    V o[NP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) o[u] = finish(r[u]);
+    for (int u = 0; u < NP; ++u) o[u] = finish(r[u]);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Act<T>::gst4(out + ((p + (unsigned)u * stride) * (unsigned)c4n + c4) * 4u, o[u]);
+    for (int u = 0; u < NP; ++u) VAcc<T, VW>::gst(out + ((p + (unsigned)u * stride) * (unsigned)cgn + cg) * (unsigned)VW, o[u]);
   }
-  for (; p < n; p += stride) Act<T>::gst4(out + (p * (unsigned)c4n + c4) * 4u, finish(merge_load<T, MODE>(a, p, c)));
+  for (; p < n; p += stride) VAcc<T, VW>::gst(out + (p * (unsigned)cgn + cg) * (unsigned)VW, finish(merge_load<T, MODE, VW>(a, p, c)));
 }
 
 // backward pass 1: dsum = dout * prelu'(s); partial sums of dz = dsum*drop, dz*xhat3 and dout*min(s,0)
-template <typename T, int MODE>
+template <typename T, int MODE, int VW>
 __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __restrict__ dout,
-                                                        T* __restrict__ dsum, int64_t npix, int c4n,
+                                                        T* __restrict__ dsum, int64_t npix, int cgn,
                                                         float* __restrict__ part) {
-  __shared__ f32x4 sm[3 * 256];
-  const int ppi = 256 / c4n;
-  const int c4 = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+  typedef fvec<VW> V;
+  constexpr int NP = VW == 8 ? 2 : 4;      // pixels per round: 16-byte accesses carry twice the elements, half the pixels keep the registers
+  __shared__ f32x4 sm[3 * (VW / 4) * 256];
+  const int ppi = 256 / cgn;
+  const int cg = threadIdx.x % cgn, pl = threadIdx.x / cgn;
   const bool active = pl < ppi;
-  const int c = c4 * 4;
-  f32x4 v[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const int c = cg * VW;
+  V v[3] = {fsplat<VW>(0.f), fsplat<VW>(0.f), fsplat<VW>(0.f)};
   if (active) {
-    const f32x4 al = ld4(a.alpha + c);
-    const MergeParams q = merge_params<MODE>(a, c);
-    auto accumulate = [&](const MergeRaw<T, MODE>& r, const f32x4& d, f32x4& ds) {
-      f32x4 xh3;
-      const f32x4 s = merge_sum<T, MODE>(q, r, xh3);
+    const V al = ldp<VW>(a.alpha + c);
+    const MergeParams<VW> q = merge_params<MODE, VW>(a, c);
+    auto accumulate = [&](const MergeRaw<VW>& r, const V& d, V& ds) {
+      V xh3;
+      const V s = merge_sum<MODE, VW>(q, r, xh3);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < VW; ++j) {
         ds[j] = d[j] * (s[j] > 0.f ? 1.f : (s[j] < 0.f ? al[j] : 0.f));
         const float dz = ds[j] * r.dropv[j];
         v[0][j] += dz;
@@ -497,55 +617,53 @@ __global__ __launch_bounds__(256) void merge_bwd_reduce(MergeArgs a, const T* __
     unsigned p = blockIdx.x * (unsigned)ppi + (unsigned)pl;
     // four pixels per round: all their loads are issued before the first result is stored (a one-pixel loop costs one
     // memory round trip per pixel and leaves the launch far below the bandwidth its 512 workgroups could draw)
-    for (; (uint64_t)p + 3ull * stride < (uint64_t)npix; p += 4u * stride) {
-      MergeRaw<T, MODE> r[4];
-      f32x4 d[4], ds[4];
+    for (; (uint64_t)p + (uint64_t)(NP - 1) * stride < (uint64_t)npix; p += (unsigned)NP * stride) {
+      MergeRaw<VW> r[NP];
+      V d[NP], ds[NP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < NP; ++u) {
         const unsigned pu = p + (unsigned)u * stride;
-        r[u] = merge_load<T, MODE>(a, pu, c);
-        d[u] = Act<T>::gld4(dout + (pu * (unsigned)c4n + (unsigned)c4) * 4u);
+        r[u] = merge_load<T, MODE, VW>(a, pu, c);
+        d[u] = VAcc<T, VW>::gld(dout + (pu * (unsigned)cgn + (unsigned)cg) * (unsigned)VW);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) accumulate(r[u], d[u], ds[u]);
+      for (int u = 0; u < NP; ++u) accumulate(r[u], d[u], ds[u]);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) Act<T>::gst4(dsum + ((p + (unsigned)u * stride) * (unsigned)c4n + (unsigned)c4) * 4u, ds[u]);
+      for (int u = 0; u < NP; ++u) VAcc<T, VW>::gst(dsum + ((p + (unsigned)u * stride) * (unsigned)cgn + (unsigned)cg) * (unsigned)VW, ds[u]);
     }
     for (; p < (unsigned)npix; p += stride) {
-      f32x4 ds;
-      const MergeRaw<T, MODE> r = merge_load<T, MODE>(a, p, c);
-      const f32x4 d = Act<T>::gld4(dout + (p * (unsigned)c4n + (unsigned)c4) * 4u);
+      V ds;
+      const MergeRaw<VW> r = merge_load<T, MODE, VW>(a, p, c);
+      const V d = VAcc<T, VW>::gld(dout + (p * (unsigned)cgn + (unsigned)cg) * (unsigned)VW);
       accumulate(r, d, ds);
-      Act<T>::gst4(dsum + (p * (unsigned)c4n + (unsigned)c4) * 4u, ds);
+      VAcc<T, VW>::gst(dsum + (p * (unsigned)cgn + (unsigned)cg) * (unsigned)VW, ds);
     }
   }
-  block_reduce_groups<3>(v, sm, c4n, ppi, active);
-  if (threadIdx.x < c4n) {
-    const int cc = c4n * 4;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) st4(part + ((int64_t)blockIdx.x * 3 + k) * cc + threadIdx.x * 4, v[k]);
-  }
+  block_reduce_v<3, VW>(v, sm, cgn, ppi, active);
+  if (threadIdx.x < cgn) store_partial_rows<3, VW>(v, part, cgn);
 }
 
 // backward pass 2: dmain = gamma3*invstd3 * (dsum*drop - mean(dz) - xhat3*mean(dz*xhat3))
-template <typename T>
+template <typename T, int VW>
 __global__ __launch_bounds__(256) void merge_bwd_apply(const T* __restrict__ dsum, const T* __restrict__ main,
                                                        const float* __restrict__ mean3, const float* __restrict__ invstd3,
                                                        const float* __restrict__ drop, const float* __restrict__ coef,
-                                                       T* __restrict__ dmain, int64_t npix, int c4n, int64_t hw) {
-  const int cc = c4n * 4;
-  const unsigned ppi = 256u / (unsigned)c4n;
-  const unsigned c4 = threadIdx.x % (unsigned)c4n, pl = threadIdx.x / (unsigned)c4n;
+                                                       T* __restrict__ dmain, int64_t npix, int cgn, int64_t hw) {
+  typedef fvec<VW> V;
+  constexpr int NP = VW == 8 ? 2 : 4;      // pixels per round: 16-byte accesses carry twice the elements, half the pixels keep the registers
+  const int cc = cgn * VW;
+  const unsigned ppi = 256u / (unsigned)cgn;
+  const unsigned cg = threadIdx.x % (unsigned)cgn, pl = threadIdx.x / (unsigned)cgn;
   if (pl >= ppi) return;
-  const int c = (int)c4 * 4;
-  const f32x4 m = ld4(mean3 + c), is = ld4(invstd3 + c);
-  const f32x4 k1 = ld4(coef + c), m1 = ld4(coef + cc + c), m2 = ld4(coef + 2 * cc + c);
-  auto one = [&](const f32x4& ds, const f32x4& mv, unsigned p) {
-    f32x4 dv = {1.f, 1.f, 1.f, 1.f};
-    if (drop) dv = ld4(drop + (p / (unsigned)hw) * (unsigned)cc + c);
-    f32x4 o;
+  const int c = (int)cg * VW;
+  const V m = ldp<VW>(mean3 + c), is = ldp<VW>(invstd3 + c);
+  const V k1 = ldp<VW>(coef + c), m1 = ldp<VW>(coef + cc + c), m2 = ldp<VW>(coef + 2 * cc + c);
+  auto one = [&](const V& ds, const V& mv, unsigned p) {
+    V dv = fsplat<VW>(1.f);
+    if (drop) dv = ldp<VW>(drop + (p / (unsigned)hw) * (unsigned)cc + c);
+    V o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < VW; ++j) {
       const float xh = (mv[j] - m[j]) * is[j];
       o[j] = k1[j] * (ds[j] * dv[j] - m1[j] - xh * m2[j]);
     }
@@ -553,22 +671,22 @@ __global__ __launch_bounds__(256) void merge_bwd_apply(const T* __restrict__ dsu
   };
   const unsigned stride = gridDim.x * ppi, n = (unsigned)npix;
   unsigned p = blockIdx.x * ppi + pl;
-  for (; (uint64_t)p + 3ull * stride < (uint64_t)n; p += 4u * stride) {
-    f32x4 ds[4], mv[4];
+  for (; (uint64_t)p + (uint64_t)(NP - 1) * stride < (uint64_t)n; p += (unsigned)NP * stride) {
+    V ds[NP], mv[NP];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const unsigned e = ((p + (unsigned)u * stride) * (unsigned)c4n + c4) * 4u;
-      ds[u] = Act<T>::gld4(dsum + e);
-      mv[u] = Act<T>::gld4(main + e);
+    for (int u = 0; u < NP; ++u) {
+      const unsigned e = ((p + (unsigned)u * stride) * (unsigned)cgn + cg) * (unsigned)VW;
+      ds[u] = VAcc<T, VW>::gld(dsum + e);
+      mv[u] = VAcc<T, VW>::gld(main + e);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ds[u] = one(ds[u], mv[u], p + (unsigned)u * stride);
+    for (int u = 0; u < NP; ++u) ds[u] = one(ds[u], mv[u], p + (unsigned)u * stride);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Act<T>::gst4(dmain + ((p + (unsigned)u * stride) * (unsigned)c4n + c4) * 4u, ds[u]);
+    for (int u = 0; u < NP; ++u) VAcc<T, VW>::gst(dmain + ((p + (unsigned)u * stride) * (unsigned)cgn + cg) * (unsigned)VW, ds[u]);
   }
   for (; p < n; p += stride) {
-    const unsigned e = (p * (unsigned)c4n + c4) * 4u;
-    Act<T>::gst4(dmain + e, one(Act<T>::gld4(dsum + e), Act<T>::gld4(main + e), p));
+    const unsigned e = (p * (unsigned)cgn + cg) * (unsigned)VW;
+    VAcc<T, VW>::gst(dmain + e, one(VAcc<T, VW>::gld(dsum + e), VAcc<T, VW>::gld(main + e), p));
   }
 }
 
@@ -617,9 +735,9 @@ static ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64
 }
 
 // grid of the pixel-strided elementwise kernels: one round of four pixels per thread, at most 4096 workgroups
-static inline int ew_blocks_px(int64_t npix, int c4n) {
+static inline int ew_blocks_px(int64_t npix, int c4n, int px_per_thread = 4) {
   const int ppi = 256 / c4n;
-  int64_t b = ceil_div64(npix, (int64_t)ppi * 4);
+  int64_t b = ceil_div64(npix, (int64_t)ppi * px_per_thread);
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
@@ -630,6 +748,22 @@ static inline int ew_blocks(int64_t total4) {
   if (b > 4096) b = 4096;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// bfloat16 tensors with at least 64 channels take eight elements (16 bytes) per access in the passes that only map
+// elements (BN apply forward / backward, merge forward, merge backward apply) where every pixel stride and base address
+// allows it; everything else takes four.  Measured alone, ENet 512x512 batch 16, 8 against 4 elements per access: merge
+// backward apply 16.3 / 18.1 us, merge forward 15.8 / 16.6, BN passes over 16 / 32 channels 6.4 / 5.9 (worse: fewer
+// threads per pixel row), the reducing passes 20.2 / 18.5 (worse); SegNet's BN passes over 64-512 channels gain 1 % of its
+// step.  These launches run at the memory system's rate plus a fixed 2-3 us either way; the access width is not their
+// limit.  The reducing passes stay at four also because their summation order must equal the float32 kernels'.
+template <typename T>
+static inline bool wide8(int c, int ld_a, int ld_b, std::initializer_list<const void*> ptrs) {
+  static const bool off = getenv("SSMI_NO_BF16_WIDE8") != nullptr;      // measurement switch
+  if (sizeof(T) != 2 || off || c < 64 || c % 8 != 0 || ld_a % 8 != 0 || ld_b % 8 != 0 || 256 % (c / 8) != 0) return false;
+  for (const void* q : ptrs)
+    if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+  return true;
 }
 
 static ssmi_status check_c(int c, const char* who) {
@@ -645,11 +779,14 @@ ssmi_status launch_bn_bwd_tail(const float* part, int rows, const T* dy, int ld_
   ssmi_status e = launch_bn_bwd_final(part, rows, c, npix, gamma, invstd, dgamma, dbeta,
                                       act == SSMI_ACT_PRELU ? dalpha : nullptr, coef, st);
   if (e) return e;
-  const int c4n = c / 4;
-  const int nb2 = ew_blocks_px(npix, c4n);
-#define L2(A) hipLaunchKernelGGL((bn_act_bwd_apply<T, A>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, npix, c4n)
+  const bool w8 = wide8<T>(c, ld_x, ld_dy, {dy, x, dx, mean, invstd, gamma, beta, coef, alpha, drop});
+  const int cgn = c / (w8 ? 8 : 4);
+  const int nb2 = ew_blocks_px(npix, cgn, w8 ? 2 : 4);
+#define L2V(A, VW) hipLaunchKernelGGL((bn_act_bwd_apply<T, A, VW>), dim3(nb2), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, coef, dx, npix, cgn)
+#define L2(A) do { if constexpr (sizeof(T) == 2) { if (w8) { L2V(A, 8); break; } } L2V(A, 4); } while (0)
   if (act == SSMI_ACT_NONE) L2(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L2(SSMI_ACT_PRELU); else L2(SSMI_ACT_LEAKY);
 #undef L2
+#undef L2V
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
@@ -749,12 +886,15 @@ static ssmi_status bn_act_drop_fwd_impl(const T* x, int32_t ld_x, const float* m
   SSMI_REQUIRE(!drop || (hw > 0 && npix % hw == 0), SSMI_E_SHAPE, "bn_act_fwd: npix must be a multiple of hw");
   SSMI_REQUIRE(npix * ld_x * 4 < 0x7FFFFFFFLL && npix * ld_y * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED,
                "bn_act_fwd: tensors of 2^29 elements or more are not supported");
-  const int c4n = c / 4;
-  const int nb = ew_blocks_px(npix, c4n);
-#define L(A) hipLaunchKernelGGL((bn_act_fwd_kernel<T, A>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, npix, c4n)
+  const bool w8 = wide8<T>(c, ld_x, ld_y, {x, y, mean, invstd, gamma, beta, alpha, drop});
+  const int cgn = c / (w8 ? 8 : 4);
+  const int nb = ew_blocks_px(npix, cgn, w8 ? 2 : 4);
+#define LV(A, VW) hipLaunchKernelGGL((bn_act_fwd_kernel<T, A, VW>), dim3(nb), dim3(256), 0, as_stream(stream), x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, y, ld_y, npix, cgn)
+#define L(A) do { if constexpr (sizeof(T) == 2) { if (w8) { LV(A, 8); break; } } LV(A, 4); } while (0)
   if (act == SSMI_ACT_NONE) L(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L(SSMI_ACT_LEAKY);
   else { set_error("bn_act_fwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L
+#undef LV
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
@@ -774,12 +914,13 @@ ssmi_status bn_act_drop_bwd_impl(const T* dy, int32_t ld_dy, const T* x, int32_t
                "bn_act_bwd: tensors of 2^29 elements or more are not supported");
   SSMI_REQUIRE(act != SSMI_ACT_PRELU || alpha, SSMI_E_INVALID_ARG, "bn_act_bwd: PReLU needs alpha");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_bn_workspace_bytes(npix, c), SSMI_E_WORKSPACE, "bn_act_bwd: workspace too small");
-  const int c4n = c / 4;
-  const int nb = red_blocks(npix, c4n);
   float* part = reinterpret_cast<float*>(ws);
   float* coef = part + (size_t)kMaxRedBlocks * 3 * c;
+  const bool w8 = false;      // reducing pass: four elements per access (summation order of the float32 kernel)
+  const int cgn = c / (w8 ? 8 : 4);
+  const int nb = red_blocks(npix, cgn);
   hipStream_t st = as_stream(stream);
-#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<T, A>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, npix, c4n, part)
+#define L1(A) hipLaunchKernelGGL((bn_act_bwd_reduce<T, A, 4>), dim3(nb), dim3(256), 0, st, dy, x, ld_x, mean, invstd, gamma, beta, alpha, slope, drop, hw, ld_dy, npix, cgn, part)
   if (act == SSMI_ACT_NONE) L1(SSMI_ACT_NONE); else if (act == SSMI_ACT_PRELU) L1(SSMI_ACT_PRELU); else if (act == SSMI_ACT_LEAKY) L1(SSMI_ACT_LEAKY);
   else { set_error("bn_act_bwd: unknown activation %d", act); return SSMI_E_INVALID_ARG; }
 #undef L1
@@ -821,14 +962,28 @@ static ssmi_status fill_merge(const ssmi_merge_desc* d, const void* main, const 
   return SSMI_OK;
 }
 
+// eight-element accesses for a bfloat16 merge: every tensor and parameter vector it touches must allow them
+template <typename T>
+static inline bool merge_wide8(const ssmi_merge_desc* d, const MergeArgs& a, std::initializer_list<const void*> more) {
+  if (!wide8<T>(d->c, d->other_mode == 1 ? d->c_other : d->c, d->c,
+                {a.main, a.other, a.mean3, a.invstd3, a.gamma3, a.beta3, a.drop, a.mean_o, a.invstd_o, a.gamma_o, a.beta_o, a.idx, a.alpha}))
+    return false;
+  for (const void* q : more)
+    if (reinterpret_cast<uintptr_t>(q) & 15) return false;
+  return true;
+}
+
 template <typename T>
 static ssmi_status merge_fwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, T* out, void* stream) {
-  const int c4n = d->c / 4;
+  const bool w8 = merge_wide8<T>(d, a, {out});
+  const int cgn = d->c / (w8 ? 8 : 4);
   const int64_t npix = (int64_t)d->n * d->h * d->w;
-  const int nb = ew_blocks_px(npix, c4n);
-#define L(M) hipLaunchKernelGGL((merge_fwd_kernel<T, M>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, npix, c4n)
+  const int nb = ew_blocks_px(npix, cgn, w8 ? 2 : 4);
+#define LV(M, VW) hipLaunchKernelGGL((merge_fwd_kernel<T, M, VW>), dim3(nb), dim3(256), 0, as_stream(stream), a, out, npix, cgn)
+#define L(M) do { if constexpr (sizeof(T) == 2) { if (w8) { LV(M, 8); break; } } LV(M, 4); } while (0)
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
+#undef LV
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;
 }
@@ -842,18 +997,29 @@ static ssmi_status merge_bwd_impl(const ssmi_merge_desc* d, const MergeArgs& a, 
   hipStream_t st = as_stream(stream);
   const int c = d->c, c4n = c / 4;
   const int64_t npix = (int64_t)d->n * d->h * d->w;
-  const int nb = red_blocks(npix, c4n);
   float* part = reinterpret_cast<float*>(ws);
   float* coef = coef_out ? coef_out : part + (size_t)kMaxRedBlocks * 3 * c;
-#define L(M) hipLaunchKernelGGL((merge_bwd_reduce<T, M>), dim3(nb), dim3(256), 0, st, a, dout, dsum, npix, c4n, part)
+  const bool w8 = merge_wide8<T>(d, a, {dsum, dmain, coef});      // for the apply pass; the reducing pass takes four
+  const int cgn = c / (w8 ? 8 : 4);
+  const int nb = red_blocks(npix, c4n);
+#define L(M) hipLaunchKernelGGL((merge_bwd_reduce<T, M, 4>), dim3(nb), dim3(256), 0, st, a, dout, dsum, npix, c4n, part)
   switch (d->other_mode) { case 0: L(0); break; case 1: L(1); break; case 2: L(2); break; default: L(3); break; }
 #undef L
   SSMI_LAUNCH_CHECK();
   ssmi_status s = launch_bn_bwd_final(part, nb, c, npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
   if (s) return s;
   if (!coef_out) {
-    hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main), bn3->mean,
-                       bn3->invstd, drop, coef, dmain, npix, c4n, (int64_t)d->h * d->w);
+    bool done = false;
+    if constexpr (sizeof(T) == 2) {
+      if (w8) {
+        hipLaunchKernelGGL((merge_bwd_apply<T, 8>), dim3(ew_blocks_px(npix, cgn, 2)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main),
+                           bn3->mean, bn3->invstd, drop, coef, dmain, npix, cgn, (int64_t)d->h * d->w);
+        done = true;
+      }
+    }
+    if (!done)
+      hipLaunchKernelGGL((merge_bwd_apply<T, 4>), dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, st, dsum, static_cast<const T*>(a.main),
+                         bn3->mean, bn3->invstd, drop, coef, dmain, npix, c4n, (int64_t)d->h * d->w);
     SSMI_LAUNCH_CHECK();
   }
   if (d->other_mode >= 2) {
@@ -989,7 +1155,7 @@ ssmi_status ssmi_merge_bwd_apply(const ssmi_merge_desc* d, const void* dsum, con
   const int64_t npix = (int64_t)d->n * d->h * d->w;
   return dispatch_dtype(d->dtype, [&](auto tag) {
     using T = decltype(tag);
-    hipLaunchKernelGGL(merge_bwd_apply<T>, dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, as_stream(stream), static_cast<const T*>(dsum),
+    hipLaunchKernelGGL((merge_bwd_apply<T, 4>), dim3(ew_blocks_px(npix, c4n)), dim3(256), 0, as_stream(stream), static_cast<const T*>(dsum),
                        static_cast<const T*>(main), bn3->mean, bn3->invstd, drop, coef, static_cast<T*>(dmain), npix, c4n,
                        (int64_t)d->h * d->w);
     SSMI_LAUNCH_CHECK();
