@@ -85,6 +85,15 @@ struct BnBwdArgs {
   unsigned pm_hw;
 };
 
+// LDS-tiled bfloat16 implicit GEMM for wide 3x3 / stride-1 / SAME layers (conv_tiled.hip).  _ok: whether the layer shape
+// qualifies; the launcher returns SSMI_E_UNSUPPORTED (nothing launched, no error text) for an epilogue or alignment it does
+// not take, and the caller then uses the direct kernel.  part != nullptr: BatchNormalization statistics rows
+// part[tile][2][cout]; bn.x / bn.add: data-gradient epilogue with rows bn.part[tile][3][cout]; *part_rows = pixel tiles.
+bool conv_tiled_bf16_ok(int h, int w, int cin, int cout, int kh, int kw, int stride, int dil, int pad_t, int pad_l, int ho, int wo,
+                        int x_ld, int y_ld);
+ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x, const void* wpack,
+                                   const float* bias, void* y, float* part, int* part_rows, const BnBwdArgs& bn, hipStream_t st);
+
 // Per-channel parameters of a BatchNormalization + PReLU whose output a kernel forms on the fly from the raw tensor
 // (PRE instantiations of conv_fwd_kernel / conv_bwd_weight_lds); same arithmetic as bn_act_fwd_kernel.
 struct PreBn {

@@ -2505,6 +2505,14 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   }
   const bool pre = bn.pre[0] != nullptr;
   if (pre) direct_only = true;
+  if constexpr (sizeof(T) == 2) {
+    if (bn.wpack && !pre && bn.pm_main == nullptr &&
+        conv_tiled_bf16_ok(g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.stride, g.dil, g.pad_t, g.pad_l, g.ho, g.wo, g.x_ld, g.y_ld)) {
+      const ssmi_status te = launch_conv_tiled_bf16(g.n, g.h, g.w, g.cin, g.cout, g.x_ld, g.y_ld, x, bn.wpack, bias, y, part, part_rows, bn, st);
+      if (te == SSMI_OK) set_last_kernel("conv3x3_tiled_bf16<%d>", g.cout % 128 == 0 ? 128 : 64);
+      if (te != SSMI_E_UNSUPPORTED) return te;
+    }
+  }
   if (!direct_only && launch_gemm_lds<T>(g, sz, 0, x, w, bias, (const T*)nullptr, y, st, &e, part, part_rows, bn)) return e;
   if (part_rows) *part_rows = (int)ceil_div64((int64_t)g.n * g.ho * g.wo, 128);
   const int64_t M = (int64_t)g.n * g.ho * g.wo;

@@ -1,0 +1,384 @@
+// LDS-tiled implicit GEMM for the wide 3x3 layers of U-Net / SegNet with bfloat16 storage (stride 1, dilation 1, SAME
+// padding, input channels in whole 32-blocks, output channels in whole 64-blocks, height and width multiples of 16):
+//   y[p, co] = bias[co] + sum_{tap, ci} x[pix(p, tap), ci] * w[tap, ci, co]      on v_mfma_f32_32x32x16_bf16.
+// Both operands go through LDS.  A workgroup (256 threads, four waves) owns a 16 x 16 tile of output pixels of one image and
+// BN = 128 or 64 output channels.  For every 32-channel chunk of the input it stages the tile's 18 x 18 halo patch ONCE
+// (80-byte pixel rows: 64 bytes of channels + 16 of padding against bank conflicts) and then walks the nine taps: a tap only
+// shifts the window the A fragments are read from, so the nine taps re-read LDS, not L2.  The kernel rows of a step
+// (tap, chunk) - [BN couts][32 channels] from the pack [tap][cout][cin] - are staged in a second, double-buffered area, the
+// next step's rows (and, once per chunk, the next patch) in flight in registers while the current step is multiplied.
+// Waves split the tile 2 x 2 (BN = 128: 128 pixels x 64 couts each, 8 accumulator tiles) or 4 x 1 (BN = 64: 64 x 64 each),
+// which keeps LDS reads per matrix instruction at 0.75 - 1 ds_read_b128.
+// Epilogue: the accumulators go through LDS once more (float32, 64 pixels per pass) so that bias, rounding, the stores and
+// the fused reductions run in the elementwise layout - a thread owns eight consecutive channels of a pixel, 16-byte accesses:
+//   EPI 1  BatchNormalization statistics: per-workgroup column sums of y and y^2 (unrounded) -> part[tile][2][cout]
+//   EPI 2  data-gradient form (forward convolution over dy with the data-gradient pack) with the BatchNormalization
+//          backward sums of the layer in front (dz, dz * xhat, d * min(z, 0)) -> bn.part[tile][3][cout]
+//   EPI 3  data-gradient form with a skip-gradient addend (and the sums of EPI 2 when bn.x is given)
+// The same arithmetic as conv_fwd_kernel's epilogues, summed in a different (fixed) order.
+#include "common.h"
+
+namespace ssmi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int kTH = 16, kTW = 16, kPW = kTW + 2, kPH = kTH + 2;
+static constexpr int kPatchPix = kPH * kPW;        // 324
+static constexpr int kRowB = 80;                    // bytes per staged pixel / kernel row
+static constexpr int kABytes = kPatchPix * kRowB;   // 25920
+
+struct TiledArgs {
+  int n, h, w, cin, cout, x_ld, y_ld;
+  const bf16* x;
+  const bf16* wpack;      // [9][cout][cin]
+  const float* bias;
+  bf16* y;
+  float* part;            // EPI 1
+  BnBwdArgs bn;           // EPI 2: add, x, ld, mean, invstd, gamma, beta, alpha, slope, act, drop, hw, part
+};
+
+__device__ __forceinline__ unsigned spread_over_xcds(unsigned b, unsigned n) {      // a bijection of [0, n) for any n
+  const unsigned q = n >> 3, r = n & 7u, x = b & 7u;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+// CW consecutive bfloat16 channels of one pixel as they travel between HBM and registers in the epilogue
+template <int CW> struct Row;
+template <> struct Row<8> {
+  typedef u32x4 raw;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); }
+  static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned off, raw v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0); }
+};
+template <> struct Row<4> {
+  typedef u32x2 raw;
+  static __device__ __forceinline__ raw ld(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0)); }
+  static __device__ __forceinline__ void st(__amdgpu_buffer_rsrc_t r, unsigned off, raw v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, off, 0, 0); }
+};
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+template <int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(TiledArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* const As = smem;
+  unsigned char* const Bs = smem + kABytes;          // two buffers of BN * kRowB bytes
+  constexpr int kBBytes = BN * kRowB;
+  constexpr int WPX = 256 / WM;                       // pixels per wave
+  constexpr int MT = WPX / 32, NTL = BN / WN / 32;
+  static_assert(WM * WN == 4 && MT >= 1 && NTL >= 1, "wave layout");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // tile coordinates
+  const int tiles_x = a.w / kTW, tiles_y = a.h / kTH;
+  const int ncb = a.cout / BN;
+  // The workgroups of one XCD (b and b + 8 share one, and its L2) take a contiguous range of (tile, column block) pairs,
+  // column block fastest: the column blocks of a tile re-read its patch from that L2, neighbouring tiles share halo rows.
+  const unsigned v = spread_over_xcds(blockIdx.x, gridDim.x);
+  const int t = (int)(v / (unsigned)ncb);
+  const int img = t / (tiles_x * tiles_y);
+  const int trem = t - img * (tiles_x * tiles_y);
+  const int y0 = (trem / tiles_x) * kTH, x0 = (trem % tiles_x) * kTW;
+  const int n0 = (int)(v % (unsigned)ncb) * BN;
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((int64_t)a.n * a.h * a.w * a.x_ld * 2));
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)((int64_t)9 * a.cout * a.cin * 2));
+
+  // staging roles.  Patch: 324 pixels x four 16-byte pieces = 1296 pieces, six rounds of 256 threads (the last one partial)
+  constexpr int ARND = (kPatchPix * 4 + 255) / 256;
+  unsigned ag[ARND], al[ARND];
+#pragma unroll
+  for (int j = 0; j < ARND; ++j) {
+    const int idx = tid + 256 * j;
+    const int pix = idx >> 2, piece = idx & 3;
+    const int py = pix / kPW, px = pix - py * kPW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = pix < kPatchPix && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+    ag[j] = ok ? (unsigned)(((img * a.h + iy) * a.w + ix) * a.x_ld) * 2u + (unsigned)piece * 16u : kOOB;
+    al[j] = pix < kPatchPix ? (unsigned)(pix * kRowB + piece * 16) : 0xFFFFFFFFu;      // no LDS slot: skipped at the commit
+  }
+  constexpr int BRND = BN / 64;                      // kernel rows: BN x four pieces / 256 threads
+  unsigned bg[BRND], bl[BRND];
+#pragma unroll
+  for (int j = 0; j < BRND; ++j) {
+    const int idx = tid + 256 * j;
+    const int row = idx >> 2, piece = idx & 3;
+    bg[j] = (unsigned)((n0 + row) * a.cin) * 2u + (unsigned)piece * 16u;
+    bl[j] = (unsigned)(row * kRowB + piece * 16);
+  }
+  const unsigned tap_stride = (unsigned)(a.cout * a.cin) * 2u;      // bytes between taps in the pack
+
+  // fragment addresses
+  unsigned abase[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int pm = wm * WPX + m * 32 + r;
+    abase[m] = (unsigned)(((pm >> 4) * kPW + (pm & 15)) * kRowB + hh * 16);
+  }
+  unsigned bbase[NTL];
+#pragma unroll
+  for (int q = 0; q < NTL; ++q) bbase[q] = (unsigned)((wn * (BN / WN) + q * 32 + r) * kRowB + hh * 16);
+
+  f32x16 acc[MT][NTL];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int q = 0; q < NTL; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
+
+  const int nchunks = a.cin >> 5;
+  u32x4 areg[ARND], breg[3][BRND];
+  auto load_a = [&](int chunk) {
+#pragma unroll
+    for (int j = 0; j < ARND; ++j)
+      areg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (ag[j] + (unsigned)chunk * 64u) | (ag[j] & kOOB), 0, 0));
+  };
+  auto commit_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < ARND; ++j)
+      if (al[j] != 0xFFFFFFFFu) *reinterpret_cast<u32x4*>(As + al[j]) = areg[j];
+  };
+  // The kernel rows of a step come out of L2 with more latency than a step of matrix work takes: they are requested three
+  // steps ahead into a ring of three register sets (slot = tap % 3; nine taps per chunk keep the slots aligned over chunks).
+  auto load_b = [&](int slot, int tap, int chunk) {
+    const unsigned oob = chunk < nchunks ? 0u : kOOB;      // past the last step: zeros nobody multiplies
+#pragma unroll
+    for (int j = 0; j < BRND; ++j)
+      breg[slot][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (bg[j] + (unsigned)tap * tap_stride + (unsigned)chunk * 64u) | oob, 0, 0));
+  };
+  auto commit_b = [&](int slot, int buf) {
+#pragma unroll
+    for (int j = 0; j < BRND; ++j) *reinterpret_cast<u32x4*>(Bs + buf * kBBytes + bl[j]) = breg[slot][j];
+  };
+
+  load_a(0);
+  load_b(0, 0, 0);
+  load_b(1, 1, 0);
+  load_b(2, 2, 0);
+  commit_a();
+  commit_b(0, 0);
+  __syncthreads();
+
+  int buf = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const bool more = chunk + 1 < nchunks;
+    if (more) load_a(chunk + 1);                      // in flight under the nine taps of this chunk
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool last = tap == 8;
+      load_b(tap % 3, (tap + 3) % 9, chunk + (tap + 3) / 9);      // this slot's rows went to LDS at the end of the previous step
+      const unsigned toff = (unsigned)(((tap / 3) * kPW + (tap % 3)) * kRowB);
+      const unsigned char* bsrc = Bs + buf * kBBytes;
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        bf16x8 af[MT], bfr[NTL];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[m] = lds_frag(As + abase[m] + toff + k2 * 32);
+#pragma unroll
+        for (int q = 0; q < NTL; ++q) bfr[q] = lds_frag(bsrc + bbase[q] + k2 * 32);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+          for (int q = 0; q < NTL; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[q], acc[m][q], 0, 0, 0);
+      }
+      commit_b((tap + 1) % 3, buf ^ 1);               // the next step's rows into the buffer nobody reads during this step
+      if (last && more) {
+        __syncthreads();                              // every wave is done with this chunk's patch
+        commit_a();
+      }
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue through LDS: 64 pixels per pass, float32 rows of BN values + 16 bytes of padding ----
+  constexpr int SROW = BN * 4 + 16;
+  constexpr int CW = 4;                             // channels per thread (8-byte accesses; eight would cost ~40 more registers)
+  constexpr int G = BN / CW;                          // channel groups
+  constexpr int PL = 256 / G;                         // pixel lanes
+  constexpr int ITEMS = 64 / PL;
+  constexpr bool kDgrad = EPI >= 2, kAdd = EPI == 3;
+  constexpr int NS = kDgrad ? 3 : 2;
+  const int cg = tid % G, pl = tid / G;
+  const int co = n0 + cg * CW;
+  float bv[CW];
+#pragma unroll
+  for (int e = 0; e < CW; ++e) bv[e] = a.bias ? a.bias[co + e] : 0.f;
+  float sums[NS][CW];
+#pragma unroll
+  for (int k = 0; k < NS; ++k)
+#pragma unroll
+    for (int e = 0; e < CW; ++e) sums[k][e] = 0.f;
+  const bool has_bn = kDgrad && a.bn.x != nullptr;
+  float mu[CW], is[CW], ga[CW], be[CW], alp[CW];
+  if constexpr (kDgrad) {
+    if (has_bn) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) {
+        mu[e] = a.bn.mean[co + e]; is[e] = a.bn.invstd[co + e]; ga[e] = a.bn.gamma[co + e]; be[e] = a.bn.beta[co + e];
+        alp[e] = a.bn.act == SSMI_ACT_PRELU ? a.bn.alpha[co + e] : a.bn.slope;
+      }
+    }
+  }
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, (unsigned)((int64_t)a.n * a.h * a.w * a.y_ld * 2));
+  const bool has_add = kAdd && a.bn.add != nullptr;
+  const __amdgpu_buffer_rsrc_t radd = make_rsrc(has_add ? a.bn.add : (const void*)a.y, has_add ? (unsigned)((int64_t)a.n * a.h * a.w * a.y_ld * 2) : 0u);
+  const __amdgpu_buffer_rsrc_t rbx = make_rsrc(has_bn ? a.bn.x : (const void*)a.y, has_bn ? (unsigned)((int64_t)a.n * a.h * a.w * a.bn.ld * 2) : 0u);
+  auto pixel_of = [&](int q, int j) {                 // global pixel index of item j of pass q
+    const int tp = 64 * q + pl + j * PL;
+    return (unsigned)((img * a.h + y0 + (tp >> 4)) * a.w + x0 + (tp & 15));
+  };
+  // what the data-gradient epilogue reads per element is requested one pass ahead (two register sets): the wait for it
+  // would otherwise be paid four times per tile
+  typename Row<CW>::raw xin[2][kDgrad ? ITEMS : 1], ain[2][kAdd ? ITEMS : 1];
+  auto request = [&](int q) {
+    if constexpr (kDgrad) {
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const unsigned gp = pixel_of(q, j);
+        xin[q & 1][j] = Row<CW>::ld(rbx, (gp * (unsigned)a.bn.ld + (unsigned)co) * 2u);
+        if constexpr (kAdd) ain[q & 1][j] = Row<CW>::ld(radd, (gp * (unsigned)a.y_ld + (unsigned)co) * 2u);
+      }
+    }
+  };
+  request(0);
+
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (q > 0) __syncthreads();                       // the previous pass has been read (pass 0: the loop ended on a barrier)
+    if (wm == (64 * q) / WPX) {
+      const int mt0 = ((64 * q) % WPX) / 32;
+#pragma unroll
+      for (int m2 = 0; m2 < 2; ++m2) {
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+          const int col = wn * (BN / WN) + nt * 32 + r;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const int row = m2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            *reinterpret_cast<float*>(smem + row * SROW + col * 4) = acc[mt0 + m2][nt][i];      // constant index once unrolled
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (q < 3) request(q + 1);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+      const int lp = pl + j * PL;                     // pixel of this pass
+      const unsigned gp = pixel_of(q, j);
+      float v[CW];
+#pragma unroll
+      for (int e4 = 0; e4 < CW / 4; ++e4) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(smem + lp * SROW + cg * (CW * 4) + e4 * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e4 * 4 + e] = sv[e] + bv[e4 * 4 + e];
+      }
+      if constexpr (EPI == 1) {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+          sums[0][e] += v[e];
+          sums[1][e] += v[e] * v[e];
+        }
+      }
+      if constexpr (kDgrad) {
+        if constexpr (kAdd) {
+#pragma unroll
+          for (int e2 = 0; e2 < CW / 2; ++e2) {
+            const unsigned wa = ain[q & 1][j][e2];
+            v[2 * e2] += __builtin_bit_cast(float, wa << 16);
+            v[2 * e2 + 1] += __builtin_bit_cast(float, wa & 0xFFFF0000u);
+          }
+        }
+        if (has_bn) {
+          float dr[CW];
+#pragma unroll
+          for (int e = 0; e < CW; ++e) dr[e] = 1.f;
+          if (a.bn.drop) {
+            const float* dp = a.bn.drop + (size_t)(gp / a.bn.hw) * (unsigned)a.cout + (unsigned)co;
+#pragma unroll
+            for (int e = 0; e < CW; ++e) dr[e] = dp[e];
+          }
+#pragma unroll
+          for (int e = 0; e < CW; ++e) {
+            const unsigned wx = xin[q & 1][j][e >> 1];
+            const float xr = __builtin_bit_cast(float, (e & 1) ? (wx & 0xFFFF0000u) : (wx << 16));
+            const float d = v[e] * dr[e];
+            const float xh = (xr - mu[e]) * is[e];
+            const float z = ga[e] * xh + be[e];
+            const float gr = a.bn.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? alp[e] : 0.f));
+            const float dz = d * gr;
+            sums[0][e] += dz;
+            sums[1][e] += dz * xh;
+            sums[2][e] += d * (z < 0.f ? z : 0.f);
+          }
+        }
+      }
+      typename Row<CW>::raw o;
+#pragma unroll
+      for (int e2 = 0; e2 < CW / 2; ++e2) o[e2] = pack_bf16x2(v[2 * e2], v[2 * e2 + 1]);
+      Row<CW>::st(ry, (gp * (unsigned)a.y_ld + (unsigned)co) * 2u, o);
+    }
+  }
+  float* dst = EPI == 1 ? a.part : (has_bn ? a.bn.part : nullptr);
+  if (EPI != 0 && dst != nullptr) {                   // uniform
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);      // [NS][PL][BN]
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+#pragma unroll
+      for (int e = 0; e < CW; ++e) red[(k * PL + pl) * BN + cg * CW + e] = sums[k][e];
+    __syncthreads();
+    if (tid < BN) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float s = 0.f;
+        for (int p2 = 0; p2 < PL; ++p2) s += red[(k * PL + p2) * BN + tid];
+        dst[((int64_t)t * NS + k) * a.cout + n0 + tid] = s;
+      }
+    }
+  }
+}
+
+bool conv_tiled_bf16_ok(int h, int w, int cin, int cout, int kh, int kw, int stride, int dil, int pad_t, int pad_l, int ho, int wo,
+                        int x_ld, int y_ld) {
+  static const bool off = getenv("SSMI_NO_TILED_BF16") != nullptr;      // measurement switch
+  return !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h % kTH == 0 &&
+         w % kTW == 0 && cin % 32 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;
+}
+
+// Launches the tiled kernel.  part != nullptr: statistics epilogue; bn.add / bn.x: data-gradient epilogue.  *part_rows
+// receives the number of partial-sum rows (pixel tiles).  Returns SSMI_E_UNSUPPORTED for argument combinations it does not
+// take (the caller falls back to the direct kernel).
+ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x, const void* wpack,
+                                   const float* bias, void* y, float* part, int* part_rows, const BnBwdArgs& bn, hipStream_t st) {
+  if (bn.mean != nullptr && bn.x == nullptr) return SSMI_E_UNSUPPORTED;      // inference epilogue: not here
+  if (bn.x != nullptr && (bn.ld % 8 != 0 || (reinterpret_cast<uintptr_t>(bn.x) & 15))) return SSMI_E_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wpack) |
+       reinterpret_cast<uintptr_t>(bn.add)) & 15)
+    return SSMI_E_UNSUPPORTED;
+  if (part != nullptr && (bn.x != nullptr || bn.add != nullptr)) return SSMI_E_UNSUPPORTED;
+  TiledArgs a{};
+  a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout; a.x_ld = x_ld; a.y_ld = y_ld;
+  a.x = static_cast<const bf16*>(x); a.wpack = static_cast<const bf16*>(wpack); a.bias = bias; a.y = static_cast<bf16*>(y);
+  a.part = part; a.bn = bn;
+  const int tiles = n * (h / kTH) * (w / kTW);
+  if (part_rows) *part_rows = tiles;
+  const int epi = part ? 1 : (bn.add ? 3 : (bn.x ? 2 : 0));
+  const bool wide = cout % 128 == 0;
+  const int bn_cols = wide ? 128 : 64;
+  dim3 grid((unsigned)(tiles * (cout / bn_cols)), 1, 1);
+  const size_t lds = (size_t)kABytes + 2 * (size_t)bn_cols * kRowB;
+#define LT(BN_, WM_, WN_, E_)                                                                                                  \
+  do {                                                                                                                          \
+    auto kfn = conv3x3_tiled_bf16<BN_, WM_, WN_, E_>;                                                                           \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                                                       \
+  } while (0)
+  if (wide) { if (epi == 0) LT(128, 2, 2, 0); else if (epi == 1) LT(128, 2, 2, 1); else if (epi == 2) LT(128, 2, 2, 2); else LT(128, 2, 2, 3); }
+  else { if (epi == 0) LT(64, 4, 1, 0); else if (epi == 1) LT(64, 4, 1, 1); else if (epi == 2) LT(64, 4, 1, 2); else LT(64, 4, 1, 3); }
+#undef LT
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+}  // namespace ssmi

@@ -345,6 +345,115 @@ def test_conv2d_bf16_matrix_instruction_path(case):
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-5)
 
 
+TILED_CASES = [  # cin, cout, N, H, W: 3x3 / stride 1 / SAME layers the LDS-tiled bfloat16 kernel takes
+    (64, 64, 2, 16, 32), (64, 128, 1, 32, 16), (128, 256, 1, 16, 16), (256, 64, 1, 16, 32), (32, 192, 2, 16, 16), (96, 128, 1, 48, 16),
+]
+
+
+def _packed_conv(eng, L0, cin, cout, w, b, packed, N, H, W, st):
+    store = eng.ParamStore(torch.bfloat16)
+    cv = eng.Conv(store, "c", 3, 3, cin, cout, stride=1, dil=1, padding="same", bias=b is not None)
+    bn_out = eng.BatchNorm(store, "bn", cout)
+    bn_in = eng.BatchNorm(store, "bn_in", cin)
+    bn_in.add_prelu(store, "pr")
+    store.materialise(torch.device(DEV))
+    store.init_values(1)
+    cv.plan(N, H, W)
+    bn_out.plan(torch.device(DEV))
+    bn_in.plan(torch.device(DEV))
+    store.views["c/kernel"].copy_(torch.from_numpy(w if packed else _bf(w)))
+    if b is not None:
+        store.views["c/bias"].copy_(torch.from_numpy(b))
+    keep = []
+    if packed:
+        usage = int(store.L.conv2d_pack_usage(cv._dref))
+        assert usage & 3 == 3
+        sp = store.specs["c/kernel"]
+        fp = torch.zeros(2 * store.theta.numel(), dtype=torch.bfloat16, device=DEV)
+        rp = torch.zeros_like(fp)
+        tab = np.zeros(1, dtype=np.dtype([("offset", "<i8"), ("kh", "<i4"), ("kw", "<i4"), ("cin", "<i4"), ("cout", "<i4")]))
+        tab[0] = (sp.offset, 3, 3, cin, cout)
+        tabd = torch.from_numpy(tab.view(np.uint8).copy()).to(DEV)
+        L0.lib().conv_pack_weights_bf16(tabd.data_ptr(), 1, store.theta.data_ptr(), fp.data_ptr(), rp.data_ptr(), st)
+        cv.desc.w_fwd_pack = fp.data_ptr() + 4 * sp.offset
+        cv.desc.w_dgrad_pack = rp.data_ptr() + 4 * sp.offset
+        keep = [fp, rp, tabd]
+    return store, cv, bn_out, bn_in, keep
+
+
+@pytest.mark.parametrize("case", TILED_CASES, ids=lambda c: "{}to{}_n{}_{}x{}".format(*c))
+def test_conv3x3_tiled_bf16_kernel(case):
+    """The LDS-tiled bfloat16 kernel (forward with fused statistics, plain forward, data gradient with a skip addend, data
+    gradient with the fused BatchNormalization backward sums incl. PReLU and dropout) against the float32-MFMA kernels on the
+    same bfloat16 tensors and bfloat16-rounded kernel: same products, float32 accumulation in a different order - stored
+    results equal or one bfloat16 step apart, reductions to rtol 2e-4 of their scale."""
+    eng, L0 = pkg("engine"), pkg("_lib")
+    cin, cout, N, H, W = case
+    rng = np.random.RandomState(cin + 3 * cout + H)
+    x = _bf(rng.standard_normal((N, H, W, cin)))
+    w = rng.standard_normal((3, 3, cin, cout)).astype(np.float32) * np.sqrt(2.0 / (9 * cin))
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    dy = _bf(rng.standard_normal((N, H, W, cout)))
+    add = _bf(rng.standard_normal((N, H, W, cin)))
+    bnx = _bf(rng.standard_normal((N, H, W, cin)) * 1.5 + 0.3)
+    drop = (rng.uniform(size=(N, cin)) > 0.3).astype(np.float32) / 0.7
+    st = torch.cuda.current_stream().cuda_stream
+    npix = N * H * W
+    outs = {}
+    for packed in (False, True):
+        store, cv, bn_out, bn_in, keep = _packed_conv(eng, L0, cin, cout, w, b, packed, N, H, W, st)
+        names = []
+        xd, dyd, addd, bnxd = (_dev(t, torch.bfloat16) for t in (x, dy, add, bnx))
+        dropd = torch.from_numpy(drop).to(DEV)
+        ws = torch.empty(max(cv.ws_bytes, 1 << 20) // 4 + 64, device=DEV)
+        y = torch.empty(N, H, W, cout, dtype=torch.bfloat16, device=DEV)
+        y2 = torch.empty_like(y)
+        cv.fwd_bn(xd, y, bn_out, npix, True, False, False, ws, st)
+        names.append(store.L.last_kernel())
+        cv.fwd(xd, y2, st)
+        names.append(store.L.last_kernel())
+        dx_plain = torch.empty(N, H, W, cin, dtype=torch.bfloat16, device=DEV)
+        dx_add = torch.empty_like(dx_plain)
+        cv.bwd_data(dyd, dx_plain, st)
+        names.append(store.L.last_kernel())
+        cv.bwd_data(dyd, dx_add, st, add=addd)
+        names.append(store.L.last_kernel())
+        # the BatchNormalization + PReLU in front of the convolution: its statistics from its raw input, then the fused backward
+        bn_in.stats(bnxd, npix, cin, True, False, False, ws, st)
+        prng = np.random.RandomState(99)      # the same parameters in both passes
+        store.views["bn_in/gamma"].copy_(torch.from_numpy(prng.uniform(0.5, 1.5, cin).astype(np.float32)))
+        store.views["bn_in/beta"].copy_(torch.from_numpy(prng.uniform(-0.5, 0.5, cin).astype(np.float32)))
+        store.views["pr/alpha"].copy_(torch.from_numpy(prng.uniform(0.05, 0.4, (1, 1, cin)).astype(np.float32)))
+        da = torch.empty_like(dx_plain)
+        dxb = torch.empty_like(dx_plain)
+        store.grad.zero_()
+        cv.bwd_data_bn(dyd, da, bn_in, bnxd, cin, dxb, npix, ws, st, drop=dropd, hw=H * W)
+        names.append(store.L.last_kernel())
+        torch.cuda.synchronize()
+        f = lambda t: t.float().cpu().numpy()
+        outs[packed] = dict(y=f(y), y2=f(y2), mean=f(bn_out.mean), invstd=f(bn_out.invstd), dx_plain=f(dx_plain), dx_add=f(dx_add),
+                            da=f(da), dxb=f(dxb), dgamma=f(bn_in.dgamma), dbeta=f(bn_in.dbeta), dalpha=f(bn_in.dalpha), names=names)
+        del keep
+    ref, got = outs[False], outs[True]
+    want = [True, True] + [cin % 64 == 0] * 3      # the data gradient is a forward pass over cout -> cin channels
+    assert [b"tiled" in (n or b"") for n in got["names"]] == want, got["names"]
+    assert not any(b"tiled" in (n or b"") for n in ref["names"]), ref["names"]
+    for k in ("y", "y2", "dx_plain", "dx_add", "da"):
+        a, r_ = got[k], ref[k]
+        diff = np.abs(a - r_)
+        scale = np.abs(r_).max()
+        assert np.all(diff <= np.maximum(np.abs(r_), 1e-30) * 2.0 ** -7 + 2.0 ** -8 * 1e-2 * scale), "{}: max deviation {:.3e} on scale {:.3e}".format(k, diff.max(), scale)
+        assert (diff > 0).mean() <= 2e-2, "{}: {:.2%} of the results differ".format(k, (diff > 0).mean())
+    assert np.array_equal(got["y"], got["y2"])
+    np.testing.assert_allclose(got["mean"], ref["mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got["invstd"], ref["invstd"], rtol=1e-5)
+    for k in ("dgamma", "dbeta", "dalpha"):
+        np.testing.assert_allclose(got[k], ref[k], rtol=2e-4, atol=2e-4 * np.abs(ref[k]).max())
+    # the apply pass runs on da (equal up to single bfloat16 steps) with coefficients equal to 2e-4
+    d = np.abs(got["dxb"] - ref["dxb"])
+    assert d.max() <= 2e-2 * np.abs(ref["dxb"]).max() and (d > 0).mean() <= 5e-2, (d.max(), (d > 0).mean())
+
+
 def _compiled(name, w0, lr=5e-4, dtype="bf16"):
     models, losses, metrics, xo = pkg("models"), pkg("losses"), pkg("metrics"), pkg("keras_extensions.extended_optimizers")
     m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY,
