@@ -94,6 +94,18 @@ bool conv_tiled_bf16_ok(int h, int w, int cin, int cout, int kh, int kw, int str
 ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x, const void* wpack,
                                    const float* bias, void* y, float* part, int* part_rows, const BnBwdArgs& bn, hipStream_t st);
 
+// Weight gradient of the same layers from staged halo patches (conv_tiled.hip): partial sums part[share][K_aug][cout]
+// (k = tap * cin + ci; row K, when with_bias, = bias gradient) for the caller's reduction kernel.
+struct WgPatchPlan {
+  bool use;
+  int K, K_aug, ntiles, tiles_per_share, shares;
+  size_t bytes;
+};
+WgPatchPlan plan_wg_patch_bf16(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                               int ho, int wo, int x_ld, int y_ld, bool with_bias);
+ssmi_status launch_wg_patch_bf16(const WgPatchPlan& p, int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x,
+                                 const void* dy, float* part, hipStream_t st);
+
 // Per-channel parameters of a BatchNormalization + PReLU whose output a kernel forms on the fly from the raw tensor
 // (PRE instantiations of conv_fwd_kernel / conv_bwd_weight_lds); same arithmetic as bn_act_fwd_kernel.
 struct PreBn {

@@ -3317,13 +3317,21 @@ static bool launch_wg_1x1(const Geo& g, const Wg1x1Plan& p, const float* x, cons
 #undef L1
 }
 
+static WgPatchPlan wg_patch_plan(const Geo& g, bool with_bias) {
+  static const bool off = getenv("SSMI_NO_BF16_WGRAD") != nullptr || getenv("SSMI_NO_BF16_MFMA") != nullptr;
+  if (off) return WgPatchPlan{};
+  return plan_wg_patch_bf16(g.n, g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.stride, g.dil, g.pad_t, g.pad_l, g.ho, g.wo, g.x_ld, g.y_ld, with_bias);
+}
+
 static size_t wg_ws_bytes(const Geo& g) {
   const TiledPlan t = plan_tiled(g, true);
   const size_t b0 = plan_wg(g, false).bytes, b1 = plan_wg(g, true).bytes;
   const size_t b2 = plan_wg(g, true, true).bytes;      // the bf16 matrix-instruction variant tiles (and so strips) differently
   const size_t b3 = plan_wg_1x1(g, false).bytes;      // direct 1x1 kernel (float32 storage, no bias)
   const size_t b = std::max(std::max(b0, b3), std::max(b1, b2));
-  return t.use && t.bytes > b ? t.bytes : b;      // the strip kernels remain the fallback for unaligned pointers
+  const WgPatchPlan wp = wg_patch_plan(g, true);      // bfloat16 storage only (the activation type is not known here)
+  const size_t b4 = wp.use ? wp.bytes : 0;
+  return std::max(t.use && t.bytes > b ? t.bytes : b, b4);      // the strip kernels remain the fallback for unaligned pointers
 }
 
 // layers whose weight gradient can take act(BN(x)) of a raw x (PRE instantiations of conv_bwd_weight_lds: one tile per wave,
@@ -3387,6 +3395,22 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
         hipLaunchKernelGGL((conv_bwd_weight_lds<T, 1, true, false, 2, 8, true>), grid, dim3(256), lds, st, g, sz, p.a, p.l, x, dy, part, *pre);
       SSMI_LAUNCH_CHECK();
       launch_wg_reduce(part, p.a.nstrips, p.a.K, p.a.K_aug, g.cout, dw, dbias, st);
+      SSMI_LAUNCH_CHECK();
+      return SSMI_OK;
+    }
+  }
+  if constexpr (sizeof(T) == 2) {
+    // wide 3x3 layers: halo patches staged once per tile, all nine taps from LDS (conv_tiled.hip)
+    const WgPatchPlan q = wg_patch_plan(g, dbias != nullptr);
+    if (q.use && !pre && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0) {
+      SSMI_REQUIRE(ws != nullptr && ws_bytes >= q.bytes, SSMI_E_WORKSPACE, "conv2d_bwd_weight: workspace too small (%zu < %zu)",
+                   ws_bytes, q.bytes);
+      SSMI_REQUIRE(q.bytes < 0x7FFFFFFFULL, SSMI_E_UNSUPPORTED, "conv2d_bwd_weight: partial sums of 2 GiB or more");
+      float* part = reinterpret_cast<float*>(ws);
+      e = launch_wg_patch_bf16(q, g.n, g.h, g.w, g.cin, g.cout, g.x_ld, g.y_ld, x, dy, part, st);
+      if (e) return e;
+      set_last_kernel("conv3x3_wgrad_patch_bf16 shares %d", q.shares);
+      launch_wg_reduce(part, q.shares, q.K, q.K_aug, g.cout, dw, dbias, st);
       SSMI_LAUNCH_CHECK();
       return SSMI_OK;
     }

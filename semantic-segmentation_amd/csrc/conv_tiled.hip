@@ -381,4 +381,196 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
   return SSMI_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers (3x3, stride 1, SAME, bfloat16 storage; input and output channels in whole 64-blocks,
+// height a multiple of 8, width of 16):
+//   dw[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co]        db[co] = sum_pixels dy[pixel][co]
+// A workgroup owns a 64 x 64 block of (ci, co) for all nine taps and a range of 8 x 16 pixel tiles.  Per tile it stages the
+// 10 x 18 halo patch of x (64 channels) and the dy tile (64 channels) in LDS ONCE - the strip kernels gather x once per tap -
+// and walks the ten patch rows: the x operand of patch row p serves tap row ky for the dy row p - ky, so one patch row
+// (three operand reads, one per kx) and one new dy row feed nine matrix instructions; the two previous dy rows stay in
+// registers.  Operands come from the transposing LDS read (ds_read_tr16_b64: pixels become the reduction dimension), rows
+// are 192 bytes (128 of channels + 64 of padding: the four pixel rows and two channel halves of one read fall into distinct
+// banks).  Four waves split the block 2 x 2 (32 x 32 x 9 taps = 144 accumulator registers each).  The next tile's rows
+// travel in registers while the current one is multiplied; two workgroups per CU cover each other's load latency.
+// Output: partial sums part[share][K_aug][cout] (k = tap * cin + ci, row K = bias gradient), summed by the caller's
+// reduction kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int kWgTH = 8, kWgPW = 18, kWgPH = kWgTH + 2;
+static constexpr int kWgRowB = 192;
+static constexpr int kWgABytes = kWgPH * kWgPW * kWgRowB;      // 34560
+static constexpr int kWgBBytes = kWgTH * 16 * kWgRowB;         // 24576
+
+struct WgPatchArgs {
+  int n, h, w, cin, cout, x_ld, y_ld, K, K_aug, ntiles, tiles_per_share, shares;
+  const bf16* x;
+  const bf16* dy;
+  float* part;
+};
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_patch_bf16(WgPatchArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  const lds_ptr lA = (lds_ptr)smem;
+  const lds_ptr lB = lA + kWgABytes;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int sq = (lane & 15) >> 2, sp = lane & 3, gh = (lane >> 4) & 1;      // this lane's part in a transposing read
+  const int wci = wave & 1, wco = wave >> 1;
+
+  // (ci block, co block) fastest, share slowest, XCD-contiguous: the workgroups of an XCD that run together work on the
+  // same pixel tiles, so x and dy are fetched into that L2 once and read from it by every block
+  const int nbi = a.cin >> 6, nbo = a.cout >> 6;
+  const unsigned v = spread_over_xcds(blockIdx.x, gridDim.x);
+  const int blk = (int)(v % (unsigned)(nbi * nbo)), share = (int)(v / (unsigned)(nbi * nbo));
+  const int bi = blk % nbi, bo = blk / nbi;
+  const int t_begin = share * a.tiles_per_share, t_end = min(a.ntiles, t_begin + a.tiles_per_share);
+  const int tiles_x = a.w >> 4, tiles_y = a.h / kWgTH;
+
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((int64_t)a.n * a.h * a.w * a.x_ld * 2));
+  const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)((int64_t)a.n * a.h * a.w * a.y_ld * 2));
+
+  // staging roles: patch 180 pixels x eight 16-byte pieces = 1440 pieces (six rounds, the last partial); dy 128 x 8 = 1024
+  constexpr int ARND = (kWgPH * kWgPW * 8 + 255) / 256, BRND = 4;
+  int apy[ARND], apx[ARND];
+  unsigned al[ARND], apiece[ARND];
+#pragma unroll
+  for (int j = 0; j < ARND; ++j) {
+    const int idx = tid + 256 * j, pix = idx >> 3;
+    apy[j] = pix / kWgPW;
+    apx[j] = pix - apy[j] * kWgPW;
+    apiece[j] = (unsigned)((bi * 64 + (idx & 7) * 8) * 2);
+    al[j] = pix < kWgPH * kWgPW ? (unsigned)(pix * kWgRowB + (idx & 7) * 16) : 0xFFFFFFFFu;
+  }
+  unsigned brel[BRND], bl[BRND];
+#pragma unroll
+  for (int j = 0; j < BRND; ++j) {
+    const int idx = tid + 256 * j, pix = idx >> 3;      // tile pixel: row pix >> 4, column pix & 15
+    brel[j] = (unsigned)(((pix >> 4) * a.w + (pix & 15)) * a.y_ld + bo * 64 + (idx & 7) * 8) * 2u;
+    bl[j] = (unsigned)(pix * kWgRowB + (idx & 7) * 16);
+  }
+  u32x4 areg[ARND], breg[BRND];
+  auto request = [&](int t) {
+    const bool tv = t < t_end;
+    const int img = t / (tiles_x * tiles_y);
+    const int trem = t - img * (tiles_x * tiles_y);
+    const int y0 = (trem / tiles_x) * kWgTH, x0 = (trem % tiles_x) * 16;
+#pragma unroll
+    for (int j = 0; j < ARND; ++j) {
+      const int iy = y0 - 1 + apy[j], ix = x0 - 1 + apx[j];
+      const bool ok = tv && al[j] != 0xFFFFFFFFu && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+      const unsigned off = (unsigned)(((img * a.h + iy) * a.w + ix) * a.x_ld) * 2u + apiece[j];
+      areg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : kOOB, 0, 0));
+    }
+    const unsigned base = (unsigned)(((img * a.h + y0) * a.w + x0) * a.y_ld) * 2u;
+#pragma unroll
+    for (int j = 0; j < BRND; ++j)
+      breg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, tv ? base + brel[j] : kOOB, 0, 0));
+  };
+
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ky][kx][i] = 0.f;
+  float bsum = 0.f;
+  const bool do_bias = a.K_aug > a.K && bi == 0 && wci == 0;      // uniform per wave
+
+  struct Pair { s16x4 lo, hi; };
+  auto operand = [&](lds_ptr p) {
+    Pair pr;
+    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * kWgRowB));
+    return __builtin_bit_cast(bf16x8, pr);
+  };
+  const int a_lane = (8 * hh + sq) * kWgRowB + (wci * 32 + 16 * gh + 4 * sp) * 2;
+  const int b_lane = (8 * hh + sq) * kWgRowB + (wco * 32 + 16 * gh + 4 * sp) * 2;
+
+  request(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();                                  // everyone is done with the previous tile
+#pragma unroll
+    for (int j = 0; j < ARND; ++j)
+      if (al[j] != 0xFFFFFFFFu) *reinterpret_cast<u32x4*>(smem + al[j]) = areg[j];
+#pragma unroll
+    for (int j = 0; j < BRND; ++j) *reinterpret_cast<u32x4*>(smem + kWgABytes + bl[j]) = breg[j];
+    __syncthreads();
+    request(t + 1);                                   // in flight while this tile is multiplied
+    bf16x8 b0, b1, b2;                                // dy rows p, p - 1, p - 2
+#pragma unroll
+    for (int p = 0; p < kWgPH; ++p) {
+      bf16x8 ax[3];
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) ax[kx] = operand(lA + a_lane + (p * kWgPW + kx) * kWgRowB);
+      b2 = b1;
+      b1 = b0;
+      if (p < kWgTH) {
+        b0 = operand(lB + b_lane + p * 16 * kWgRowB);
+        if (do_bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum += (float)b0[e];
+        }
+      }
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        if (p < kWgTH) acc[0][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kx], b0, acc[0][kx], 0, 0, 0);
+        if (p >= 1 && p - 1 < kWgTH) acc[1][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kx], b1, acc[1][kx], 0, 0, 0);
+        if (p >= 2 && p - 2 < kWgTH) acc[2][kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ax[kx], b2, acc[2][kx], 0, 0, 0);
+      }
+    }
+  }
+
+  float* pbase = a.part + (int64_t)share * a.K_aug * a.cout;
+  const int co = bo * 64 + wco * 32 + r;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = bi * 64 + wci * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        pbase[(int64_t)((ky * 3 + kx) * a.cin + ci) * a.cout + co] = acc[ky][kx][i];
+      }
+  if (do_bias) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (hh == 0) pbase[(int64_t)a.K * a.cout + co] = bsum;
+  }
+}
+
+WgPatchPlan plan_wg_patch_bf16(int n, int h, int w, int cin, int cout, int kh, int kw, int stride, int dil, int pad_t, int pad_l,
+                               int ho, int wo, int x_ld, int y_ld, bool with_bias) {
+  static const bool off = getenv("SSMI_NO_WG_PATCH") != nullptr;      // measurement switch
+  WgPatchPlan p{};
+  p.use = !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h % kWgTH == 0 &&
+          w % 16 == 0 && cin % 64 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;
+  if (!p.use) return p;
+  p.K = 9 * cin;
+  p.K_aug = p.K + (with_bias ? 1 : 0);
+  p.ntiles = n * (h / kWgTH) * (w / 16);
+  const int nblocks = (cin / 64) * (cout / 64);
+  int shares = 512 / nblocks;                                      // one round of two workgroups per CU
+  if (shares > p.ntiles / 2) shares = p.ntiles / 2;                // at least two tiles per workgroup
+  if (shares < 1) shares = 1;
+  p.tiles_per_share = (p.ntiles + shares - 1) / shares;
+  p.shares = (p.ntiles + p.tiles_per_share - 1) / p.tiles_per_share;
+  p.bytes = (size_t)p.shares * p.K_aug * cout * sizeof(float);
+  return p;
+}
+
+ssmi_status launch_wg_patch_bf16(const WgPatchPlan& p, int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x,
+                                 const void* dy, float* part, hipStream_t st) {
+  WgPatchArgs a{};
+  a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout; a.x_ld = x_ld; a.y_ld = y_ld; a.K = p.K; a.K_aug = p.K_aug;
+  a.ntiles = p.ntiles; a.tiles_per_share = p.tiles_per_share; a.shares = p.shares;
+  a.x = static_cast<const bf16*>(x); a.dy = static_cast<const bf16*>(dy); a.part = part;
+  const unsigned grid = (unsigned)(p.shares * (cin / 64) * (cout / 64));
+  hipLaunchKernelGGL(conv3x3_wgrad_patch_bf16, dim3(grid), dim3(256), (size_t)(kWgABytes + kWgBBytes), st, a);
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
 }  // namespace ssmi

@@ -347,6 +347,7 @@ def test_conv2d_bf16_matrix_instruction_path(case):
 
 TILED_CASES = [  # cin, cout, N, H, W: 3x3 / stride 1 / SAME layers the LDS-tiled bfloat16 kernel takes
     (64, 64, 2, 16, 32), (64, 128, 1, 32, 16), (128, 256, 1, 16, 16), (256, 64, 1, 16, 32), (32, 192, 2, 16, 16), (96, 128, 1, 48, 16),
+    (192, 64, 3, 48, 32), (128, 128, 5, 16, 48),
 ]
 
 
@@ -429,9 +430,15 @@ def test_conv3x3_tiled_bf16_kernel(case):
         store.grad.zero_()
         cv.bwd_data_bn(dyd, da, bn_in, bnxd, cin, dxb, npix, ws, st, drop=dropd, hw=H * W)
         names.append(store.L.last_kernel())
+        store.grad.zero_()
+        cv.bwd_weight(xd, dyd, ws, st)
+        assert (b"wgrad_patch" in (store.L.last_kernel() or b"")) == (cin % 64 == 0 and cout % 64 == 0)
+        torch.cuda.synchronize()
+        dw, db = cv.dw.cpu().numpy().astype(np.float64), cv.db.cpu().numpy().astype(np.float64)
+        cv.bwd_data_bn(dyd, da, bn_in, bnxd, cin, dxb, npix, ws, st, drop=dropd, hw=H * W)      # (parameter gradients again)
         torch.cuda.synchronize()
         f = lambda t: t.float().cpu().numpy()
-        outs[packed] = dict(y=f(y), y2=f(y2), mean=f(bn_out.mean), invstd=f(bn_out.invstd), dx_plain=f(dx_plain), dx_add=f(dx_add),
+        outs[packed] = dict(dw=dw, db=db, y=f(y), y2=f(y2), mean=f(bn_out.mean), invstd=f(bn_out.invstd), dx_plain=f(dx_plain), dx_add=f(dx_add),
                             da=f(da), dxb=f(dxb), dgamma=f(bn_in.dgamma), dbeta=f(bn_in.dbeta), dalpha=f(bn_in.dalpha), names=names)
         del keep
     ref, got = outs[False], outs[True]
@@ -449,6 +456,14 @@ def test_conv3x3_tiled_bf16_kernel(case):
     np.testing.assert_allclose(got["invstd"], ref["invstd"], rtol=1e-5)
     for k in ("dgamma", "dbeta", "dalpha"):
         np.testing.assert_allclose(got[k], ref[k], rtol=2e-4, atol=2e-4 * np.abs(ref[k]).max())
+    # weight gradient (staged-patch kernel when input and output channels come in whole 64-blocks): float32 sums of exact
+    # products against float64
+    xp = np.pad(x.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    ref_dw = np.stack([np.stack([np.einsum("nyxi,nyxo->io", xp[:, ky:ky + H, kx:kx + W], dy.astype(np.float64)) for kx in range(3)])
+                       for ky in range(3)])
+    for k in (False, True):
+        assert np.abs(outs[k]["dw"] - ref_dw).max() <= 2e-5 * np.abs(ref_dw).max(), np.abs(outs[k]["dw"] - ref_dw).max()
+        np.testing.assert_allclose(outs[k]["db"], dy.astype(np.float64).sum((0, 1, 2)), rtol=1e-5, atol=1e-4)
     # the apply pass runs on da (equal up to single bfloat16 steps) with coefficients equal to 2e-4
     d = np.abs(got["dxb"] - ref["dxb"])
     assert d.max() <= 2e-2 * np.abs(ref["dxb"]).max() and (d > 0).mean() <= 5e-2, (d.max(), (d > 0).mean())
