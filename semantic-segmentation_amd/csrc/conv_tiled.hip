@@ -22,10 +22,8 @@ namespace ssmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-static constexpr int kTH = 16, kTW = 16, kPW = kTW + 2, kPH = kTH + 2;
-static constexpr int kPatchPix = kPH * kPW;        // 324
+static constexpr int kTW = 16, kPW = kTW + 2;      // tiles are 16 pixels wide and TH = 16 or 8 rows high
 static constexpr int kRowB = 80;                    // bytes per staged pixel / kernel row
-static constexpr int kABytes = kPatchPix * kRowB;   // 25920
 
 struct TiledArgs {
   int n, h, w, cin, cout, x_ld, y_ld;
@@ -55,13 +53,14 @@ template <> struct Row<4> {
 };
 __device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-template <int BN, int WM, int WN, int EPI>
+template <int BN, int WM, int WN, int EPI, int TH>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(TiledArgs a) {
+  constexpr int kPatchPix = (TH + 2) * kPW, kABytes = kPatchPix * kRowB, BM = TH * kTW;      // 16 rows: 324 pixels, 25920 bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const As = smem;
   unsigned char* const Bs = smem + kABytes;          // two buffers of BN * kRowB bytes
   constexpr int kBBytes = BN * kRowB;
-  constexpr int WPX = 256 / WM;                       // pixels per wave
+  constexpr int WPX = BM / WM;                       // pixels per wave
   constexpr int MT = WPX / 32, NTL = BN / WN / 32;
   static_assert(WM * WN == 4 && MT >= 1 && NTL >= 1, "wave layout");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,7 +68,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   const int wm = wave / WN, wn = wave % WN;
 
   // tile coordinates
-  const int tiles_x = a.w / kTW, tiles_y = a.h / kTH;
+  const int tiles_x = a.w / kTW, tiles_y = a.h / TH;
   const int ncb = a.cout / BN;
   // The workgroups of one XCD (b and b + 8 share one, and its L2) take a contiguous range of (tile, column block) pairs,
   // column block fastest: the column blocks of a tile re-read its patch from that L2, neighbouring tiles share halo rows.
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   const int t = (int)(v / (unsigned)ncb);
   const int img = t / (tiles_x * tiles_y);
   const int trem = t - img * (tiles_x * tiles_y);
-  const int y0 = (trem / tiles_x) * kTH, x0 = (trem % tiles_x) * kTW;
+  const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * kTW;
   const int n0 = (int)(v % (unsigned)ncb) * BN;
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((int64_t)a.n * a.h * a.w * a.x_ld * 2));
@@ -244,25 +243,25 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   request(0);
 
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < BM / 64; ++q) {
     if (q > 0) __syncthreads();                       // the previous pass has been read (pass 0: the loop ended on a barrier)
-    if (wm == (64 * q) / WPX) {
-      const int mt0 = ((64 * q) % WPX) / 32;
 #pragma unroll
-      for (int m2 = 0; m2 < 2; ++m2) {
+    for (int m = 0; m < MT; ++m) {
+      const int pb = wm * WPX + m * 32;               // first tile pixel of this wave's m-th 32-pixel block
+      if (pb / 64 == q) {                             // uniform per wave
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
           const int col = wn * (BN / WN) + nt * 32 + r;
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
-            const int row = m2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-            *reinterpret_cast<float*>(smem + row * SROW + col * 4) = acc[mt0 + m2][nt][i];      // constant index once unrolled
+            const int row = (pb & 63) + (i & 3) + 8 * (i >> 2) + 4 * hh;
+            *reinterpret_cast<float*>(smem + row * SROW + col * 4) = acc[m][nt][i];
           }
         }
       }
     }
     __syncthreads();
-    if (q < 3) request(q + 1);
+    if (q + 1 < BM / 64) request(q + 1);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
       const int lp = pl + j * PL;                     // pixel of this pass
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
 bool conv_tiled_bf16_ok(int h, int w, int cin, int cout, int kh, int kw, int stride, int dil, int pad_t, int pad_l, int ho, int wo,
                         int x_ld, int y_ld) {
   static const bool off = getenv("SSMI_NO_TILED_BF16") != nullptr;      // measurement switch
-  return !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h % kTH == 0 &&
+  return !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h % 16 == 0 &&
          w % kTW == 0 && cin % 32 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;
 }
 
@@ -362,17 +361,21 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
   a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout; a.x_ld = x_ld; a.y_ld = y_ld;
   a.x = static_cast<const bf16*>(x); a.wpack = static_cast<const bf16*>(wpack); a.bias = bias; a.y = static_cast<bf16*>(y);
   a.part = part; a.bn = bn;
-  const int tiles = n * (h / kTH) * (w / kTW);
-  if (part_rows) *part_rows = tiles;
   const int epi = part ? 1 : (bn.add ? 3 : (bn.x ? 2 : 0));
   const bool wide = cout % 128 == 0;
   const int bn_cols = wide ? 128 : 64;
+  // 16-row tiles share more of the halo and of the kernel rows; layers too small to give every CU two workgroups that way
+  // take 8-row tiles
+  static const int below = getenv("SSMI_TILED_TH8_BELOW") ? atoi(getenv("SSMI_TILED_TH8_BELOW")) : 512;      // measurement switch
+  const int th = (n * (h / 16) * (w / kTW) * (cout / bn_cols) < below) ? 8 : 16;
+  const int tiles = n * (h / th) * (w / kTW);
+  if (part_rows) *part_rows = tiles;
   dim3 grid((unsigned)(tiles * (cout / bn_cols)), 1, 1);
-  const size_t lds = (size_t)kABytes + 2 * (size_t)bn_cols * kRowB;
+  const size_t lds = (size_t)(th + 2) * kPW * kRowB + 2 * (size_t)bn_cols * kRowB;
 #define LT(BN_, WM_, WN_, E_)                                                                                                  \
   do {                                                                                                                          \
-    auto kfn = conv3x3_tiled_bf16<BN_, WM_, WN_, E_>;                                                                           \
-    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                                                       \
+    if (th == 16) hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, 16>), grid, dim3(256), lds, st, a);                 \
+    else hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, 8>), grid, dim3(256), lds, st, a);                           \
   } while (0)
   if (wide) { if (epi == 0) LT(128, 2, 2, 0); else if (epi == 1) LT(128, 2, 2, 1); else if (epi == 2) LT(128, 2, 2, 2); else LT(128, 2, 2, 3); }
   else { if (epi == 0) LT(64, 4, 1, 0); else if (epi == 1) LT(64, 4, 1, 1); else if (epi == 2) LT(64, 4, 1, 2); else LT(64, 4, 1, 3); }

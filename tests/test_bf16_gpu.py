@@ -348,6 +348,8 @@ def test_conv2d_bf16_matrix_instruction_path(case):
 TILED_CASES = [  # cin, cout, N, H, W: 3x3 / stride 1 / SAME layers the LDS-tiled bfloat16 kernel takes
     (64, 64, 2, 16, 32), (64, 128, 1, 32, 16), (128, 256, 1, 16, 16), (256, 64, 1, 16, 32), (32, 192, 2, 16, 16), (96, 128, 1, 48, 16),
     (192, 64, 3, 48, 32), (128, 128, 5, 16, 48),
+    # large enough for 16-row tiles (the cases above run on 8-row tiles: fewer than 512 workgroups otherwise)
+    (64, 64, 2, 256, 256), (128, 128, 8, 128, 128),
 ]
 
 
