@@ -106,6 +106,9 @@ WgPatchPlan plan_wg_patch_bf16(int n, int h, int w, int cin, int cout, int kh, i
 ssmi_status launch_wg_patch_bf16(const WgPatchPlan& p, int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x,
                                  const void* dy, float* part, hipStream_t st);
 
+// bfloat16 kernel packs of `count` layers (table on the device): fpack[tap][co][ci], rpack[ntaps-1-tap][ci][co] (conv_tiled.hip)
+ssmi_status launch_conv_pack_bf16(const ssmi_rot_entry* table, int count, const float* theta, void* fpack, void* rpack, hipStream_t st);
+
 // Per-channel parameters of a BatchNormalization + PReLU whose output a kernel forms on the fly from the raw tensor
 // (PRE instantiations of conv_fwd_kernel / conv_bwd_weight_lds); same arithmetic as bn_act_fwd_kernel.
 struct PreBn {

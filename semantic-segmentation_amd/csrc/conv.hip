@@ -3668,6 +3668,8 @@ ssmi_status ssmi_conv_pack_weights_bf16(const ssmi_rot_entry* table, int32_t cou
                                         uint16_t* dgrad_pack, void* stream) {
   SSMI_REQUIRE(table && theta && (fwd_pack || dgrad_pack) && count > 0 && count <= 65535, SSMI_E_INVALID_ARG,
                "conv_pack_weights_bf16: bad argument");
+  static const bool simple = getenv("SSMI_SIMPLE_PACK") != nullptr;      // measurement switch: the element-by-element kernel
+  if (!simple) return launch_conv_pack_bf16(table, count, theta, fwd_pack, dgrad_pack, as_stream(stream));
   hipLaunchKernelGGL(conv_pack_bf16_batch_kernel, dim3(64, (unsigned)count), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const RotEntry*>(table), theta, reinterpret_cast<bf16*>(fwd_pack),
                      reinterpret_cast<bf16*>(dgrad_pack));

@@ -576,4 +576,70 @@ ssmi_status launch_wg_patch_bf16(const WgPatchPlan& p, int n, int h, int w, int 
   return SSMI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bfloat16 kernel packs of every table entry, once per step after the optimizer: fpack[tap][co][ci] (transposed) and
+// rpack[ntaps - 1 - tap][ci][co] = bf16(w[tap][ci][co]).  A workgroup takes 64 x 64 (ci, co) tiles of a layer: float32 rows
+// in with 16-byte loads, the straight pack out with 8-byte stores, the transposed pack through LDS so that its stores are
+// 8 bytes of consecutive ci as well.  Layers whose channel counts are not multiples of four go element by element.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_pack_bf16_tiled_kernel(const ssmi_rot_entry* __restrict__ table, const float* __restrict__ theta,
+                                                                   bf16* __restrict__ fpack, bf16* __restrict__ rpack) {
+  __shared__ unsigned short sm[64][68];
+  const ssmi_rot_entry en = table[blockIdx.y];
+  const float* w = theta + en.offset;
+  const int cin = en.cin, cout = en.cout, per_tap = cin * cout, ntaps = en.kh * en.kw;
+  bf16* const fp = fpack ? fpack + 2 * en.offset : nullptr;      // byte offset 4 * offset: 16-byte aligned like theta's segments
+  bf16* const rp = rpack ? rpack + 2 * en.offset : nullptr;
+  if ((cin | cout) & 3) {
+    const int total = ntaps * per_tap;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+      const int tap = e / per_tap, rem = e - tap * per_tap;
+      const int ci = rem / cout, co = rem - ci * cout;
+      const bf16 v = (bf16)w[e];
+      if (fp) fp[(int64_t)(tap * cout + co) * cin + ci] = v;
+      if (rp) rp[(int64_t)(ntaps - 1 - tap) * per_tap + rem] = v;
+    }
+    return;
+  }
+  const int tci_n = (cin + 63) >> 6, tco_n = (cout + 63) >> 6;
+  const int ntiles = ntaps * tci_n * tco_n;
+  const int row0 = threadIdx.x >> 4, c4 = (threadIdx.x & 15) * 4;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tap = tile / (tci_n * tco_n), rem = tile - tap * (tci_n * tco_n);
+    const int ci0 = (rem / tco_n) * 64, co0 = (rem % tco_n) * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = row0 + 16 * j, ci = ci0 + row, co = co0 + c4;
+      u32x2 pk = {0u, 0u};
+      if (ci < cin && co < cout) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + (int64_t)(tap * cin + ci) * cout + co);
+        pk = pack_bf16x4(v);
+        if (rp) *reinterpret_cast<u32x2*>(rp + (int64_t)(ntaps - 1 - tap) * per_tap + (int64_t)ci * cout + co) = pk;
+      }
+      *reinterpret_cast<u32x2*>(&sm[row][c4]) = pk;
+    }
+    __syncthreads();
+    if (fp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cor = row0 + 16 * j, co = co0 + cor, ci = ci0 + c4;      // this thread's four consecutive ci of output channel co
+        if (co < cout && ci < cin) {
+          u32x2 pk;
+          pk[0] = (unsigned)sm[c4][cor] | ((unsigned)sm[c4 + 1][cor] << 16);
+          pk[1] = (unsigned)sm[c4 + 2][cor] | ((unsigned)sm[c4 + 3][cor] << 16);
+          *reinterpret_cast<u32x2*>(fp + (int64_t)(tap * cout + co) * cin + ci) = pk;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+ssmi_status launch_conv_pack_bf16(const ssmi_rot_entry* table, int count, const float* theta, void* fpack, void* rpack, hipStream_t st) {
+  hipLaunchKernelGGL(conv_pack_bf16_tiled_kernel, dim3(192, (unsigned)count), dim3(256), 0, st, table, theta, static_cast<bf16*>(fpack),
+                     static_cast<bf16*>(rpack));
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
 }  // namespace ssmi
