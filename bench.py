@@ -265,7 +265,7 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = measure_roofline(model, stream)
+        roof = measure_roofline(model, stream, args.model)
 
     # Second measurement, same step with bfloat16 activation storage (float32 arithmetic, parameters and optimizer state).
     # The headline value above stays the float32 one.
@@ -279,8 +279,9 @@ def main():
         el16, loss16, _ = timed_run(tr16, "bf16")
         bf16 = {"value": round(args.batch * world * args.steps / el16, 2), "unit": "images/s",
                 "ms_per_step": round(el16 / args.steps * 1e3, 3), "final_loss": round(loss16, 5),
-                "dtype": "bf16 activation and activation-gradient storage; f32 multiply-add, statistics, parameters, Adam",
-                "roofline": measure_roofline(tr16.model, stream) if rank == 0 and not args.no_roofline else None}
+                "dtype": "bf16 activation and activation-gradient storage; layers with >= 16 channels multiply bf16 operands on the bf16 "
+                         "matrix instructions (f32 accumulation), the others in f32; statistics, parameters, Adam f32",
+                "roofline": measure_roofline(tr16.model, stream, args.model) if rank == 0 and not args.no_roofline else None}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -306,7 +307,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measure_roofline(model, stream, steps=3):
+def measure_roofline(model, stream, model_name, steps=3):
     """Eager instrumented steps (same buffers and kernels as the graph replay).  The library brackets every convolution
     kernel launch (forward and data gradient) with HIP events on the launch stream and records the kernel variant with
     the algorithmic bytes / flops of that launch (ssmi_profile_*).  The dominant kernel is the variant with the largest
@@ -343,8 +344,11 @@ def measure_roofline(model, stream, steps=3):
         r[1] += by
         r[2] += fl
         r[3] += 1
-    kernel, (ms, by, fl, n) = max(agg.items(), key=lambda kv: kv[1][0])
-    conv_ms = sum(v[0] for v in agg.values()) / steps
+    # the bf16 patch weight gradient is recorded too, but it runs on a side stream beside the main chain: its bracket also
+    # times the kernels it shares the chip with, so it is listed (wgrad_patch_ms_per_step_overlapped) but not priced here
+    main = {k: v for k, v in agg.items() if "wgrad" not in k}
+    kernel, (ms, by, fl, n) = max(main.items(), key=lambda kv: kv[1][0])
+    conv_ms = sum(v[0] for k, v in agg.items() if "wgrad" not in k) / steps      # (the bf16 patch weight gradient is recorded too)
     ai = fl / by
     gbs = by / (ms * 1e-3) / 1e9
     tfs = fl / (ms * 1e-3) / 1e12
@@ -354,26 +358,33 @@ def measure_roofline(model, stream, steps=3):
     import re
     want_bf16 = getattr(model.graph.store, "act_dtype", torch.float32) == torch.bfloat16
     base = kernel.replace(" bf16 mfma", "")
-    for fname in (("r02_traffic_bf16.json",) if want_bf16 else ("r02_traffic.json", "r01_traffic.json")):
+    tag = "" if model_name == "enet-naive-upsampling" else "_" + model_name
+    if want_bf16:
+        files = ("r03_traffic{}_bf16.json".format(tag),) + (("r02_traffic_bf16.json",) if not tag else ())
+    else:
+        files = ("r03_traffic{}.json".format(tag),) + (("r02_traffic.json", "r01_traffic.json") if not tag else ())
+    for fname in files:
         tpath = os.path.join(ROOT, "profiles", fname)
         if traffic is None and os.path.exists(tpath):
             with open(tpath) as f:
                 raw = json.load(f)
-            # trace names: storage type first, then the record's arguments, then (newer builds) the normalise-on-load flag
+            # trace names: storage type first, then the record's arguments, then (newer builds) the normalise-on-load flag;
+            # kernels that exist for one storage type only carry no type and are recorded under the trace's own name
             for k, v in raw.items():
-                m = re.match(r"^(\w+)<(float|__bf16), (.*?)(, false)?>$", k)
-                if m and (m.group(2) == "__bf16") == want_bf16 and "{}<{}>".format(m.group(1), m.group(3)) == base:
+                m = re.match(r"^(\w+)<(float|__bf16|bf16), (.*?)(, false)?>$", k)
+                if k == base or (m and (m.group(2) != "float") == want_bf16 and "{}<{}>".format(m.group(1), m.group(3)) == base):
                     traffic = v.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/" + fname
     common = {"kernel": "ssmi::" + kernel, "launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
               "algorithmic_bytes_per_launch": round(by / n), "algorithmic_flops_per_launch": round(fl / n),
               "arithmetic_intensity_flop_per_byte": round(ai, 2), "achieved_gbs": round(gbs, 1), "achieved_tflops": round(tfs, 2),
               "kernel_ms_per_step": round(ms / steps, 3), "all_conv_fwd_bwd_data_ms_per_step": round(conv_ms, 3),
-              "event_bracket_overhead_us": round(overhead_ms * 1e3, 2), "traffic": traffic,
+              "event_bracket_overhead_us": round(overhead_ms * 1e3, 2),
+              "wgrad_patch_ms_per_step_overlapped": round(sum(v[0] for k, v in agg.items() if "wgrad" in k) / steps, 3), "traffic": traffic,
               # HBM bytes per launch come from committed rocprofv3 counter passes of this kernel, not from this run
               "traffic_source": traffic_source}
     # a variant that multiplies on the bf16 matrix instructions is priced against THEIR dense peak (ridge 312 FLOP/B)
-    mfma_peak = BF16_MFMA_PEAK_TFLOPS if kernel.endswith("bf16 mfma") else F32_MFMA_PEAK_TFLOPS
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if (kernel.endswith("bf16 mfma") or "_bf16" in kernel) else F32_MFMA_PEAK_TFLOPS
     if ai < mfma_peak * 1e3 / HBM_PEAK_GBS:
         return dict({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4)}, **common)

@@ -40,10 +40,10 @@ traffic = {short(k): v for k, v in json.load(open(out + "/traffic.json")).items(
 def uses_bf16_mfma(k, recs):
     """bfloat16 matrix instructions: the bfloat16 weight-gradient kernels by name, the direct kernels when the library's
     records of this run list the variant with its ' bf16 mfma' suffix."""
+    if "_bf16<" in k or k.endswith("_bf16"):      # bfloat16-only kernels (tiled / patch convolutions, weight gradients)
+        return "pack" not in k
     if storage_type(k) != "bf16":
         return False
-    if "_bf16<" in k or k.endswith("_bf16"):
-        return True
     base = short(k, strip_type=True)
     m = re.match(r"^(conv_fwd_kernel<\d+, (?:true|false)), (?:true|false)(?:, \d+)?>$", base)
     return bool(m) and any(r.startswith(m.group(1) + ">") and r.endswith("bf16 mfma") for r in recs)

@@ -2509,7 +2509,6 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
     if (bn.wpack && !pre && bn.pm_main == nullptr &&
         conv_tiled_bf16_ok(g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.stride, g.dil, g.pad_t, g.pad_l, g.ho, g.wo, g.x_ld, g.y_ld)) {
       const ssmi_status te = launch_conv_tiled_bf16(g.n, g.h, g.w, g.cin, g.cout, g.x_ld, g.y_ld, x, bn.wpack, bias, y, part, part_rows, bn, st);
-      if (te == SSMI_OK) set_last_kernel("conv3x3_tiled_bf16<%d>", g.cout % 128 == 0 ? 128 : 64);
       if (te != SSMI_E_UNSUPPORTED) return te;
     }
   }
@@ -3407,9 +3406,13 @@ static ssmi_status launch_bwd_weight(const Geo& g, const T* x, const T* dy, floa
                    ws_bytes, q.bytes);
       SSMI_REQUIRE(q.bytes < 0x7FFFFFFFULL, SSMI_E_UNSUPPORTED, "conv2d_bwd_weight: partial sums of 2 GiB or more");
       float* part = reinterpret_cast<float*>(ws);
-      e = launch_wg_patch_bf16(q, g.n, g.h, g.w, g.cin, g.cout, g.x_ld, g.y_ld, x, dy, part, st);
-      if (e) return e;
-      set_last_kernel("conv3x3_wgrad_patch_bf16 shares %d", q.shares);
+      {
+        const double M = (double)g.n * g.ho * g.wo;
+        ProfileScope prof(st, M * (g.cin + g.cout) * 2.0 + (double)q.K_aug * g.cout * 4.0, conv_flops(g));
+        set_last_kernel("conv3x3_wgrad_patch_bf16");
+        e = launch_wg_patch_bf16(q, g.n, g.h, g.w, g.cin, g.cout, g.x_ld, g.y_ld, x, dy, part, st);
+        if (e) return e;
+      }
       launch_wg_reduce(part, q.shares, q.K, q.K_aug, g.cout, dw, dbias, st);
       SSMI_LAUNCH_CHECK();
       return SSMI_OK;

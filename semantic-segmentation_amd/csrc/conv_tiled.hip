@@ -377,6 +377,7 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
     if (th == 16) hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, 16>), grid, dim3(256), lds, st, a);                 \
     else hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, 8>), grid, dim3(256), lds, st, a);                           \
   } while (0)
+  set_last_kernel(wide ? "conv3x3_tiled_bf16<128, 2, 2, %d, %d>" : "conv3x3_tiled_bf16<64, 4, 1, %d, %d>", epi, th);      // as the profiler prints it
   if (wide) { if (epi == 0) LT(128, 2, 2, 0); else if (epi == 1) LT(128, 2, 2, 1); else if (epi == 2) LT(128, 2, 2, 2); else LT(128, 2, 2, 3); }
   else { if (epi == 0) LT(64, 4, 1, 0); else if (epi == 1) LT(64, 4, 1, 1); else if (epi == 2) LT(64, 4, 1, 2); else LT(64, 4, 1, 3); }
 #undef LT
