@@ -146,6 +146,9 @@ def main():
         raise SystemExit("--gpus {} does not match WORLD_SIZE={} of the launcher".format(args.gpus, world))
     cfg = {"input_shape": [None, None, 3], "optimizer": {"name": "adam", "learning_rate": 5e-4}, "ignore_classes": [0],
            "random_seed": 14874, "num_labeled_per_batch": args.batch}
+    eval_bf16 = args.mode == "eval" and args.dtype == "bf16"      # evaluation is one measurement: --dtype picks its storage type
+    if eval_bf16:
+        cfg["activation_dtype"] = "bf16"
     tr = trainers.SegmentationTrainer("segmentation_supervised", args.model, "bench", config=cfg, num_classes=24)
     rank, world = tr.rank, tr.world_size
     dev = torch.device(tr.device)
@@ -252,7 +255,7 @@ def main():
             print(json.dumps({"metric": "eval images/sec @{0}x{0} ENet".format(args.size), "value": round(value, 2),
                               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dtype": "f32", "data": "synthetic",
+                              "dtype": "bf16 activation storage" if eval_bf16 else "f32", "data": "synthetic",
                               "config": {"workload": "{} 24 classes {}x{} per-GPU batch {} inference + loss + confusion matrix, "
                                                      "matrices summed over ranks".format(args.model, args.size, args.size, args.batch),
                                          "parallelism": "dp{}".format(world), "pixels_counted": int(cm.sum()),

@@ -15,6 +15,7 @@
 //   EPI 2  data-gradient form (forward convolution over dy with the data-gradient pack) with the BatchNormalization
 //          backward sums of the layer in front (dz, dz * xhat, d * min(z, 0)) -> bn.part[tile][3][cout]
 //   EPI 3  data-gradient form with a skip-gradient addend (and the sums of EPI 2 when bn.x is given)
+//   EPI 4  inference phase: BatchNormalization with fixed statistics + activation applied before the store
 // The same arithmetic as conv_fwd_kernel's epilogues, summed in a different (fixed) order.
 #include "common.h"
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   constexpr int G = BN / CW;                          // channel groups
   constexpr int PL = 256 / G;                         // pixel lanes
   constexpr int ITEMS = 64 / PL;
-  constexpr bool kDgrad = EPI >= 2, kAdd = EPI == 3;
+  constexpr bool kDgrad = EPI == 2 || EPI == 3, kAdd = EPI == 3, kInfer = EPI == 4;
   constexpr int NS = kDgrad ? 3 : 2;
   const int cg = tid % G, pl = tid / G;
   const int co = n0 + cg * CW;
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
     for (int e = 0; e < CW; ++e) sums[k][e] = 0.f;
   const bool has_bn = kDgrad && a.bn.x != nullptr;
   float mu[CW], is[CW], ga[CW], be[CW], alp[CW];
-  if constexpr (kDgrad) {
-    if (has_bn) {
+  if constexpr (kDgrad || kInfer) {
+    if (has_bn || kInfer) {
 #pragma unroll
       for (int e = 0; e < CW; ++e) {
         mu[e] = a.bn.mean[co + e]; is[e] = a.bn.invstd[co + e]; ga[e] = a.bn.gamma[co + e]; be[e] = a.bn.beta[co + e];
@@ -313,6 +314,13 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
           }
         }
       }
+      if constexpr (kInfer) {      // BatchNormalization with fixed statistics + activation (conv_fwd_kernel's inference epilogue)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+          const float z = ga[e] * ((v[e] - mu[e]) * is[e]) + be[e];
+          v[e] = (a.bn.act == SSMI_ACT_NONE || z > 0.f) ? z : alp[e] * z;
+        }
+      }
       typename Row<CW>::raw o;
 #pragma unroll
       for (int e2 = 0; e2 < CW / 2; ++e2) o[e2] = pack_bf16x2(v[2 * e2], v[2 * e2 + 1]);
@@ -320,7 +328,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
     }
   }
   float* dst = EPI == 1 ? a.part : (has_bn ? a.bn.part : nullptr);
-  if (EPI != 0 && dst != nullptr) {                   // uniform
+  if (EPI != 0 && EPI != 4 && dst != nullptr) {       // uniform
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);      // [NS][PL][BN]
 #pragma unroll
@@ -351,7 +359,8 @@ bool conv_tiled_bf16_ok(int h, int w, int cin, int cout, int kh, int kw, int str
 // take (the caller falls back to the direct kernel).
 ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x_ld, int y_ld, const void* x, const void* wpack,
                                    const float* bias, void* y, float* part, int* part_rows, const BnBwdArgs& bn, hipStream_t st) {
-  if (bn.mean != nullptr && bn.x == nullptr) return SSMI_E_UNSUPPORTED;      // inference epilogue: not here
+  const bool infer = bn.mean != nullptr && bn.x == nullptr;                    // BatchNormalization + activation in the epilogue
+  if (infer && (bn.skip != nullptr || part != nullptr || bn.add != nullptr)) return SSMI_E_UNSUPPORTED;
   if (bn.x != nullptr && (bn.ld % 8 != 0 || (reinterpret_cast<uintptr_t>(bn.x) & 15))) return SSMI_E_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wpack) |
        reinterpret_cast<uintptr_t>(bn.add)) & 15)
@@ -361,25 +370,26 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
   a.n = n; a.h = h; a.w = w; a.cin = cin; a.cout = cout; a.x_ld = x_ld; a.y_ld = y_ld;
   a.x = static_cast<const bf16*>(x); a.wpack = static_cast<const bf16*>(wpack); a.bias = bias; a.y = static_cast<bf16*>(y);
   a.part = part; a.bn = bn;
-  const int epi = part ? 1 : (bn.add ? 3 : (bn.x ? 2 : 0));
+  const int epi = infer ? 4 : (part ? 1 : (bn.add ? 3 : (bn.x ? 2 : 0)));
   const bool wide = cout % 128 == 0;
   const int bn_cols = wide ? 128 : 64;
   // 16-row tiles share more of the halo and of the kernel rows; layers too small to give every CU two workgroups that way
   // take 8-row tiles
   static const int below = getenv("SSMI_TILED_TH8_BELOW") ? atoi(getenv("SSMI_TILED_TH8_BELOW")) : 512;      // measurement switch
-  const int th = (n * (h / 16) * (w / kTW) * (cout / bn_cols) < below) ? 8 : 16;
+  // (the addend epilogue needs a second prefetch set and exceeds the 16-row variant's register budget: 8-row tiles always)
+  const int th = (epi == 3 || n * (h / 16) * (w / kTW) * (cout / bn_cols) < below) ? 8 : 16;
   const int tiles = n * (h / th) * (w / kTW);
   if (part_rows) *part_rows = tiles;
   dim3 grid((unsigned)(tiles * (cout / bn_cols)), 1, 1);
   const size_t lds = (size_t)(th + 2) * kPW * kRowB + 2 * (size_t)bn_cols * kRowB;
 #define LT(BN_, WM_, WN_, E_)                                                                                                  \
   do {                                                                                                                          \
-    if (th == 16) hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, 16>), grid, dim3(256), lds, st, a);                 \
+    if (th == 16) hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, (E_ == 3 ? 8 : 16)>), grid, dim3(256), lds, st, a); \
     else hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, 8>), grid, dim3(256), lds, st, a);                           \
   } while (0)
   set_last_kernel(wide ? "conv3x3_tiled_bf16<128, 2, 2, %d, %d>" : "conv3x3_tiled_bf16<64, 4, 1, %d, %d>", epi, th);      // as the profiler prints it
-  if (wide) { if (epi == 0) LT(128, 2, 2, 0); else if (epi == 1) LT(128, 2, 2, 1); else if (epi == 2) LT(128, 2, 2, 2); else LT(128, 2, 2, 3); }
-  else { if (epi == 0) LT(64, 4, 1, 0); else if (epi == 1) LT(64, 4, 1, 1); else if (epi == 2) LT(64, 4, 1, 2); else LT(64, 4, 1, 3); }
+  if (wide) { if (epi == 0) LT(128, 2, 2, 0); else if (epi == 1) LT(128, 2, 2, 1); else if (epi == 2) LT(128, 2, 2, 2); else if (epi == 3) LT(128, 2, 2, 3); else LT(128, 2, 2, 4); }
+  else { if (epi == 0) LT(64, 4, 1, 0); else if (epi == 1) LT(64, 4, 1, 1); else if (epi == 2) LT(64, 4, 1, 2); else if (epi == 3) LT(64, 4, 1, 3); else LT(64, 4, 1, 4); }
 #undef LT
   SSMI_LAUNCH_CHECK();
   return SSMI_OK;

@@ -415,6 +415,9 @@ def test_conv3x3_tiled_bf16_kernel(case):
         names.append(store.L.last_kernel())
         cv.fwd(xd, y2, st)
         names.append(store.L.last_kernel())
+        y3 = torch.empty_like(y)      # inference phase: BatchNormalization (the statistics just taken) + LeakyReLU in the epilogue
+        cv.fwd_bn_act_infer(xd, y3, bn_out, st, act=eng.ACT_LEAKY, slope=0.1)
+        infer_name = store.L.last_kernel()
         dx_plain = torch.empty(N, H, W, cin, dtype=torch.bfloat16, device=DEV)
         dx_add = torch.empty_like(dx_plain)
         cv.bwd_data(dyd, dx_plain, st)
@@ -440,14 +443,15 @@ def test_conv3x3_tiled_bf16_kernel(case):
         cv.bwd_data_bn(dyd, da, bn_in, bnxd, cin, dxb, npix, ws, st, drop=dropd, hw=H * W)      # (parameter gradients again)
         torch.cuda.synchronize()
         f = lambda t: t.float().cpu().numpy()
-        outs[packed] = dict(dw=dw, db=db, y=f(y), y2=f(y2), mean=f(bn_out.mean), invstd=f(bn_out.invstd), dx_plain=f(dx_plain), dx_add=f(dx_add),
+        outs[packed] = dict(dw=dw, db=db, y3=f(y3), infer_name=infer_name, y=f(y), y2=f(y2), mean=f(bn_out.mean), invstd=f(bn_out.invstd), dx_plain=f(dx_plain), dx_add=f(dx_add),
                             da=f(da), dxb=f(dxb), dgamma=f(bn_in.dgamma), dbeta=f(bn_in.dbeta), dalpha=f(bn_in.dalpha), names=names)
         del keep
     ref, got = outs[False], outs[True]
     want = [True, True] + [cin % 64 == 0] * 3      # the data gradient is a forward pass over cout -> cin channels
     assert [b"tiled" in (n or b"") for n in got["names"]] == want, got["names"]
     assert not any(b"tiled" in (n or b"") for n in ref["names"]), ref["names"]
-    for k in ("y", "y2", "dx_plain", "dx_add", "da"):
+    assert b"tiled" in got["infer_name"] and b"tiled" not in ref["infer_name"], (got["infer_name"], ref["infer_name"])
+    for k in ("y", "y2", "y3", "dx_plain", "dx_add", "da"):
         a, r_ = got[k], ref[k]
         diff = np.abs(a - r_)
         scale = np.abs(r_).max()
