@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <vector>
 namespace ssmi {
+void set_last_kernel(const char*, ...) {}
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)

@@ -23,6 +23,9 @@ namespace ssmi {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef TILED_ABLATE
+#define TILED_ABLATE 0      // microbenchmark builds only: 1 = no reduction loop, 2 = no output stores, 3 = neither (results meaningless)
+#endif
 static constexpr int kTW = 16, kPW = kTW + 2;      // tiles are 16 pixels wide and TH = 16 or 8 rows high
 static constexpr int kRowB = 80;                    // bytes per staged pixel / kernel row
 
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
 
-  const int nchunks = a.cin >> 5;
+  const int nchunks = (TILED_ABLATE & 1) ? 0 : a.cin >> 5;
   u32x4 areg[ARND], breg[3][BRND];
   auto load_a = [&](int chunk) {
 #pragma unroll
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
       typename Row<CW>::raw o;
 #pragma unroll
       for (int e2 = 0; e2 < CW / 2; ++e2) o[e2] = pack_bf16x2(v[2 * e2], v[2 * e2 + 1]);
-      Row<CW>::st(ry, (gp * (unsigned)a.y_ld + (unsigned)co) * 2u, o);
+      if (!(TILED_ABLATE & 2) || o[0] == 0x12345678u) Row<CW>::st(ry, (gp * (unsigned)a.y_ld + (unsigned)co) * 2u, o);
     }
   }
   float* dst = EPI == 1 ? a.part : (has_bn ? a.bn.part : nullptr);

@@ -896,9 +896,8 @@ class ClassifierHead(Block):
     def __init__(self, store, cin, num_classes):
         self.name = "logits"
         self.store = store
-        if store.dtype_code != F32:
-            raise NotImplementedError("the encoder-only classification heads run in float32 only")
         self.cin, self.num_classes = cin, num_classes
+        self.staged = store.dtype_code != F32      # bfloat16 storage: the pooling kernels take float32, widen around them
         self.dense = Conv(store, "logits", 1, 1, cin, num_classes, padding="valid", bias=True, init="glorot_uniform",
                           kernel_shape=(cin, num_classes))
 
@@ -914,17 +913,34 @@ class ClassifierHead(Block):
         self.out = torch.empty(n, self.num_classes, **f32)
         self.dout = torch.empty_like(self.out)
         self.dx = torch.empty(n, h, w, self.cin, **f32)
+        if self.staged:
+            w32 = dict(dtype=torch.float32, device=dev)
+            self.x32 = torch.empty(n, h, w, self.cin, **w32)      # also receives the input gradient before it is rounded
+            self.pooled32 = torch.empty(n, 1, 1, self.cin, **w32)
+            self.dpooled32 = torch.empty_like(self.pooled32)
         return (1, 1, self.num_classes)
 
     def fwd(self, x, cfg):
-        lib().global_avgpool_fwd(_ptr(x), self.n, self.hw, self.cin, _ptr(self.pooled), cfg.st)
+        L = lib()
+        if self.staged:
+            L.cast_bf16_to_f32(_ptr(x), _ptr(self.x32), x.numel(), cfg.st)
+            L.global_avgpool_fwd(_ptr(self.x32), self.n, self.hw, self.cin, _ptr(self.pooled32), cfg.st)
+            L.cast_f32_to_bf16(_ptr(self.pooled32), _ptr(self.pooled), self.pooled.numel(), cfg.st)
+        else:
+            L.global_avgpool_fwd(_ptr(x), self.n, self.hw, self.cin, _ptr(self.pooled), cfg.st)
         self.dense.fwd(self.pooled, self.out, cfg.st)
         return self.out
 
     def bwd(self, dout, cfg):
+        L = lib()
         cfg.wgrad(self.dense, self.pooled, dout)
         self.dense.bwd_data(dout, self.dpooled, cfg.st)
-        lib().global_avgpool_bwd(_ptr(self.dpooled), self.n, self.hw, self.cin, _ptr(self.dx), cfg.st)
+        if self.staged:
+            L.cast_bf16_to_f32(_ptr(self.dpooled), _ptr(self.dpooled32), self.dpooled.numel(), cfg.st)
+            L.global_avgpool_bwd(_ptr(self.dpooled32), self.n, self.hw, self.cin, _ptr(self.x32), cfg.st)
+            L.cast_f32_to_bf16(_ptr(self.x32), _ptr(self.dx), self.dx.numel(), cfg.st)
+        else:
+            L.global_avgpool_bwd(_ptr(self.dpooled), self.n, self.hw, self.cin, _ptr(self.dx), cfg.st)
         return self.dx
 
 

@@ -65,8 +65,10 @@ class ExtendedModel(object):
         # are [batch, classes] float tensors, the logits have rank 2
         self.classification = bool(classification and lambda_loss)
         self.act_dtype = graph.store.act_dtype
-        if self.act_dtype != torch.float32 and (self.mean_teacher or self.superpixel or self.classification):
-            raise NotImplementedError("bfloat16 activations are implemented for the supervised segmentation loss only")
+        # bfloat16 activations with the semi-supervised costs or the classification loss: those kernels take float32 logits,
+        # so the (small) logits tensor is widened in front of them and the summed gradient rounded once behind them
+        self._stage_logits = self.act_dtype != torch.float32 and (self.mean_teacher or self.superpixel or self.classification)
+        self._logits_f32 = self._dlogits_f32 = None
         if self.mean_teacher:
             self.input_names += ["mt_predictions", "consistency_cost"]
         if self.superpixel:
@@ -342,6 +344,10 @@ class ExtendedModel(object):
             self.sp_coef_buf = torch.zeros(1, dtype=torch.float32, device=dev)
             self._sp_cost_buf = torch.zeros(1, dtype=torch.float32, device=dev)
             self._sp_ws = None
+        if self._stage_logits:      # float32 copies of the logits and their gradient for the loss kernels (allocated here, not
+            shape = (n, self.num_classes) if self.classification else (n, h, w, self.num_classes)      # under a capture)
+            self._logits_f32 = torch.empty(shape, dtype=torch.float32, device=dev)
+            self._dlogits_f32 = torch.empty_like(self._logits_f32)
         self._num_labeled = n
         self.graph.plan(n, h, w)
         self._bufs_shape = (n, h, w)
@@ -411,33 +417,50 @@ class ExtendedModel(object):
             raise ValueError("metrics were built for {} unlabeled rows per batch, the batch has {} rows".format(nu_m, n))
         npix_m = (n - nu_m) * h * w if training else npix      # rows the confusion matrix covers
 
+        L32 = lib()      # the float32 entry points (L is the view of the activation type)
+
+        def staged_logits(st, want_grad):
+            """float32 logits / gradient buffers for the loss kernels below: the graph's own (float32 storage) or widened
+            copies (bfloat16 storage)."""
+            if not self._stage_logits:
+                return _ptr(g.logits), (_ptr(g.dlogits) if want_grad else None)
+            L32.cast_bf16_to_f32(_ptr(g.logits), _ptr(self._logits_f32), g.logits.numel(), st)
+            return _ptr(self._logits_f32), (_ptr(self._dlogits_f32) if want_grad else None)
+
+        def unstage_gradient(st, want_grad):
+            if self._stage_logits and want_grad:
+                L32.cast_f32_to_bf16(_ptr(self._dlogits_f32), _ptr(g.dlogits), g.dlogits.numel(), st)
+
         def loss_call_semi(st, want_grad):
             # classification cost over the labeled rows, metrics over every row (src/losses.py:416-422), then the
             # mean-teacher consistency cost over every row (:428) and / or the superpixel cost over the unlabeled rows
             # (:484), each added to the loss and to the logits gradient
             nl = self._num_labeled
             npl = nl * h * w
-            dl = _ptr(g.dlogits) if want_grad else None
-            L.softmax_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), npl, C_, 1.0, dl,
-                                   _ptr(self._loss_buf), _ptr(self._cm), npix_m, self._ignore_bits, None, _ptr(self._bad),
-                                   _ptr(g.ws), g.ws.numel() * 4, st)
+            lg, dl = staged_logits(st, want_grad)
+            L32.softmax_xent_fwd_bwd(lg, _ptr(self.labels_buf), _ptr(self.weights_buf), npl, C_, 1.0, dl,
+                                     _ptr(self._loss_buf), _ptr(self._cm), npix_m, self._ignore_bits, None, _ptr(self._bad),
+                                     _ptr(g.ws), g.ws.numel() * 4, st)
             if self.mean_teacher:
-                L.mt_consistency_fwd_bwd(_ptr(g.logits), _ptr(self.mt_buf), npix, C_, _ptr(self.coef_buf), 1.0, npl, dl,
-                                         _ptr(self._loss_buf), 1, _ptr(self._cost_buf), _ptr(g.ws), g.ws.numel() * 4, st)
+                L32.mt_consistency_fwd_bwd(lg, _ptr(self.mt_buf), npix, C_, _ptr(self.coef_buf), 1.0, npl, dl,
+                                           _ptr(self._loss_buf), 1, _ptr(self._cost_buf), _ptr(g.ws), g.ws.numel() * 4, st)
             if self.superpixel:
                 if nl < n:
                     off = npl * C_ * 4
-                    L.superpixel_cost_fwd_bwd(_ptr(g.logits) + off, _ptr(self.sp_mask_buf) + npl * 4, n - nl, h, w, C_,
-                                              _ptr(self.sp_coef_buf), 1.0, 10e-7, (dl + off) if want_grad else None,
-                                              1 if self.mean_teacher else 0, _ptr(self._loss_buf), 1, _ptr(self._sp_cost_buf),
-                                              _ptr(self._sp_ws), self._sp_ws.numel() * 4, st)
+                    L32.superpixel_cost_fwd_bwd(lg + off, _ptr(self.sp_mask_buf) + npl * 4, n - nl, h, w, C_,
+                                                _ptr(self.sp_coef_buf), 1.0, 10e-7, (dl + off) if want_grad else None,
+                                                1 if self.mean_teacher else 0, _ptr(self._loss_buf), 1, _ptr(self._sp_cost_buf),
+                                                _ptr(self._sp_ws), self._sp_ws.numel() * 4, st)
                 else:
-                    L.fill_f32(_ptr(self._sp_cost_buf), 0.0, 1, st)
+                    L32.fill_f32(_ptr(self._sp_cost_buf), 0.0, 1, st)
+            unstage_gradient(st, want_grad)
 
         def loss_call(st, want_grad):
             if self.classification:
-                L.classification_xent_fwd_bwd(_ptr(g.logits), _ptr(self.labels_buf), _ptr(self.weights_buf), n, C_, 10e-7, 1.0,
-                                              _ptr(g.dlogits) if want_grad else None, _ptr(self._loss_buf), st)
+                lg, dl = staged_logits(st, want_grad)
+                L32.classification_xent_fwd_bwd(lg, _ptr(self.labels_buf), _ptr(self.weights_buf), n, C_, 10e-7, 1.0,
+                                                dl, _ptr(self._loss_buf), st)
+                unstage_gradient(st, want_grad)
                 return
             if self.mean_teacher or self.superpixel:
                 return loss_call_semi(st, want_grad)
