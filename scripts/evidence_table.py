@@ -45,7 +45,7 @@ def uses_bf16_mfma(k, recs):
     if storage_type(k) != "bf16":
         return False
     base = short(k, strip_type=True)
-    m = re.match(r"^(conv_fwd_kernel<\d+, (?:true|false)), (?:true|false)(?:, \d+)?>$", base)
+    m = re.match(r"^(conv_fwd_kernel<\d+, (?:true|false))(?:, (?:true|false|\d+))?(?:, \d+)?>$", base)
     return bool(m) and any(r.startswith(m.group(1) + ">") and r.endswith("bf16 mfma") for r in recs)
 
 recs = json.load(open(out + "/conv_records.json"))
@@ -68,9 +68,9 @@ for k, (n, us, ms) in sorted(dur.items(), key=lambda kv: -kv[1][2]):
     bf = uses_bf16_mfma(k, recs)
     rec = recs.get(kb) or recs.get(kb + " bf16 mfma")
     if rec is None:      # trace names of the forward kernel carry the normalise-on-load flag, the library's records a suffix
-        m = re.match(r"^(conv_fwd_kernel<\d+, (?:true|false)), (true|false)(?:, \d+)?>$", kb)
+        m = re.match(r"^(conv_fwd_kernel<\d+, (?:true|false))(?:, (true|false|\d+))?(?:, \d+)?>$", kb)
         if m:
-            key = m.group(1) + ">" + (" prebn" if m.group(2) == "true" else "")
+            key = m.group(1) + ">" + {"true": " prebn", "1": " prebn", "2": " premerge"}.get(m.group(2) or "", "")
             rec = recs.get(key + " bf16 mfma" if bf else key) or recs.get(key)
     gf = rec["flops_per_step"] / max(rec["launches_per_step"], 1) / 1e9 if rec else None
     c = pmc.get(k)
