@@ -353,7 +353,7 @@ TILED_CASES = [  # cin, cout, N, H, W: 3x3 / stride 1 / SAME layers the LDS-tile
 ]
 
 
-def _packed_conv(eng, L0, cin, cout, w, b, packed, N, H, W, st):
+def _packed_conv(eng, L0, cin, cout, w, b, packed, N, H, W, st, x_ld=None, y_ld=None):
     store = eng.ParamStore(torch.bfloat16)
     cv = eng.Conv(store, "c", 3, 3, cin, cout, stride=1, dil=1, padding="same", bias=b is not None)
     bn_out = eng.BatchNorm(store, "bn", cout)
@@ -361,7 +361,7 @@ def _packed_conv(eng, L0, cin, cout, w, b, packed, N, H, W, st):
     bn_in.add_prelu(store, "pr")
     store.materialise(torch.device(DEV))
     store.init_values(1)
-    cv.plan(N, H, W)
+    cv.plan(N, H, W, x_ld=x_ld, y_ld=y_ld)
     bn_out.plan(torch.device(DEV))
     bn_in.plan(torch.device(DEV))
     store.views["c/kernel"].copy_(torch.from_numpy(w if packed else _bf(w)))
@@ -473,6 +473,51 @@ def test_conv3x3_tiled_bf16_kernel(case):
     # the apply pass runs on da (equal up to single bfloat16 steps) with coefficients equal to 2e-4
     d = np.abs(got["dxb"] - ref["dxb"])
     assert d.max() <= 2e-2 * np.abs(ref["dxb"]).max() and (d > 0).mean() <= 5e-2, (d.max(), (d > 0).mean())
+
+
+def test_conv3x3_tiled_bf16_kernels_on_channel_slices():
+    """The tiled kernels on channel slices of wider buffers (pixel strides larger than the channel counts, as the descriptor
+    allows): forward with statistics, data gradient and weight gradient read and write only their slice."""
+    eng, L0 = pkg("engine"), pkg("_lib")
+    cin, cout, N, H, W, xl, yl, x0, y0 = 64, 128, 2, 32, 32, 96, 192, 16, 64
+    rng = np.random.RandomState(5)
+    xb = _bf(rng.standard_normal((N, H, W, xl)))
+    w = rng.standard_normal((3, 3, cin, cout)).astype(np.float32) * np.sqrt(2.0 / (9 * cin))
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    dyb = _bf(rng.standard_normal((N, H, W, yl)))
+    st = torch.cuda.current_stream().cuda_stream
+    outs = {}
+    for packed in (False, True):
+        store, cv, bn_out, _, keep = _packed_conv(eng, L0, cin, cout, w, b, packed, N, H, W, st, x_ld=xl, y_ld=yl)
+        xd, dyd = _dev(xb, torch.bfloat16), _dev(dyb, torch.bfloat16)
+        y = torch.full((N, H, W, yl), 7.0, dtype=torch.bfloat16, device=DEV)
+        dx = torch.full((N, H, W, xl), 7.0, dtype=torch.bfloat16, device=DEV)
+        ws = torch.empty(max(cv.ws_bytes, 1 << 20) // 4 + 64, device=DEV)
+        xs, ys, dys, dxs = xd[..., x0:], y[..., y0:], dyd[..., y0:], dx[..., x0:]      # slices: only their first element's address is used
+        cv.fwd_bn(xs, ys, bn_out, N * H * W, True, False, False, ws, st)
+        n1 = store.L.last_kernel()
+        cv.bwd_data(dys, dxs, st)
+        n2 = store.L.last_kernel()
+        store.grad.zero_()
+        cv.bwd_weight(xs, dys, ws, st)
+        n3 = store.L.last_kernel()
+        torch.cuda.synchronize()
+        f = lambda t: t.float().cpu().numpy()
+        outs[packed] = dict(y=f(y), dx=f(dx), mean=f(bn_out.mean), dw=cv.dw.cpu().numpy().astype(np.float64), names=(n1, n2, n3))
+        del keep
+    ref, got = outs[False], outs[True]
+    assert all(b"tiled" in n or b"wgrad_patch" in n for n in got["names"]), got["names"]
+    for k, lo, hi in (("y", y0, y0 + cout), ("dx", x0, x0 + cin)):
+        a, r_ = got[k], ref[k]
+        assert np.all(a[..., :lo] == 7.0) and np.all(a[..., hi:] == 7.0), k + ": wrote outside its channel slice"
+        d = np.abs(a[..., lo:hi] - r_[..., lo:hi])
+        assert np.all(d <= np.abs(r_[..., lo:hi]) * 2.0 ** -7 + 2.0 ** -8 * 1e-2 * np.abs(r_).max()) and (d > 0).mean() <= 2e-2, k
+    np.testing.assert_allclose(got["mean"], ref["mean"], rtol=1e-5, atol=1e-6)
+    xp = np.pad(xb[..., x0:x0 + cin].astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    dyv = dyb[..., y0:y0 + cout].astype(np.float64)
+    ref_dw = np.stack([np.stack([np.einsum("nyxi,nyxo->io", xp[:, ky:ky + H, kx:kx + W], dyv) for kx in range(3)]) for ky in range(3)])
+    for k in (False, True):
+        assert np.abs(outs[k]["dw"] - ref_dw).max() <= 2e-5 * np.abs(ref_dw).max()
 
 
 def _compiled(name, w0, lr=5e-4, dtype="bf16"):
