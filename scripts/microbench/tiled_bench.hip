@@ -5,6 +5,8 @@
 #include "../../semantic-segmentation_amd/csrc/conv_tiled.hip"
 #include <stdarg.h>
 #include <vector>
+#include <cmath>
+#include <cstring>
 namespace ssmi {
 void set_last_kernel(const char*, ...) {}
 void set_error(const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); }
@@ -20,7 +22,15 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&w, (size_t)9 * 1024 * 1024 * 2)); CK(hipMalloc(&part, (size_t)8192 * 3 * 1024 * 4)); CK(hipMalloc(&par, 8 * 1024 * 4));
   // small finite values: 0x3c00 = bf16 0.0078125-ish patterns; fill with a repeating pattern of bf16(0.5)/bf16(-0.25)
   std::vector<unsigned short> h(max_act / 2);
-  for (size_t i = 0; i < h.size(); ++i) h[i] = (i * 2654435761u >> 28) & 1 ? 0x3f00 : 0xbe80;
+  const bool random_data = argc > 1 && argv[1][0] == 'r';      // "r": normally distributed values (what a network holds) instead of a two-valued pattern
+  unsigned long long sd = 88172645463325252ull;
+  auto rnd = [&]() { sd ^= sd << 13; sd ^= sd >> 7; sd ^= sd << 17; return (double)(sd >> 11) / 9007199254740992.0; };
+  for (size_t i = 0; i < h.size(); ++i) {
+    if (!random_data) { h[i] = (i * 2654435761u >> 28) & 1 ? 0x3f00 : 0xbe80; continue; }
+    const float v = (float)(std::sqrt(-2.0 * std::log(rnd() + 1e-300)) * std::cos(6.283185307179586 * rnd())) * 0.5f;
+    unsigned u; memcpy(&u, &v, 4);
+    h[i] = (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+  }
   CK(hipMemcpy(x, h.data(), max_act, hipMemcpyHostToDevice)); CK(hipMemcpy(bx, h.data(), max_act, hipMemcpyHostToDevice));
   CK(hipMemcpy(w, h.data(), (size_t)9 * 1024 * 1024 * 2, hipMemcpyHostToDevice));
   std::vector<float> hp(8 * 1024, 0.5f);
