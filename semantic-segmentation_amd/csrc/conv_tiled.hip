@@ -569,7 +569,10 @@ WgPatchPlan plan_wg_patch_bf16(int n, int h, int w, int cin, int cout, int kh, i
   p.K_aug = p.K + (with_bias ? 1 : 0);
   p.ntiles = n * (h / kWgTH) * (w / 16);
   const int nblocks = (cin / 64) * (cout / 64);
-  int shares = 512 / nblocks;                                      // one round of two workgroups per CU
+  static const int target = getenv("SSMI_WG_PATCH_WGS") ? atoi(getenv("SSMI_WG_PATCH_WGS")) : 256;      // measurement switch
+  // one workgroup per CU: inside the step (beside the main chain) 256 measured best - 384 / 512 / 768 / 1024: +0.02 / +0.15 /
+  // +0.33 / +0.55 ms on SegNet, 128: +0.3 (every share writes a full partial dW, and the main chain needs room on the CUs)
+  int shares = target / nblocks;
   if (shares > p.ntiles / 2) shares = p.ntiles / 2;                // at least two tiles per workgroup
   if (shares < 1) shares = 1;
   p.tiles_per_share = (p.ntiles + shares - 1) / shares;
