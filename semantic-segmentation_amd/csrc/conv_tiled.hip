@@ -1,5 +1,5 @@
 // LDS-tiled implicit GEMM for the wide 3x3 layers of U-Net / SegNet with bfloat16 storage (stride 1, dilation 1, SAME
-// padding, input channels in whole 32-blocks, output channels in whole 64-blocks, height and width multiples of 16):
+// padding, input channels in whole 32-blocks, output channels in whole 64-blocks; any map size, border tiles are masked):
 //   y[p, co] = bias[co] + sum_{tap, ci} x[pix(p, tap), ci] * w[tap, ci, co]      on v_mfma_f32_32x32x16_bf16.
 // Both operands go through LDS.  A workgroup (256 threads, four waves) owns a 16 x 16 tile of output pixels of one image and
 // BN = 128 or 64 output channels.  For every 32-channel chunk of the input it stages the tile's 18 x 18 halo patch ONCE
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   const int wm = wave / WN, wn = wave % WN;
 
   // tile coordinates
-  const int tiles_x = a.w / kTW, tiles_y = a.h / TH;
+  const int tiles_x = (a.w + kTW - 1) / kTW, tiles_y = (a.h + TH - 1) / TH;      // border tiles may be partial
   const int ncb = a.cout / BN;
   // The workgroups of one XCD (b and b + 8 share one, and its L2) take a contiguous range of (tile, column block) pairs,
   // column block fastest: the column blocks of a tile re-read its patch from that L2, neighbouring tiles share halo rows.
@@ -227,9 +227,13 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   const bool has_add = kAdd && a.bn.add != nullptr;
   const __amdgpu_buffer_rsrc_t radd = make_rsrc(has_add ? a.bn.add : (const void*)a.y, has_add ? (unsigned)((int64_t)a.n * a.h * a.w * a.y_ld * 2) : 0u);
   const __amdgpu_buffer_rsrc_t rbx = make_rsrc(has_bn ? a.bn.x : (const void*)a.y, has_bn ? (unsigned)((int64_t)a.n * a.h * a.w * a.bn.ld * 2) : 0u);
-  auto pixel_of = [&](int q, int j) {                 // global pixel index of item j of pass q
+  auto pixel_of = [&](int q, int j) {                 // global pixel index of item j of pass q, kOOB for a pixel past the border
     const int tp = 64 * q + pl + j * PL;
-    return (unsigned)((img * a.h + y0 + (tp >> 4)) * a.w + x0 + (tp & 15));
+    const int yy = y0 + (tp >> 4), xx = x0 + (tp & 15);
+    return (yy < a.h && xx < a.w) ? (unsigned)((img * a.h + yy) * a.w + xx) : kOOB;
+  };
+  auto at = [&](unsigned gp, unsigned ld) {           // byte offset of this thread's channels of pixel gp (out of range for kOOB)
+    return gp == kOOB ? kOOB : (gp * ld + (unsigned)co) * 2u;
   };
   // what the data-gradient epilogue reads per element is requested one pass ahead (two register sets): the wait for it
   // would otherwise be paid four times per tile
@@ -239,8 +243,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
 #pragma unroll
       for (int j = 0; j < ITEMS; ++j) {
         const unsigned gp = pixel_of(q, j);
-        xin[q & 1][j] = Row<CW>::ld(rbx, (gp * (unsigned)a.bn.ld + (unsigned)co) * 2u);
-        if constexpr (kAdd) ain[q & 1][j] = Row<CW>::ld(radd, (gp * (unsigned)a.y_ld + (unsigned)co) * 2u);
+        xin[q & 1][j] = Row<CW>::ld(rbx, at(gp, (unsigned)a.bn.ld));
+        if constexpr (kAdd) ain[q & 1][j] = Row<CW>::ld(radd, at(gp, (unsigned)a.y_ld));
       }
     }
   };
@@ -270,6 +274,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
     for (int j = 0; j < ITEMS; ++j) {
       const int lp = pl + j * PL;                     // pixel of this pass
       const unsigned gp = pixel_of(q, j);
+      const float live = gp == kOOB ? 0.f : 1.f;      // pixels past the border add nothing to the fused sums and are not stored
       float v[CW];
 #pragma unroll
       for (int e4 = 0; e4 < CW / 4; ++e4) {
@@ -280,8 +285,9 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
       if constexpr (EPI == 1) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) {
-          sums[0][e] += v[e];
-          sums[1][e] += v[e] * v[e];
+          const float vv = v[e] * live;
+          sums[0][e] += vv;
+          sums[1][e] += vv * vv;
         }
       }
       if constexpr (kDgrad) {
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
 #pragma unroll
           for (int e = 0; e < CW; ++e) dr[e] = 1.f;
           if (a.bn.drop) {
-            const float* dp = a.bn.drop + (size_t)(gp / a.bn.hw) * (unsigned)a.cout + (unsigned)co;
+            const float* dp = a.bn.drop + (size_t)((gp == kOOB ? 0u : gp) / a.bn.hw) * (unsigned)a.cout + (unsigned)co;
 #pragma unroll
             for (int e = 0; e < CW; ++e) dr[e] = dp[e];
           }
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
           for (int e = 0; e < CW; ++e) {
             const unsigned wx = xin[q & 1][j][e >> 1];
             const float xr = __builtin_bit_cast(float, (e & 1) ? (wx & 0xFFFF0000u) : (wx << 16));
-            const float d = v[e] * dr[e];
+            const float d = v[e] * dr[e] * live;
             const float xh = (xr - mu[e]) * is[e];
             const float z = ga[e] * xh + be[e];
             const float gr = a.bn.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? alp[e] : 0.f));
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
       typename Row<CW>::raw o;
 #pragma unroll
       for (int e2 = 0; e2 < CW / 2; ++e2) o[e2] = pack_bf16x2(v[2 * e2], v[2 * e2 + 1]);
-      if (!(TILED_ABLATE & 2) || o[0] == 0x12345678u) Row<CW>::st(ry, (gp * (unsigned)a.y_ld + (unsigned)co) * 2u, o);
+      if (!(TILED_ABLATE & 2) || o[0] == 0x12345678u) Row<CW>::st(ry, at(gp, (unsigned)a.y_ld), o);
     }
   }
   float* dst = EPI == 1 ? a.part : (has_bn ? a.bn.part : nullptr);
@@ -353,8 +359,8 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
 bool conv_tiled_bf16_ok(int h, int w, int cin, int cout, int kh, int kw, int stride, int dil, int pad_t, int pad_l, int ho, int wo,
                         int x_ld, int y_ld) {
   static const bool off = getenv("SSMI_NO_TILED_BF16") != nullptr;      // measurement switch
-  return !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h % 16 == 0 &&
-         w % kTW == 0 && cin % 32 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;
+  return !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h >= 8 && w >= 8 &&
+         cin % 32 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;      // any map size: border tiles are masked
 }
 
 // Launches the tiled kernel.  part != nullptr: statistics epilogue; bn.add / bn.x: data-gradient epilogue.  *part_rows
@@ -380,8 +386,12 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
   // take 8-row tiles
   static const int below = getenv("SSMI_TILED_TH8_BELOW") ? atoi(getenv("SSMI_TILED_TH8_BELOW")) : 512;      // measurement switch
   // (the addend epilogue needs a second prefetch set and exceeds the 16-row variant's register budget: 8-row tiles always)
-  const int th = (epi == 3 || n * (h / 16) * (w / kTW) * (cout / bn_cols) < below) ? 8 : 16;
-  const int tiles = n * (h / th) * (w / kTW);
+  const int tx_n = (w + kTW - 1) / kTW;
+  const int th = (epi == 3 || h % 16 == 8 || n * ((h + 15) / 16) * tx_n * (cout / bn_cols) < below) ? 8 : 16;
+  const int tiles = n * ((h + th - 1) / th) * tx_n;
+  // one row of partial sums per tile: the callers' workspaces hold ceil(pixels / 128) + 1024 rows (narrow maps with many
+  // partial tiles could exceed that: those go to the direct kernel)
+  if ((part != nullptr || bn.x != nullptr) && tiles > ((int64_t)n * h * w + 127) / 128 + 1024) return SSMI_E_UNSUPPORTED;
   if (part_rows) *part_rows = tiles;
   dim3 grid((unsigned)(tiles * (cout / bn_cols)), 1, 1);
   const size_t lds = (size_t)(th + 2) * kPW * kRowB + 2 * (size_t)bn_cols * kRowB;
@@ -400,8 +410,8 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Weight gradient of the same layers (3x3, stride 1, SAME, bfloat16 storage; input and output channels in whole 64-blocks,
-// height a multiple of 8, width of 16):
+// Weight gradient of the same layers (3x3, stride 1, SAME, bfloat16 storage; input and output channels in whole 64-blocks;
+// any map size: dy rows past the border read zeros):
 //   dw[tap][ci][co] = sum_pixels x[pixel + tap][ci] * dy[pixel][co]        db[co] = sum_pixels dy[pixel][co]
 // A workgroup owns a 64 x 64 block of (ci, co) for all nine taps and a range of 8 x 16 pixel tiles.  Per tile it stages the
 // 10 x 18 halo patch of x (64 channels) and the dy tile (64 channels) in LDS ONCE - the strip kernels gather x once per tap -
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_patch_bf16(WgPatchArgs a
   const int blk = (int)(v % (unsigned)(nbi * nbo)), share = (int)(v / (unsigned)(nbi * nbo));
   const int bi = blk % nbi, bo = blk / nbi;
   const int t_begin = share * a.tiles_per_share, t_end = min(a.ntiles, t_begin + a.tiles_per_share);
-  const int tiles_x = a.w >> 4, tiles_y = a.h / kWgTH;
+  const int tiles_x = (a.w + 15) >> 4, tiles_y = (a.h + kWgTH - 1) / kWgTH;      // border tiles: dy rows past the border read zeros
 
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((int64_t)a.n * a.h * a.w * a.x_ld * 2));
   const __amdgpu_buffer_rsrc_t rdy = make_rsrc(a.dy, (unsigned)((int64_t)a.n * a.h * a.w * a.y_ld * 2));
@@ -462,10 +472,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_patch_bf16(WgPatchArgs a
     al[j] = pix < kWgPH * kWgPW ? (unsigned)(pix * kWgRowB + (idx & 7) * 16) : 0xFFFFFFFFu;
   }
   unsigned brel[BRND], bl[BRND];
+  int bpy[BRND], bpx[BRND];
 #pragma unroll
   for (int j = 0; j < BRND; ++j) {
     const int idx = tid + 256 * j, pix = idx >> 3;      // tile pixel: row pix >> 4, column pix & 15
-    brel[j] = (unsigned)(((pix >> 4) * a.w + (pix & 15)) * a.y_ld + bo * 64 + (idx & 7) * 8) * 2u;
+    bpy[j] = pix >> 4;
+    bpx[j] = pix & 15;
+    brel[j] = (unsigned)((bpy[j] * a.w + bpx[j]) * a.y_ld + bo * 64 + (idx & 7) * 8) * 2u;
     bl[j] = (unsigned)(pix * kWgRowB + (idx & 7) * 16);
   }
   u32x4 areg[ARND], breg[BRND];
@@ -484,7 +497,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_patch_bf16(WgPatchArgs a
     const unsigned base = (unsigned)(((img * a.h + y0) * a.w + x0) * a.y_ld) * 2u;
 #pragma unroll
     for (int j = 0; j < BRND; ++j)
-      breg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rdy, tv ? base + brel[j] : kOOB, 0, 0));
+      breg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+          rdy, (tv && y0 + bpy[j] < a.h && x0 + bpx[j] < a.w) ? base + brel[j] : kOOB, 0, 0));
   };
 
   f32x16 acc[3][3];
@@ -562,12 +576,12 @@ WgPatchPlan plan_wg_patch_bf16(int n, int h, int w, int cin, int cout, int kh, i
                                int ho, int wo, int x_ld, int y_ld, bool with_bias) {
   static const bool off = getenv("SSMI_NO_WG_PATCH") != nullptr;      // measurement switch
   WgPatchPlan p{};
-  p.use = !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h % kWgTH == 0 &&
-          w % 16 == 0 && cin % 64 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;
+  p.use = !off && kh == 3 && kw == 3 && stride == 1 && dil == 1 && pad_t == 1 && pad_l == 1 && ho == h && wo == w && h >= 8 && w >= 8 &&
+          cin % 64 == 0 && cout % 64 == 0 && x_ld % 8 == 0 && y_ld % 8 == 0;      // any map size: border tiles are masked
   if (!p.use) return p;
   p.K = 9 * cin;
   p.K_aug = p.K + (with_bias ? 1 : 0);
-  p.ntiles = n * (h / kWgTH) * (w / 16);
+  p.ntiles = n * ((h + kWgTH - 1) / kWgTH) * ((w + 15) / 16);
   const int nblocks = (cin / 64) * (cout / 64);
   static const int target = getenv("SSMI_WG_PATCH_WGS") ? atoi(getenv("SSMI_WG_PATCH_WGS")) : 256;      // measurement switch
   // one workgroup per CU: inside the step (beside the main chain) 256 measured best - 384 / 512 / 768 / 1024: +0.02 / +0.15 /

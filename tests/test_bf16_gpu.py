@@ -350,6 +350,8 @@ TILED_CASES = [  # cin, cout, N, H, W: 3x3 / stride 1 / SAME layers the LDS-tile
     (192, 64, 3, 48, 32), (128, 128, 5, 16, 48),
     # large enough for 16-row tiles (the cases above run on 8-row tiles: fewer than 512 workgroups otherwise)
     (64, 64, 2, 256, 256), (128, 128, 8, 128, 128),
+    # map sizes that are not multiples of the tile: masked border tiles (120 x 160 is the third level of a 480 x 640 input)
+    (64, 64, 2, 24, 40), (128, 128, 1, 30, 50), (64, 128, 3, 9, 17), (64, 64, 1, 120, 160), (64, 64, 2, 250, 270),
 ]
 
 
