@@ -1,16 +1,17 @@
 // LDS-tiled implicit GEMM for the wide 3x3 layers of U-Net / SegNet with bfloat16 storage (stride 1, dilation 1, SAME
 // padding, input channels in whole 32-blocks, output channels in whole 64-blocks; any map size, border tiles are masked):
 //   y[p, co] = bias[co] + sum_{tap, ci} x[pix(p, tap), ci] * w[tap, ci, co]      on v_mfma_f32_32x32x16_bf16.
-// Both operands go through LDS.  A workgroup (256 threads, four waves) owns a 16 x 16 tile of output pixels of one image and
-// BN = 128 or 64 output channels.  For every 32-channel chunk of the input it stages the tile's 18 x 18 halo patch ONCE
-// (80-byte pixel rows: 64 bytes of channels + 16 of padding against bank conflicts) and then walks the nine taps: a tap only
-// shifts the window the A fragments are read from, so the nine taps re-read LDS, not L2.  The kernel rows of a step
-// (tap, chunk) - [BN couts][32 channels] from the pack [tap][cout][cin] - are staged in a second, double-buffered area, the
-// next step's rows (and, once per chunk, the next patch) in flight in registers while the current step is multiplied.
-// Waves split the tile 2 x 2 (BN = 128: 128 pixels x 64 couts each, 8 accumulator tiles) or 4 x 1 (BN = 64: 64 x 64 each),
+// Both operands go through LDS.  A workgroup (256 threads, four waves) owns a TH x 16 tile of output pixels of one image
+// (TH = 16, or 8 for layers that would otherwise launch fewer than two workgroups per CU) and BN = 128 or 64 output channels.
+// For every 32-channel chunk of the input it stages the tile's (TH + 2) x 18 halo patch ONCE (80-byte pixel rows: 64 bytes of
+// channels + 16 of padding against bank conflicts) and then walks the nine taps: a tap only shifts the window the A fragments
+// are read from, so the nine taps re-read LDS, not L2.  The kernel rows of a step (tap, chunk) - [BN couts][32 channels] from
+// the pack [tap][cout][cin] - are staged in a second, double-buffered area; they are requested three steps ahead into a ring
+// of register sets, the next chunk's patch nine steps ahead.
+// Waves split the tile 2 x 2 (BN = 128, TH = 16: 128 pixels x 64 couts each, 8 accumulator tiles) or 4 x 1 (BN = 64),
 // which keeps LDS reads per matrix instruction at 0.75 - 1 ds_read_b128.
 // Epilogue: the accumulators go through LDS once more (float32, 64 pixels per pass) so that bias, rounding, the stores and
-// the fused reductions run in the elementwise layout - a thread owns eight consecutive channels of a pixel, 16-byte accesses:
+// the fused reductions run in the elementwise layout - a thread owns four consecutive channels of a pixel, 8-byte accesses:
 //   EPI 1  BatchNormalization statistics: per-workgroup column sums of y and y^2 (unrounded) -> part[tile][2][cout]
 //   EPI 2  data-gradient form (forward convolution over dy with the data-gradient pack) with the BatchNormalization
 //          backward sums of the layer in front (dz, dz * xhat, d * min(z, 0)) -> bn.part[tile][3][cout]
@@ -420,7 +421,8 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
 // registers.  Operands come from the transposing LDS read (ds_read_tr16_b64: pixels become the reduction dimension), rows
 // are 192 bytes (128 of channels + 64 of padding: the four pixel rows and two channel halves of one read fall into distinct
 // banks).  Four waves split the block 2 x 2 (32 x 32 x 9 taps = 144 accumulator registers each).  The next tile's rows
-// travel in registers while the current one is multiplied; two workgroups per CU cover each other's load latency.
+// travel in registers while the current one is multiplied (two workgroups fit a CU; the launch is sized to about one per CU,
+// which measured best beside the main chain of a training step).
 // Output: partial sums part[share][K_aug][cout] (k = tap * cin + ci, row K = bias gradient), summed by the caller's
 // reduction kernel.
 // ---------------------------------------------------------------------------------------------------------------------
