@@ -87,19 +87,19 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, (unsigned)((int64_t)a.n * a.h * a.w * a.x_ld * 2));
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpack, (unsigned)((int64_t)9 * a.cout * a.cin * 2));
 
-  // staging roles.  Patch: 324 pixels x four 16-byte pieces = 1296 pieces, six rounds of 256 threads (the last one partial)
+  // staging roles.  Patch: (TH + 2) x 18 pixels x four 16-byte pieces (TH = 16: 1296 pieces, six rounds of 256 threads, the last
+  // one partial).  Round j of a thread handles piece tid + 256 j: its LDS slot is a constant away from round 0's, its global
+  // offset is recomputed per chunk (a dozen integer instructions per nine steps; kept in registers the six offsets and
+  // six slots cost the 128-wide variant the registers it needs to read fragments ahead of the matrix instructions)
   constexpr int ARND = (kPatchPix * 4 + 255) / 256;
-  unsigned ag[ARND], al[ARND];
-#pragma unroll
-  for (int j = 0; j < ARND; ++j) {
-    const int idx = tid + 256 * j;
-    const int pix = idx >> 2, piece = idx & 3;
+  const unsigned al0 = (unsigned)((tid >> 2) * kRowB + (tid & 3) * 16);
+  auto a_offset = [&](int j) -> unsigned {
+    const int pix = (tid >> 2) + 64 * j;
     const int py = pix / kPW, px = pix - py * kPW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
     const bool ok = pix < kPatchPix && (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-    ag[j] = ok ? (unsigned)(((img * a.h + iy) * a.w + ix) * a.x_ld) * 2u + (unsigned)piece * 16u : kOOB;
-    al[j] = pix < kPatchPix ? (unsigned)(pix * kRowB + piece * 16) : 0xFFFFFFFFu;      // no LDS slot: skipped at the commit
-  }
+    return ok ? (unsigned)(((img * a.h + iy) * a.w + ix) * a.x_ld) * 2u + (unsigned)(tid & 3) * 16u : kOOB;
+  };
   constexpr int BRND = BN / 64;                      // kernel rows: BN x four pieces / 256 threads
   unsigned bg[BRND], bl[BRND];
 #pragma unroll
@@ -134,13 +134,15 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
   u32x4 areg[ARND], breg[3][BRND];
   auto load_a = [&](int chunk) {
 #pragma unroll
-    for (int j = 0; j < ARND; ++j)
-      areg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (ag[j] + (unsigned)chunk * 64u) | (ag[j] & kOOB), 0, 0));
+    for (int j = 0; j < ARND; ++j) {
+      const unsigned o = a_offset(j);
+      areg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (o + (unsigned)chunk * 64u) | (o & kOOB), 0, 0));
+    }
   };
   auto commit_a = [&]() {
 #pragma unroll
     for (int j = 0; j < ARND; ++j)
-      if (al[j] != 0xFFFFFFFFu) *reinterpret_cast<u32x4*>(As + al[j]) = areg[j];
+      if ((tid >> 2) + 64 * j < kPatchPix) *reinterpret_cast<u32x4*>(As + al0 + j * (64 * kRowB)) = areg[j];
   };
   // The kernel rows of a step come out of L2 with more latency than a step of matrix work takes: they are requested three
   // steps ahead into a ring of three register sets (slot = tap % 3; nine taps per chunk keep the slots aligned over chunks).
