@@ -62,8 +62,12 @@ template <int BN, int WM, int WN, int EPI, int TH>
 __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(TiledArgs a) {
   constexpr int kPatchPix = (TH + 2) * kPW, kABytes = kPatchPix * kRowB, BM = TH * kTW;      // 16 rows: 324 pixels, 25920 bytes
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const As = smem;
-  unsigned char* const Bs = smem + kABytes;          // two buffers of BN * kRowB bytes
+  // The 128-wide variants keep TWO patch images: the next chunk's patch is then fetched and committed in two halves in the
+  // middle of the current chunk (half the staging registers, no extra barrier at the chunk boundary).  The 64-wide variants
+  // have the registers and want three workgroups per CU, i.e. the smaller LDS footprint.
+  constexpr bool ADB = BN == 128;
+  constexpr int kABufs = ADB ? 2 : 1;
+  unsigned char* const Bs = smem + kABufs * kABytes;   // two buffers of BN * kRowB bytes
   constexpr int kBBytes = BN * kRowB;
   constexpr int WPX = BM / WM;                       // pixels per wave
   constexpr int MT = WPX / 32, NTL = BN / WN / 32;
@@ -131,18 +135,22 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
       for (int i = 0; i < 16; ++i) acc[m][q][i] = 0.f;
 
   const int nchunks = (TILED_ABLATE & 1) ? 0 : a.cin >> 5;
-  u32x4 areg[ARND], breg[3][BRND];
-  auto load_a = [&](int chunk) {
+  constexpr int AH = ADB ? (ARND + 1) / 2 : ARND;      // staging rounds held in registers at a time
+  u32x4 areg[AH], breg[3][BRND];
+  auto load_a = [&](int chunk, int j0) {              // rounds j0 .. j0 + AH - 1 of the patch of `chunk`
 #pragma unroll
-    for (int j = 0; j < ARND; ++j) {
-      const unsigned o = a_offset(j);
+    for (int j = 0; j < AH; ++j) {
+      if (j0 + j >= ARND) break;
+      const unsigned o = a_offset(j0 + j);
       areg[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, (o + (unsigned)chunk * 64u) | (o & kOOB), 0, 0));
     }
   };
-  auto commit_a = [&]() {
+  auto commit_a = [&](unsigned char* dst, int j0) {
 #pragma unroll
-    for (int j = 0; j < ARND; ++j)
-      if ((tid >> 2) + 64 * j < kPatchPix) *reinterpret_cast<u32x4*>(As + al0 + j * (64 * kRowB)) = areg[j];
+    for (int j = 0; j < AH; ++j) {
+      if (j0 + j >= ARND) break;
+      if ((tid >> 2) + 64 * (j0 + j) < kPatchPix) *reinterpret_cast<u32x4*>(dst + al0 + (j0 + j) * (64 * kRowB)) = areg[j];
+    }
   };
   // The kernel rows of a step come out of L2 with more latency than a step of matrix work takes: they are requested three
   // steps ahead into a ring of three register sets (slot = tap % 3; nine taps per chunk keep the slots aligned over chunks).
@@ -157,22 +165,35 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
     for (int j = 0; j < BRND; ++j) *reinterpret_cast<u32x4*>(Bs + buf * kBBytes + bl[j]) = breg[slot][j];
   };
 
-  load_a(0);
-  load_b(0, 0, 0);
-  load_b(1, 1, 0);
-  load_b(2, 2, 0);
-  commit_a();
+  {      // first patch: every round at once (these registers are free again before the loop)
+    u32x4 first[ARND];
+#pragma unroll
+    for (int j = 0; j < ARND; ++j) first[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_offset(j), 0, 0));
+    load_b(0, 0, 0);
+    load_b(1, 1, 0);
+    load_b(2, 2, 0);
+#pragma unroll
+    for (int j = 0; j < ARND; ++j)
+      if ((tid >> 2) + 64 * j < kPatchPix) *reinterpret_cast<u32x4*>(smem + al0 + j * (64 * kRowB)) = first[j];
+  }
   commit_b(0, 0);
   __syncthreads();
 
-  int buf = 0;
+  int buf = 0, abuf = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     const bool more = chunk + 1 < nchunks;
-    if (more) load_a(chunk + 1);                      // in flight under the nine taps of this chunk
+    const unsigned char* const As = smem + abuf * kABytes;
+    unsigned char* const Anext = smem + (kABufs - 1 - abuf) * kABytes;      // (the same image with a single buffer)
+    if (!ADB && more) load_a(chunk + 1, 0);           // in flight under the nine taps of this chunk
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const bool last = tap == 8;
       load_b(tap % 3, (tap + 3) % 9, chunk + (tap + 3) / 9);      // this slot's rows went to LDS at the end of the previous step
+      if constexpr (ADB) {                            // next patch: first half requested at tap 0, second at tap 3
+        if (more && tap == 0) load_a(chunk + 1, 0);
+        if (more && tap == 3) { commit_a(Anext, 0); load_a(chunk + 1, AH); }
+        if (more && tap == 6) commit_a(Anext, AH);
+      }
       const unsigned toff = (unsigned)(((tap / 3) * kPW + (tap % 3)) * kRowB);
       const unsigned char* bsrc = Bs + buf * kBBytes;
 #pragma unroll
@@ -188,13 +209,14 @@ __global__ __launch_bounds__(256, BN == 64 ? 3 : 2) void conv3x3_tiled_bf16(Tile
           for (int q = 0; q < NTL; ++q) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[q], acc[m][q], 0, 0, 0);
       }
       commit_b((tap + 1) % 3, buf ^ 1);               // the next step's rows into the buffer nobody reads during this step
-      if (last && more) {
+      if (!ADB && last && more) {
         __syncthreads();                              // every wave is done with this chunk's patch
-        commit_a();
+        commit_a(smem, 0);
       }
       __syncthreads();
       buf ^= 1;
     }
+    if constexpr (ADB) abuf ^= 1;
   }
 
   // ---- epilogue through LDS: 64 pixels per pass, float32 rows of BN values + 16 bytes of padding ----
@@ -397,7 +419,7 @@ ssmi_status launch_conv_tiled_bf16(int n, int h, int w, int cin, int cout, int x
   if ((part != nullptr || bn.x != nullptr) && tiles > ((int64_t)n * h * w + 127) / 128 + 1024) return SSMI_E_UNSUPPORTED;
   if (part_rows) *part_rows = tiles;
   dim3 grid((unsigned)(tiles * (cout / bn_cols)), 1, 1);
-  const size_t lds = (size_t)(th + 2) * kPW * kRowB + 2 * (size_t)bn_cols * kRowB;
+  const size_t lds = (size_t)(wide ? 2 : 1) * (th + 2) * kPW * kRowB + 2 * (size_t)bn_cols * kRowB;      // two patch images for the 128-wide variants
 #define LT(BN_, WM_, WN_, E_)                                                                                                  \
   do {                                                                                                                          \
     if (th == 16) hipLaunchKernelGGL((conv3x3_tiled_bf16<BN_, WM_, WN_, E_, (E_ == 3 ? 8 : 16)>), grid, dim3(256), lds, st, a); \
