@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void merge_bwd_other(const T* __restrict__ dsu
   }
 }
 
-static ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64_t npix, const float* gamma,
+ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64_t npix, const float* gamma,
                                        const float* invstd, float* dgamma, float* dbeta, float* dalpha, float* coef,
                                        hipStream_t st) {
   SSMI_REQUIRE((int64_t)rows * 3 * c * 4 < 0x7FFFFFFFLL, SSMI_E_UNSUPPORTED, "bn backward: partial-sum table too large");

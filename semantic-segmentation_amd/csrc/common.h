@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <initializer_list>
 #include <string>
 
 #include "../../include/ssmi.h"
@@ -47,6 +48,11 @@ void set_last_kernel(const char* fmt, ...);
 ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t npix, float eps, float momentum,
                                   int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, hipStream_t stream);
+
+// Finalises per-workgroup sums part[rows][3][c] (dz, dz*xhat, d*min(z,0)) into dgamma / dbeta / dalpha and the three
+// coefficient vectors of the apply pass, coef = k1 | m1 | m2 (bn.hip)
+ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64_t npix, const float* gamma, const float* invstd,
+                                float* dgamma, float* dbeta, float* dalpha, float* coef, hipStream_t st);
 
 // Backward of a BatchNormalization(+activation, +spatial dropout) fused into the epilogue of the data-gradient kernel that
 // produces the gradient of the BN's output: the kernel adds per-workgroup column sums of dz, dz*xhat and d*min(z,0) to

@@ -1,0 +1,322 @@
+// The 1x1 expansion of a regular ENet bottleneck (src/models.py:1142-1172: Conv2D 1x1 -> BatchNormalization ->
+// SpatialDropout2D -> Add with the block input -> PReLU) WITHOUT its output tensor.  The expansion maps 16 or 32 channels to
+// 64 or 128: recomputing it from its 4x smaller input is nearly free, while its output y3 is the widest tensor of the block and
+// is written once and read three times (merge forward, both merge-backward passes).  Every kernel here recomputes
+//     y3 = PReLU2(BN2(y2_raw)) * W3                 (normalise on load, as ssmi_conv2d_fwd_bn_stats_prebn)
+// on v_mfma_f32_32x32x2_f32 and consumes it in place:
+//   mode S   column sums of y3 and y3^2 (training-phase statistics of BN3); nothing is stored
+//   mode F   out = PReLU3(drop * BN3(y3) + skip)                                      (ssmi_merge_fwd, identity skip)
+//   mode B1  dsum = dout * PReLU3'(s), column sums of dz, dz * xhat3, dout * min(s, 0) (ssmi_merge_bwd, reducing pass)
+//   mode B2  dmain = k1 * (dsum * drop - m1 - xhat3 * m2)                              (ssmi_merge_bwd, apply pass)
+// with the arithmetic of the merge kernels per element.  A 256-thread workgroup walks 64-pixel tiles: the raw input tile is
+// normalised on its way into LDS, four waves multiply (pixel half x channel half, kernel matrix resident in LDS), the
+// accumulators go through LDS, and the elementwise phase runs in the merge kernels' layout - a thread owns four consecutive
+// channels of a pixel, 16-byte accesses - with every global operand of the tile requested before the multiply phase.
+// float32 storage; (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
+#include "common.h"
+
+namespace ssmi {
+
+struct ExpandArgs {
+  int npix, hw;
+  const float* y2;          // [npix][C4] raw output of the convolution in front
+  const float* pre[5];      // mean2, invstd2, gamma2, beta2, alpha2 (alpha2 nullptr: no activation)
+  const float* w;           // [C4][C]
+  const float *mean3, *invstd3, *gamma3, *beta3, *alpha3;
+  const float* drop;        // [n][C] or nullptr
+  const float* skip;        // [npix][C]                       (F, B1)
+  const float* dout;        // [npix][C]                       (B1)
+  const float* dsum_in;     // [npix][C]                       (B2)
+  const float* coef;        // k1 | m1 | m2, C floats each     (B2)
+  float* out;               // F: block output; B1: dsum; B2: dmain
+  float* y3_out;            // F only, nullable: also store the recomputed expansion output (tests, debugging)
+  float* part;              // S: [grid][2][C]; B1: [grid][3][C]
+};
+
+template <int C4, int C, int MODE>
+__global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
+  constexpr int TP = 64;                      // pixels per tile
+  constexpr int AS = C4 + 1;                  // row stride of the normalised input tile (floats; odd: conflict-free column reads)
+  constexpr int SS = C + 4;                   // row stride of the staged accumulators
+  constexpr int G = C / 4, PL = 256 / G, NPASS = TP / PL;
+  constexpr int NT = C / 64;                  // 32-column tiles per wave
+  constexpr int P4 = C4 / 4, NY = TP * P4 / 256;
+  constexpr int NS = MODE == 0 ? 2 : 3;
+  constexpr bool kSums = MODE == 0 || MODE == 2;
+  static_assert(NY >= 1 && 256 % P4 == 0 && 256 % G == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const Wl = sm;                       // [C4][C]
+  float* const Al = Wl + C4 * C;              // [TP][AS]
+  float* const St = Al + ((TP * AS + 3) & ~3);      // [TP][SS], later the reduction scratch
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int pw = wave & 1, cw = wave >> 1;
+
+  for (int e = tid * 4; e < C4 * C; e += 1024) *reinterpret_cast<f32x4*>(Wl + e) = *reinterpret_cast<const f32x4*>(a.w + e);
+
+  // the thread's four input channels (normalise-on-load role) and their BN2 / PReLU2 parameters
+  const int yc = (tid % P4) * 4;
+  const f32x4 m2 = *reinterpret_cast<const f32x4*>(a.pre[0] + yc), is2 = *reinterpret_cast<const f32x4*>(a.pre[1] + yc);
+  const f32x4 g2 = *reinterpret_cast<const f32x4*>(a.pre[2] + yc), b2 = *reinterpret_cast<const f32x4*>(a.pre[3] + yc);
+  const bool act2 = a.pre[4] != nullptr;
+  f32x4 al2 = {0.f, 0.f, 0.f, 0.f};
+  if (act2) al2 = *reinterpret_cast<const f32x4*>(a.pre[4] + yc);
+
+  // the thread's four output channels (elementwise role) and their parameters
+  const int cg = tid % G, pl = tid / G, c = cg * 4;
+  f32x4 m3, is3, g3, b3, al3, k1, q1, q2;
+  m3 = is3 = g3 = b3 = al3 = k1 = q1 = q2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (MODE != 0) {
+    m3 = *reinterpret_cast<const f32x4*>(a.mean3 + c);
+    is3 = *reinterpret_cast<const f32x4*>(a.invstd3 + c);
+  }
+  if constexpr (MODE == 1 || MODE == 2) {
+    g3 = *reinterpret_cast<const f32x4*>(a.gamma3 + c);
+    b3 = *reinterpret_cast<const f32x4*>(a.beta3 + c);
+    al3 = *reinterpret_cast<const f32x4*>(a.alpha3 + c);
+  }
+  if constexpr (MODE == 3) {
+    k1 = *reinterpret_cast<const f32x4*>(a.coef + c);
+    q1 = *reinterpret_cast<const f32x4*>(a.coef + C + c);
+    q2 = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + c);
+  }
+  f32x4 v[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const unsigned wide_bytes = (unsigned)a.npix * (unsigned)C * 4u;
+  const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
+  const __amdgpu_buffer_rsrc_t rskip = make_rsrc(MODE == 1 || MODE == 2 ? (const void*)a.skip : (const void*)a.y2, MODE == 1 || MODE == 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rd = make_rsrc(MODE == 2 ? (const void*)a.dout : (MODE == 3 ? (const void*)a.dsum_in : (const void*)a.y2),
+                                              MODE >= 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ro = make_rsrc(MODE != 0 ? (void*)a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
+
+  const int ntiles = (a.npix + TP - 1) / TP;
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const unsigned p0 = (unsigned)t * TP;
+    // every global operand of the tile, requested up front
+    f32x4 yv[NY];
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const unsigned p = p0 + (unsigned)((tid + 256 * j) / P4);
+      yv[j] = bload4(ry2, p < (unsigned)a.npix ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB);
+    }
+    f32x4 xs[MODE == 1 || MODE == 2 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const unsigned p = p0 + (unsigned)(q * PL + pl);
+      const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB;
+      if constexpr (MODE == 1 || MODE == 2) xs[q] = bload4(rskip, off);
+      if constexpr (MODE >= 2) dv[q] = bload4(rd, off);
+    }
+    __syncthreads();                           // the previous tile's staged accumulators have been read (first tile: W is in LDS)
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      const int px = (tid + 256 * j) / P4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Al[px * AS + yc + e] = pre_bn_act(yv[j][e], m2[e], is2[e], g2[e], b2[e], al2[e], act2);
+    }
+    __syncthreads();
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < C4 / 2; ++s) {
+      const int k = 2 * s + hh;
+      const float av = Al[(pw * 32 + r) * AS + k];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / 2) + u * 32 + r], acc[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) St[(pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * SS + cw * (C / 2) + u * 32 + r] = acc[u][i];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NPASS; ++q) {
+      const int lp = q * PL + pl;
+      const unsigned p = p0 + (unsigned)lp;
+      const bool live = p < (unsigned)a.npix;
+      const f32x4 y3 = *reinterpret_cast<const f32x4*>(St + lp * SS + c);
+      f32x4 dr = {1.f, 1.f, 1.f, 1.f};
+      if constexpr (MODE != 0) {
+        if (a.drop) dr = *reinterpret_cast<const f32x4*>(a.drop + (size_t)((live ? p : 0u) / (unsigned)a.hw) * C + c);
+      }
+      if constexpr (MODE == 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yy = live ? y3[e] : 0.f;
+          v[0][e] += yy;
+          v[1][e] += yy * yy;
+        }
+      } else if constexpr (MODE == 3) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (y3[e] - m3[e]) * is3[e];
+          o[e] = k1[e] * (dv[q][e] * dr[e] - q1[e] - xh * q2[e]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, 0, 0);
+      } else {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (y3[e] - m3[e]) * is3[e];
+          float s = (g3[e] * xh + b3[e]) * dr[e];
+          s += xs[q][e];
+          if constexpr (MODE == 1) {
+            o[e] = s > 0.f ? s : al3[e] * s;
+          } else {
+            const float d = live ? dv[q][e] : 0.f;
+            o[e] = d * (s > 0.f ? 1.f : (s < 0.f ? al3[e] : 0.f));
+            const float dz = o[e] * dr[e];
+            v[0][e] += dz;
+            v[1][e] += dz * xh;
+            v[2][e] += d * (s < 0.f ? s : 0.f);
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, 0, 0);
+        if constexpr (MODE == 1) {
+          if (a.y3_out != nullptr && live) *reinterpret_cast<f32x4*>(a.y3_out + (size_t)p * C + c) = y3;      // uniform test
+        }
+      }
+    }
+  }
+  if constexpr (kSums) {      // one row of column sums per workgroup, pixel lanes added in a fixed order
+    __syncthreads();
+    float* red = St;          // [NS][PL][C]
+#pragma unroll
+    for (int k = 0; k < NS; ++k) *reinterpret_cast<f32x4*>(red + (k * PL + pl) * C + c) = v[k];
+    __syncthreads();
+    if (tid < C) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        float s = 0.f;
+        for (int p2 = 0; p2 < PL; ++p2) s += red[(k * PL + p2) * C + tid];
+        a.part[((size_t)blockIdx.x * NS + k) * C + tid] = s;
+      }
+    }
+  }
+}
+
+static constexpr int kExpandMaxGrid = 512;      // two workgroups per CU; also the number of partial-sum rows
+
+static bool expand_shape_ok(const ssmi_expand_desc* d) {
+  return d && d->n > 0 && d->h > 0 && d->w > 0 && ((d->cin == 16 && d->cout == 64) || (d->cin == 32 && d->cout == 128)) &&
+         (int64_t)d->n * d->h * d->w * d->cout * 4 < 0x7FFFFFFFLL;
+}
+
+template <int MODE>
+static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
+  const int ntiles = (a.npix + 63) / 64;
+  const int grid = ntiles < kExpandMaxGrid ? ntiles : kExpandMaxGrid;
+  if (rows) *rows = grid;
+  if (d->cin == 16) {
+    constexpr int C4 = 16, C = 64;
+    const size_t lds = (size_t)(C4 * C + ((64 * (C4 + 1) + 3) & ~3) + 64 * (C + 4)) * 4;
+    hipLaunchKernelGGL((expand_kernel<C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
+  } else {
+    constexpr int C4 = 32, C = 128;
+    const size_t lds = (size_t)(C4 * C + ((64 * (C4 + 1) + 3) & ~3) + 64 * (C + 4)) * 4;
+    hipLaunchKernelGGL((expand_kernel<C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
+  }
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
+}
+
+static bool aligned16(std::initializer_list<const void*> ps) {
+  for (const void* p : ps)
+    if (reinterpret_cast<uintptr_t>(p) & 15) return false;
+  return true;
+}
+
+static ExpandArgs expand_args(const ssmi_expand_desc* d, const void* y2, const ssmi_bn_params* pre, const float* pre_alpha, const float* w) {
+  ExpandArgs a{};
+  a.npix = d->n * d->h * d->w;
+  a.hw = d->h * d->w;
+  a.y2 = static_cast<const float*>(y2);
+  a.pre[0] = pre->mean; a.pre[1] = pre->invstd; a.pre[2] = pre->gamma; a.pre[3] = pre->beta; a.pre[4] = pre_alpha;
+  a.w = w;
+  return a;
+}
+
+}  // namespace ssmi
+
+using namespace ssmi;
+
+extern "C" {
+
+int32_t ssmi_expand_supported(const ssmi_expand_desc* d) { return expand_shape_ok(d) ? 1 : 0; }
+
+size_t ssmi_expand_workspace_bytes(const ssmi_expand_desc* d) {
+  if (!expand_shape_ok(d)) return 0;
+  return ((size_t)kExpandMaxGrid * 3 + 3) * (size_t)d->cout * sizeof(float);      // partial rows + the apply pass's coefficients
+}
+
+ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                 const float* w, float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
+                                 float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_bn_stats: float32 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && save_mean && save_invstd, SSMI_E_INVALID_ARG,
+               "expand_bn_stats: NULL argument");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "expand_bn_stats: workspace too small");
+  SSMI_REQUIRE(aligned16({x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, ws}), SSMI_E_INVALID_ARG,
+               "expand_bn_stats: pointers must be 16-byte aligned");
+  ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
+  a.part = static_cast<float*>(ws);
+  int rows = 0;
+  ssmi_status s = launch_expand<0>(d, a, &rows, as_stream(stream));
+  if (s) return s;
+  return launch_bn_stats_final(a.part, rows, d->cout, a.npix, eps, momentum, unbiased_moving, moving_mean, moving_var, save_mean,
+                               save_invstd, as_stream(stream));
+}
+
+ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                  const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, const float* alpha,
+                                  void* out, void* y3_out, void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_fwd: float32 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd && bn3->gamma &&
+               bn3->beta && skip && alpha && out, SSMI_E_INVALID_ARG, "expand_merge_fwd: NULL argument");
+  SSMI_REQUIRE(aligned16({x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma, bn3->beta,
+                          drop, skip, alpha, out}), SSMI_E_INVALID_ARG, "expand_merge_fwd: pointers must be 16-byte aligned");
+  ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
+  a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
+  a.drop = drop; a.skip = static_cast<const float*>(skip); a.out = static_cast<float*>(out);
+  a.y3_out = static_cast<float*>(y3_out);
+  SSMI_REQUIRE(aligned16({y3_out}), SSMI_E_INVALID_ARG, "expand_merge_fwd: pointers must be 16-byte aligned");
+  return launch_expand<1>(d, a, nullptr, as_stream(stream));
+}
+
+ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
+                                  const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
+                                  const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_bwd: float32 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
+               bn3->gamma && bn3->beta && skip && alpha && dmain && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
+               "expand_merge_bwd: NULL argument");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "expand_merge_bwd: workspace too small");
+  SSMI_REQUIRE(aligned16({dout, x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma,
+                          bn3->beta, drop, skip, alpha, dmain, dsum, ws}), SSMI_E_INVALID_ARG,
+               "expand_merge_bwd: pointers must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
+  a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
+  a.drop = drop; a.skip = static_cast<const float*>(skip); a.dout = static_cast<const float*>(dout);
+  a.out = static_cast<float*>(dsum);
+  a.part = static_cast<float*>(ws);
+  float* coef = a.part + (size_t)kExpandMaxGrid * 3 * d->cout;
+  int rows = 0;
+  ssmi_status s = launch_expand<2>(d, a, &rows, st);
+  if (s) return s;
+  s = launch_bn_bwd_final(a.part, rows, d->cout, a.npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
+  if (s) return s;
+  ExpandArgs b = expand_args(d, x_raw, pre, pre_alpha, w);
+  b.mean3 = bn3->mean; b.invstd3 = bn3->invstd;
+  b.drop = drop; b.dsum_in = static_cast<const float*>(dsum); b.coef = coef; b.out = static_cast<float*>(dmain);
+  return launch_expand<3>(d, b, nullptr, st);
+}
+
+}  // extern "C"

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from ._lib import BF16, F32, BnParams, ConvDesc, MergeDesc, Premerge, lib, lib_for
+from ._lib import BF16, F32, BnParams, ConvDesc, ExpandDesc, MergeDesc, Premerge, lib, lib_for
 
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.1   # src/models.py:1064 (weight of the OLD moving value)
@@ -707,6 +707,18 @@ class Bottleneck(Block):
         md.dtype = self.store.dtype_code
         self.md = md
         self._mref = C.byref(md)
+        # Regular bottleneck, float32 storage, training phase: the expansion's output y3 is never stored - statistics, merge
+        # forward and both merge-backward passes recompute it from the raw output of conv2 (ssmi_expand_*).  SSMI_NO_EXPAND=1
+        # keeps the stored route; keep_y3 (tests) has the forward kernel store y3 as well.
+        self.expand = None
+        if self.mode == 0 and self.store.dtype_code == F32 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok:
+            ed = ExpandDesc()
+            ed.n, ed.h, ed.w, ed.cin, ed.cout = n, h2, w2, i, c
+            if lib().expand_supported(C.byref(ed)):
+                self.expand = ed
+                self._eref = C.byref(ed)
+        self._expanded = False
+        self.keep_y3 = bool(os.environ.get("SSMI_KEEP_Y3"))
         return (h2, w2, c)
 
     def _merge_other(self):
@@ -751,6 +763,17 @@ class Bottleneck(Block):
             self._drop_used = None
             self.conv3.fwd_bn_add_act_infer(self.a2, self.out, self.bn3, x, self.cin, self.alpha3, st)
             return self.out
+        self._expanded = bool(tr and getattr(self, "_pre3", False) and self.expand is not None)
+        if self._expanded:
+            drop = self.drop_mask if (cfg.use_dropout and self.drop_mask is not None) else None
+            self._drop_used = drop
+            bn2, bn3, L0 = self.bn2, self.bn3, lib()
+            L0.expand_bn_stats(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), BN_EPS, BN_MOMENTUM,
+                               1 if ub else 0, _ptr(bn3.mm) if um else None, _ptr(bn3.mv) if um else None, _ptr(bn3.mean),
+                               _ptr(bn3.invstd), _ptr(ws), ws.numel() * 4, st)
+            L0.expand_merge_fwd(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), bn3._pref, _ptr(drop),
+                                _ptr(x), _ptr(self.alpha3), _ptr(self.out), _ptr(self.y3) if self.keep_y3 else None, st)
+            return self.out
         if tr and getattr(self, "_pre3", False):
             self.conv3.fwd_bn_prebn(self.y2, self.bn2, self.y3, self.bn3, um, ub, ws, st)
         else:
@@ -778,7 +801,11 @@ class Bottleneck(Block):
         # on its stream.
         premerge = self.conv3.premerge_ok and self.conv3.wrot is not None
         before3 = None
-        if premerge:
+        if self._expanded:
+            lib().expand_merge_bwd(self._eref, _ptr(dout), _ptr(self.y2), self.bn2._pref, _ptr(self.bn2.alpha), _ptr(self.conv3.w),
+                                   self.bn3._pref, _ptr(self._drop_used), _ptr(self.x), _ptr(self.alpha3), _ptr(self.dy3),
+                                   _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
+        elif premerge:
             L.merge_bwd_deferred(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o,
                                  _ptr(idx), _ptr(self.alpha3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
                                  _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(self.coef3), _ptr(ws), wsb, st)

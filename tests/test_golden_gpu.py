@@ -14,6 +14,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(autouse=True)
+def _keep_expansion_outputs(monkeypatch):
+    """The branch replay below reads every bottleneck's expansion output y3 from the device; the training step does not store
+    it for regular bottlenecks unless asked to (the forward kernel then writes it beside the block output, same values)."""
+    monkeypatch.setenv("SSMI_KEEP_Y3", "1")
+
+
+
 def _t(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
 

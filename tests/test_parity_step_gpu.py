@@ -28,6 +28,14 @@ from oracle import enet_oracle as E
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _keep_expansion_outputs(monkeypatch):
+    """The branch replay below reads every bottleneck's expansion output y3 from the device; the training step does not store
+    it for regular bottlenecks unless asked to (the forward kernel then writes it beside the block output, same values)."""
+    monkeypatch.setenv("SSMI_KEEP_Y3", "1")
+
+
+
 def _close(a, b, rtol, atol, what):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
