@@ -83,6 +83,9 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   f32x4 v[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float lane_s[NT][2];      // mode S: this lane's column sums (channel cw * C/2 + u * 32 + r)
+#pragma unroll
+  for (int u = 0; u < NT; ++u) lane_s[u][0] = lane_s[u][1] = 0.f;
 
   const unsigned wide_bytes = (unsigned)a.npix * (unsigned)C * 4u;
   const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
@@ -129,6 +132,19 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
       for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / 2) + u * 32 + r], acc[u], 0, 0, 0);
     }
+    if constexpr (MODE == 0) {      // statistics straight from the accumulators: a lane owns 16 pixels of one channel per tile
+      const bool full = p0 + TP <= (unsigned)a.npix;      // uniform
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const unsigned p = p0 + (unsigned)(pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh);
+          const float yy = (full || p < (unsigned)a.npix) ? acc[u][i] : 0.f;
+          lane_s[u][0] += yy;
+          lane_s[u][1] += yy * yy;
+        }
+      continue;
+    }
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
@@ -144,14 +160,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       if constexpr (MODE != 0) {
         if (a.drop) dr = *reinterpret_cast<const f32x4*>(a.drop + (size_t)((live ? p : 0u) / (unsigned)a.hw) * C + c);
       }
-      if constexpr (MODE == 0) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float yy = live ? y3[e] : 0.f;
-          v[0][e] += yy;
-          v[1][e] += yy * yy;
-        }
-      } else if constexpr (MODE == 3) {
+      if constexpr (MODE == 3) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -184,7 +193,22 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       }
     }
   }
-  if constexpr (kSums) {      // one row of column sums per workgroup, pixel lanes added in a fixed order
+  if constexpr (MODE == 0) {  // lane halves, then the two pixel-half waves of a channel half, in a fixed order
+    __syncthreads();
+    float* red = St;          // [2 sums][2 pixel halves][C]
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float t2 = lane_s[u][k] + __shfl_xor(lane_s[u][k], 32, 64);
+        if (hh == 0) red[(k * 2 + pw) * C + cw * (C / 2) + u * 32 + r] = t2;
+      }
+    __syncthreads();
+    if (tid < C) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) a.part[((size_t)blockIdx.x * 2 + k) * C + tid] = red[(k * 2) * C + tid] + red[(k * 2 + 1) * C + tid];
+    }
+  } else if constexpr (kSums) {      // one row of column sums per workgroup, pixel lanes added in a fixed order
     __syncthreads();
     float* red = St;          // [NS][PL][C]
 #pragma unroll
