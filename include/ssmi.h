@@ -654,7 +654,7 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
 
 /* ------------------------------------------------------------------------------------------------------------------
  * The 1x1 expansion of a regular bottleneck without its output tensor (src/models.py:1142-1172: Conv2D 1x1 ->
- * BatchNormalization -> SpatialDropout2D -> Add with the block input -> PReLU; training phase, float32 tensors).
+ * BatchNormalization -> SpatialDropout2D -> Add with the block input -> PReLU; training phase).
  * The three calls replace  ssmi_conv2d_fwd_bn_stats_prebn + ssmi_merge_fwd  and  ssmi_merge_bwd  (other_mode 0) for a
  * block whose expansion maps 16 -> 64 or 32 -> 128 channels: each recomputes y3 = PReLU(BN(x_raw)) * w from the raw
  * input of the BatchNormalization in front of the expansion (pre, pre_alpha: its final statistics, parameters and PReLU
@@ -668,6 +668,7 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  * Outputs equal the stored route's up to the order of the float32 sums inside y3. */
 typedef struct ssmi_expand_desc {
   int32_t n, h, w, cin, cout;
+  int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x_raw, skip, out, dout, dsum, dmain, y3_out */
 } ssmi_expand_desc;
 int32_t ssmi_expand_supported(const ssmi_expand_desc* d);
 size_t ssmi_expand_workspace_bytes(const ssmi_expand_desc* d);

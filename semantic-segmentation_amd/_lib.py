@@ -28,7 +28,7 @@ class MergeDesc(C.Structure):
 
 
 class ExpandDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cin", "cout")]
+    _fields_ = [(n, C.c_int32) for n in ("n", "h", "w", "cin", "cout", "dtype")]
 
 
 class BnParams(C.Structure):

@@ -8,38 +8,41 @@
 //   mode F   out = PReLU3(drop * BN3(y3) + skip)                                      (ssmi_merge_fwd, identity skip)
 //   mode B1  dsum = dout * PReLU3'(s), column sums of dz, dz * xhat3, dout * min(s, 0) (ssmi_merge_bwd, reducing pass)
 //   mode B2  dmain = k1 * (dsum * drop - m1 - xhat3 * m2)                              (ssmi_merge_bwd, apply pass)
-// with the arithmetic of the merge kernels per element.  A 256-thread workgroup walks 64-pixel tiles: the raw input tile is
-// normalised on its way into LDS, four waves multiply (pixel half x channel half, kernel matrix resident in LDS), the
+// with the arithmetic of the merge kernels per element.  A 256-thread workgroup walks 64-pixel (64 channels) or 32-pixel (128 channels) tiles: the raw input tile is
+// normalised on its way into LDS, four waves multiply (pixel blocks x channel groups, kernel matrix resident in LDS), the
 // accumulators go through LDS, and the elementwise phase runs in the merge kernels' layout - a thread owns four consecutive
 // channels of a pixel, 16-byte accesses - with every global operand of the tile requested before the multiply phase.
-// float32 storage; (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
+// Both storage types (bfloat16: the operand, the kernel and y3 take the roundings the stored route's tensors and packs have, so
+// the values equal that route's up to summation order); (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
 #include "common.h"
 
 namespace ssmi {
 
 struct ExpandArgs {
   int npix, hw;
-  const float* y2;          // [npix][C4] raw output of the convolution in front
+  const void* y2;           // [npix][C4] raw output of the convolution in front (activation type)
   const float* pre[5];      // mean2, invstd2, gamma2, beta2, alpha2 (alpha2 nullptr: no activation)
   const float* w;           // [C4][C]
   const float *mean3, *invstd3, *gamma3, *beta3, *alpha3;
   const float* drop;        // [n][C] or nullptr
-  const float* skip;        // [npix][C]                       (F, B1)
-  const float* dout;        // [npix][C]                       (B1)
-  const float* dsum_in;     // [npix][C]                       (B2)
+  const void* skip;         // [npix][C]                       (F, B1)
+  const void* dout;         // [npix][C]                       (B1)
+  const void* dsum_in;      // [npix][C]                       (B2)
   const float* coef;        // k1 | m1 | m2, C floats each     (B2)
-  float* out;               // F: block output; B1: dsum; B2: dmain
-  float* y3_out;            // F only, nullable: also store the recomputed expansion output (tests, debugging)
+  void* out;                // F: block output; B1: dsum; B2: dmain
+  void* y3_out;             // F only, nullable: also store the recomputed expansion output (tests, debugging)
   float* part;              // S: [grid][2][C]; B1: [grid][3][C]
 };
 
-template <int C4, int C, int MODE>
+template <typename T, int C4, int C, int MODE>
 __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
-  constexpr int TP = 64;                      // pixels per tile
+  constexpr bool kBf = sizeof(T) == 2;      // bfloat16 storage: operands and y3 take the roundings the stored route's tensors have
+  constexpr int TP = C == 128 ? 32 : 64;      // pixels per tile (eight elementwise passes per tile cost the 128-wide variant > 256 registers)
+  constexpr int PWN = TP / 32, CWN = 4 / PWN; // waves along pixels / along channels
   constexpr int AS = C4 + 1;                  // row stride of the normalised input tile (floats; odd: conflict-free column reads)
   constexpr int SS = C + 4;                   // row stride of the staged accumulators
   constexpr int G = C / 4, PL = 256 / G, NPASS = TP / PL;
-  constexpr int NT = C / 64;                  // 32-column tiles per wave
+  constexpr int NT = C / (32 * CWN);          // 32-column tiles per wave
   constexpr int P4 = C4 / 4, NY = TP * P4 / 256;
   constexpr int NS = MODE == 0 ? 2 : 3;
   constexpr bool kSums = MODE == 0 || MODE == 2;
@@ -50,9 +53,13 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   float* const St = Al + ((TP * AS + 3) & ~3);      // [TP][SS], later the reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const int pw = wave & 1, cw = wave >> 1;
+  const int pw = wave % PWN, cw = wave / PWN;
 
-  for (int e = tid * 4; e < C4 * C; e += 1024) *reinterpret_cast<f32x4*>(Wl + e) = *reinterpret_cast<const f32x4*>(a.w + e);
+  for (int e = tid * 4; e < C4 * C; e += 1024) {
+    f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e);
+    if constexpr (kBf) wv = unpack_bf16x4(pack_bf16x4(wv));      // the bf16 route multiplies bf16-rounded kernels (its packs)
+    *reinterpret_cast<f32x4*>(Wl + e) = wv;
+  }
 
   // the thread's four input channels (normalise-on-load role) and their BN2 / PReLU2 parameters
   const int yc = (tid % P4) * 4;
@@ -87,37 +94,47 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
   for (int u = 0; u < NT; ++u) lane_s[u][0] = lane_s[u][1] = 0.f;
 
+  // offsets below are byte offsets of a float32 tensor; the bf16 accessors halve them (common.h)
   const unsigned wide_bytes = (unsigned)a.npix * (unsigned)C * 4u;
-  const __amdgpu_buffer_rsrc_t ry2 = make_rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
-  const __amdgpu_buffer_rsrc_t rskip = make_rsrc(MODE == 1 || MODE == 2 ? (const void*)a.skip : (const void*)a.y2, MODE == 1 || MODE == 2 ? wide_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rd = make_rsrc(MODE == 2 ? (const void*)a.dout : (MODE == 3 ? (const void*)a.dsum_in : (const void*)a.y2),
-                                              MODE >= 2 ? wide_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t ro = make_rsrc(MODE != 0 ? (void*)a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ry2 = Act<T>::rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
+  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(MODE == 1 || MODE == 2 ? a.skip : a.y2, MODE == 1 || MODE == 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(MODE == 2 ? a.dout : (MODE == 3 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 ? a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(MODE == 1 && a.y3_out ? a.y3_out : (void*)a.part, MODE == 1 && a.y3_out ? wide_bytes : 0u);
+  auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off4, const f32x4& val) {      // out-of-range offsets are dropped
+    if constexpr (kBf) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(val), rs, off4 >> 1, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, off4, 0, 0);
+  };
 
   const int ntiles = (a.npix + TP - 1) / TP;
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const unsigned p0 = (unsigned)t * TP;
     // every global operand of the tile, requested up front
-    f32x4 yv[NY];
+    typename Act<T>::raw4 yv[NY];      // raw while in flight, widened at the use
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const unsigned p = p0 + (unsigned)((tid + 256 * j) / P4);
-      yv[j] = bload4(ry2, p < (unsigned)a.npix ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB);
+      yv[j] = Act<T>::ld4r(ry2, p < (unsigned)a.npix ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB);
     }
-    f32x4 xs[MODE == 1 || MODE == 2 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
+    typename Act<T>::raw4 xs[MODE == 1 || MODE == 2 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       const unsigned p = p0 + (unsigned)(q * PL + pl);
       const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB;
-      if constexpr (MODE == 1 || MODE == 2) xs[q] = bload4(rskip, off);
-      if constexpr (MODE >= 2) dv[q] = bload4(rd, off);
+      if constexpr (MODE == 1 || MODE == 2) xs[q] = Act<T>::ld4r(rskip, off);
+      if constexpr (MODE >= 2) dv[q] = Act<T>::ld4r(rd, off);
     }
     __syncthreads();                           // the previous tile's staged accumulators have been read (first tile: W is in LDS)
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int px = (tid + 256 * j) / P4;
+      const f32x4 yw = Act<T>::up4(yv[j]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) Al[px * AS + yc + e] = pre_bn_act(yv[j][e], m2[e], is2[e], g2[e], b2[e], al2[e], act2);
+      for (int e = 0; e < 4; ++e) {
+        float av = pre_bn_act(yw[e], m2[e], is2[e], g2[e], b2[e], al2[e], act2);
+        if constexpr (kBf) av = (float)(bf16)av;      // as the stored normalised tensor would have been rounded
+        Al[px * AS + yc + e] = av;
+      }
     }
     __syncthreads();
     f32x16 acc[NT];
@@ -130,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       const int k = 2 * s + hh;
       const float av = Al[(pw * 32 + r) * AS + k];
 #pragma unroll
-      for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / 2) + u * 32 + r], acc[u], 0, 0, 0);
+      for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / CWN) + u * 32 + r], acc[u], 0, 0, 0);
     }
     if constexpr (MODE == 0) {      // statistics straight from the accumulators: a lane owns 16 pixels of one channel per tile
       const bool full = p0 + TP <= (unsigned)a.npix;      // uniform
@@ -148,7 +165,11 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) St[(pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * SS + cw * (C / 2) + u * 32 + r] = acc[u][i];
+      for (int i = 0; i < 16; ++i) {
+        float yy = acc[u][i];
+        if constexpr (kBf) yy = (float)(bf16)yy;      // the value a stored y3 would hold (the statistics above take the unrounded one)
+        St[(pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * SS + cw * (C / CWN) + u * 32 + r] = yy;
+      }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
@@ -156,6 +177,9 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       const unsigned p = p0 + (unsigned)lp;
       const bool live = p < (unsigned)a.npix;
       const f32x4 y3 = *reinterpret_cast<const f32x4*>(St + lp * SS + c);
+      f32x4 xq = {0.f, 0.f, 0.f, 0.f}, dq = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (MODE == 1 || MODE == 2) xq = Act<T>::up4(xs[q]);
+      if constexpr (MODE >= 2) dq = Act<T>::up4(dv[q]);
       f32x4 dr = {1.f, 1.f, 1.f, 1.f};
       if constexpr (MODE != 0) {
         if (a.drop) dr = *reinterpret_cast<const f32x4*>(a.drop + (size_t)((live ? p : 0u) / (unsigned)a.hw) * C + c);
@@ -165,20 +189,20 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (y3[e] - m3[e]) * is3[e];
-          o[e] = k1[e] * (dv[q][e] * dr[e] - q1[e] - xh * q2[e]);
+          o[e] = k1[e] * (dq[e] * dr[e] - q1[e] - xh * q2[e]);
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, 0, 0);
+        store4(ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, o);
       } else {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (y3[e] - m3[e]) * is3[e];
           float s = (g3[e] * xh + b3[e]) * dr[e];
-          s += xs[q][e];
+          s += xq[e];
           if constexpr (MODE == 1) {
             o[e] = s > 0.f ? s : al3[e] * s;
           } else {
-            const float d = live ? dv[q][e] : 0.f;
+            const float d = live ? dq[e] : 0.f;
             o[e] = d * (s > 0.f ? 1.f : (s < 0.f ? al3[e] : 0.f));
             const float dz = o[e] * dr[e];
             v[0][e] += dz;
@@ -186,27 +210,30 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
             v[2][e] += d * (s < 0.f ? s : 0.f);
           }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, 0, 0);
-        if constexpr (MODE == 1) {
-          if (a.y3_out != nullptr && live) *reinterpret_cast<f32x4*>(a.y3_out + (size_t)p * C + c) = y3;      // uniform test
-        }
+        store4(ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, o);
+        if constexpr (MODE == 1) store4(ry3, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, y3);      // (empty descriptor: dropped)
       }
     }
   }
   if constexpr (MODE == 0) {  // lane halves, then the two pixel-half waves of a channel half, in a fixed order
     __syncthreads();
-    float* red = St;          // [2 sums][2 pixel halves][C]
+    float* red = St;          // [2 sums][PWN pixel blocks][C]
 #pragma unroll
     for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const float t2 = lane_s[u][k] + __shfl_xor(lane_s[u][k], 32, 64);
-        if (hh == 0) red[(k * 2 + pw) * C + cw * (C / 2) + u * 32 + r] = t2;
+        if (hh == 0) red[(k * PWN + pw) * C + cw * (C / CWN) + u * 32 + r] = t2;
       }
     __syncthreads();
     if (tid < C) {
 #pragma unroll
-      for (int k = 0; k < 2; ++k) a.part[((size_t)blockIdx.x * 2 + k) * C + tid] = red[(k * 2) * C + tid] + red[(k * 2 + 1) * C + tid];
+      for (int k = 0; k < 2; ++k) {
+        float t2 = red[(k * PWN) * C + tid];
+#pragma unroll
+        for (int b = 1; b < PWN; ++b) t2 += red[(k * PWN + b) * C + tid];
+        a.part[((size_t)blockIdx.x * 2 + k) * C + tid] = t2;
+      }
     }
   } else if constexpr (kSums) {      // one row of column sums per workgroup, pixel lanes added in a fixed order
     __syncthreads();
@@ -229,25 +256,30 @@ static constexpr int kExpandMaxGrid = 512;      // two workgroups per CU; also t
 
 static bool expand_shape_ok(const ssmi_expand_desc* d) {
   return d && d->n > 0 && d->h > 0 && d->w > 0 && ((d->cin == 16 && d->cout == 64) || (d->cin == 32 && d->cout == 128)) &&
-         (int64_t)d->n * d->h * d->w * d->cout * 4 < 0x7FFFFFFFLL;
+         (int64_t)d->n * d->h * d->w * d->cout * 4 < 0x7FFFFFFFLL && (d->dtype == SSMI_F32 || d->dtype == SSMI_BF16);
 }
 
 template <int MODE>
 static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
-  const int ntiles = (a.npix + 63) / 64;
+  const int tp = d->cout == 128 ? 32 : 64;
+  const int ntiles = (a.npix + tp - 1) / tp;
   const int grid = ntiles < kExpandMaxGrid ? ntiles : kExpandMaxGrid;
   if (rows) *rows = grid;
-  if (d->cin == 16) {
-    constexpr int C4 = 16, C = 64;
-    const size_t lds = (size_t)(C4 * C + ((64 * (C4 + 1) + 3) & ~3) + 64 * (C + 4)) * 4;
-    hipLaunchKernelGGL((expand_kernel<C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
-  } else {
-    constexpr int C4 = 32, C = 128;
-    const size_t lds = (size_t)(C4 * C + ((64 * (C4 + 1) + 3) & ~3) + 64 * (C + 4)) * 4;
-    hipLaunchKernelGGL((expand_kernel<C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
-  }
-  SSMI_LAUNCH_CHECK();
-  return SSMI_OK;
+  return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {
+    using T = decltype(tag);
+    if (d->cin == 16) {
+      constexpr int C4 = 16, C = 64, TP = 64;
+      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4;
+      hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
+    } else {
+      constexpr int C4 = 32, C = 128, TP = 32;
+      // (the reduction scratch of the summing modes, 3 sums x 8 pixel lanes x 128 channels, fits the staged tile)
+      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4;
+      hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
+    }
+    SSMI_LAUNCH_CHECK();
+    return SSMI_OK;
+  });
 }
 
 static bool aligned16(std::initializer_list<const void*> ps) {
@@ -260,7 +292,7 @@ static ExpandArgs expand_args(const ssmi_expand_desc* d, const void* y2, const s
   ExpandArgs a{};
   a.npix = d->n * d->h * d->w;
   a.hw = d->h * d->w;
-  a.y2 = static_cast<const float*>(y2);
+  a.y2 = y2;
   a.pre[0] = pre->mean; a.pre[1] = pre->invstd; a.pre[2] = pre->gamma; a.pre[3] = pre->beta; a.pre[4] = pre_alpha;
   a.w = w;
   return a;
@@ -282,7 +314,7 @@ size_t ssmi_expand_workspace_bytes(const ssmi_expand_desc* d) {
 ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
                                  const float* w, float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
                                  float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream) {
-  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_bn_stats: float32 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_bn_stats: 16 -> 64 or 32 -> 128 channel expansions only");
   SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && save_mean && save_invstd, SSMI_E_INVALID_ARG,
                "expand_bn_stats: NULL argument");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "expand_bn_stats: workspace too small");
@@ -300,15 +332,15 @@ ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, c
 ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
                                   const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, const float* alpha,
                                   void* out, void* y3_out, void* stream) {
-  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_fwd: float32 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_fwd: 16 -> 64 or 32 -> 128 channel expansions only");
   SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd && bn3->gamma &&
                bn3->beta && skip && alpha && out, SSMI_E_INVALID_ARG, "expand_merge_fwd: NULL argument");
   SSMI_REQUIRE(aligned16({x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma, bn3->beta,
                           drop, skip, alpha, out}), SSMI_E_INVALID_ARG, "expand_merge_fwd: pointers must be 16-byte aligned");
   ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
   a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
-  a.drop = drop; a.skip = static_cast<const float*>(skip); a.out = static_cast<float*>(out);
-  a.y3_out = static_cast<float*>(y3_out);
+  a.drop = drop; a.skip = skip; a.out = out;
+  a.y3_out = y3_out;
   SSMI_REQUIRE(aligned16({y3_out}), SSMI_E_INVALID_ARG, "expand_merge_fwd: pointers must be 16-byte aligned");
   return launch_expand<1>(d, a, nullptr, as_stream(stream));
 }
@@ -317,7 +349,7 @@ ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, c
                                   const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
                                   const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
                                   size_t ws_bytes, void* stream) {
-  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_bwd: float32 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_bwd: 16 -> 64 or 32 -> 128 channel expansions only");
   SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
                bn3->gamma && bn3->beta && skip && alpha && dmain && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
                "expand_merge_bwd: NULL argument");
@@ -328,8 +360,8 @@ ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, c
   hipStream_t st = as_stream(stream);
   ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
   a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
-  a.drop = drop; a.skip = static_cast<const float*>(skip); a.dout = static_cast<const float*>(dout);
-  a.out = static_cast<float*>(dsum);
+  a.drop = drop; a.skip = skip; a.dout = dout;
+  a.out = dsum;
   a.part = static_cast<float*>(ws);
   float* coef = a.part + (size_t)kExpandMaxGrid * 3 * d->cout;
   int rows = 0;
@@ -339,7 +371,7 @@ ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, c
   if (s) return s;
   ExpandArgs b = expand_args(d, x_raw, pre, pre_alpha, w);
   b.mean3 = bn3->mean; b.invstd3 = bn3->invstd;
-  b.drop = drop; b.dsum_in = static_cast<const float*>(dsum); b.coef = coef; b.out = static_cast<float*>(dmain);
+  b.drop = drop; b.dsum_in = dsum; b.coef = coef; b.out = dmain;
   return launch_expand<3>(d, b, nullptr, st);
 }
 

@@ -707,13 +707,16 @@ class Bottleneck(Block):
         md.dtype = self.store.dtype_code
         self.md = md
         self._mref = C.byref(md)
-        # Regular bottleneck, float32 storage, training phase: the expansion's output y3 is never stored - statistics, merge
+        # Regular bottleneck, training phase: the expansion's output y3 is never stored - statistics, merge
         # forward and both merge-backward passes recompute it from the raw output of conv2 (ssmi_expand_*).  SSMI_NO_EXPAND=1
         # keeps the stored route; keep_y3 (tests) has the forward kernel store y3 as well.
         self.expand = None
-        if self.mode == 0 and self.store.dtype_code == F32 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok:
+        # (bfloat16 storage: built and tested, but measured slower than the stored route - 6.89 against 6.67 ms per ENet step: the
+        # recomputation costs what it costs with float32 while the tensors it avoids are half the size; SSMI_EXPAND_BF16=1 opts in)
+        if (self.mode == 0 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok
+                and (self.store.dtype_code == F32 or os.environ.get("SSMI_EXPAND_BF16"))):
             ed = ExpandDesc()
-            ed.n, ed.h, ed.w, ed.cin, ed.cout = n, h2, w2, i, c
+            ed.n, ed.h, ed.w, ed.cin, ed.cout, ed.dtype = n, h2, w2, i, c, self.store.dtype_code
             if lib().expand_supported(C.byref(ed)):
                 self.expand = ed
                 self._eref = C.byref(ed)

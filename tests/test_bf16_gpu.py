@@ -542,10 +542,15 @@ def _rel_l2(got, ref):
     return float(np.linalg.norm(np.asarray(got, np.float64) - ref) / max(np.linalg.norm(ref), 1e-30))
 
 
-@pytest.mark.parametrize("name,B,H,W,seed", [("enet-naive-upsampling", 2, 64, 64, 3), ("enet-max-unpooling", 2, 64, 96, 5),
-                                             ("enet-naive-upsampling-enhanced", 2, 48, 80, 9)])
-def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed):
+@pytest.mark.parametrize("name,B,H,W,seed,expand", [("enet-naive-upsampling", 2, 64, 64, 3, False), ("enet-max-unpooling", 2, 64, 96, 5, False),
+                                                    ("enet-naive-upsampling-enhanced", 2, 48, 80, 9, False),
+                                                    ("enet-naive-upsampling", 2, 64, 64, 3, True)])
+def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed, expand, monkeypatch):
+    """expand: the regular bottlenecks recompute their expansion instead of storing it (ssmi_expand_*, opt-in for bf16)."""
     from test_parity_step_gpu import _hip_branches
+    monkeypatch.setenv("SSMI_KEEP_Y3", "1")      # the branch replay reads y3
+    if expand:
+        monkeypatch.setenv("SSMI_EXPAND_BF16", "1")
     w0 = E.init_weights(name, NC, seed=seed, perturb=True)
     m = _compiled(name, w0)
     cw = np.ones(NC, dtype=np.float32)
@@ -564,6 +569,7 @@ def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed):
         outs = m.train_on_batch([images, labels, pw, np.zeros((B, 1), np.int32)])
     torch.cuda.synchronize()
     assert g.logits.dtype == torch.bfloat16 and g.by_name["en_bn_1.0"].y1.dtype == torch.bfloat16
+    assert any(getattr(b, "_expanded", False) for b in g.blocks) == expand
     forced = _hip_branches(m, w0)
     hip_logits = g.logits.float().cpu().numpy()
     # --- whole network, quantities that survive compounding --------------------------------------------------------------
