@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   }
 }
 
-static constexpr int kExpandMaxGrid = 512;      // two workgroups per CU; also the number of partial-sum rows
+static constexpr int kExpandMaxGrid = 1024;     // also the largest number of partial-sum rows
 
 static bool expand_shape_ok(const ssmi_expand_desc* d) {
   return d && d->n > 0 && d->h > 0 && d->w > 0 && ((d->cin == 16 && d->cout == 64) || (d->cin == 32 && d->cout == 128)) &&
@@ -263,7 +263,9 @@ template <int MODE>
 static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
   const int tp = d->cout == 128 ? 32 : 64;
   const int ntiles = (a.npix + tp - 1) / tp;
-  const int grid = ntiles < kExpandMaxGrid ? ntiles : kExpandMaxGrid;
+  static const int gmax = getenv("SSMI_EXPAND_GRID") ? atoi(getenv("SSMI_EXPAND_GRID")) : 512;      // measurement switch; ENet step with 256 / 384 / 512 / 768 / 1024: 8.81 / 8.70 / 8.49 / 8.51 / 8.52 ms
+  const int cap = gmax < kExpandMaxGrid ? gmax : kExpandMaxGrid;
+  const int grid = ntiles < cap ? ntiles : cap;
   if (rows) *rows = grid;
   return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {
     using T = decltype(tag);
