@@ -655,11 +655,13 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
 /* ------------------------------------------------------------------------------------------------------------------
  * The 1x1 expansion of a regular bottleneck without its output tensor (src/models.py:1142-1172: Conv2D 1x1 ->
  * BatchNormalization -> SpatialDropout2D -> Add with the block input -> PReLU; training phase).
- * The three calls replace  ssmi_conv2d_fwd_bn_stats_prebn + ssmi_merge_fwd  and  ssmi_merge_bwd  (other_mode 0) for a
+ * The three calls replace  ssmi_conv2d_fwd_bn_stats_prebn + ssmi_merge_fwd  and  ssmi_merge_bwd  (other_mode 0 / 1) for a
  * block whose expansion maps 16 -> 64 or 32 -> 128 channels: each recomputes y3 = PReLU(BN(x_raw)) * w from the raw
  * input of the BatchNormalization in front of the expansion (pre, pre_alpha: its final statistics, parameters and PReLU
  * slopes, as for ssmi_conv2d_fwd_bn_stats_prebn) instead of reading a stored y3, with the merge kernels' arithmetic per
- * element.  w: the expansion's kernel [cin][cout] (no bias).  ws: ssmi_expand_workspace_bytes(d).
+ * element.  w: the expansion's kernel [cin][cout] (no bias).  ws: ssmi_expand_workspace_bytes(d).  skip: [n,h,w,c_skip], the
+ * first c_skip channels of the skip branch (c_skip = cout: identity skip, other_mode 0; fewer: the max-pooled, channel-padded
+ * skip of a downsampling block, other_mode 1 - the caller pools and routes dsum back through the pooling as before).
  *   ssmi_expand_bn_stats   training-phase statistics of the BatchNormalization behind the expansion (save_mean /
  *                          save_invstd, moving-average update); stores no activation
  *   ssmi_expand_merge_fwd  out = PReLU_alpha(drop * BN3(y3) + skip); y3_out (nullable): also store y3 (tests, debugging)
@@ -676,11 +678,11 @@ ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, c
                                  const float* w, float eps, float momentum, int32_t unbiased_moving, float* moving_mean,
                                  float* moving_var, float* save_mean, float* save_invstd, void* ws, size_t ws_bytes, void* stream);
 ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
-                                  const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, const float* alpha,
-                                  void* out, void* y3_out, void* stream);
+                                  const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
+                                  const float* alpha, void* out, void* y3_out, void* stream);
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
                                   const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
-                                  const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
+                                  int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
                                   size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus

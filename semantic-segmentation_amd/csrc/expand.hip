@@ -25,7 +25,8 @@ struct ExpandArgs {
   const float* w;           // [C4][C]
   const float *mean3, *invstd3, *gamma3, *beta3, *alpha3;
   const float* drop;        // [n][C] or nullptr
-  const void* skip;         // [npix][C]                       (F, B1)
+  const void* skip;         // [npix][c_skip]: the first c_skip channels of the skip branch, zeros beyond   (F, B1)
+  int c_skip;
   const void* dout;         // [npix][C]                       (B1)
   const void* dsum_in;      // [npix][C]                       (B2)
   const float* coef;        // k1 | m1 | m2, C floats each     (B2)
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   // offsets below are byte offsets of a float32 tensor; the bf16 accessors halve them (common.h)
   const unsigned wide_bytes = (unsigned)a.npix * (unsigned)C * 4u;
   const __amdgpu_buffer_rsrc_t ry2 = Act<T>::rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
-  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(MODE == 1 || MODE == 2 ? a.skip : a.y2, MODE == 1 || MODE == 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(MODE == 1 || MODE == 2 ? a.skip : a.y2,
+                                                    MODE == 1 || MODE == 2 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
+  const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
   const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(MODE == 2 ? a.dout : (MODE == 3 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 ? a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(MODE == 1 && a.y3_out ? a.y3_out : (void*)a.part, MODE == 1 && a.y3_out ? wide_bytes : 0u);
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     for (int q = 0; q < NPASS; ++q) {
       const unsigned p = p0 + (unsigned)(q * PL + pl);
       const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB;
-      if constexpr (MODE == 1 || MODE == 2) xs[q] = Act<T>::ld4r(rskip, off);
+      if constexpr (MODE == 1 || MODE == 2)
+        xs[q] = Act<T>::ld4r(rskip, (p < (unsigned)a.npix && has_skip) ? (p * (unsigned)a.c_skip + (unsigned)c) * 4u : kOOB);
       if constexpr (MODE >= 2) dv[q] = Act<T>::ld4r(rd, off);
     }
     __syncthreads();                           // the previous tile's staged accumulators have been read (first tile: W is in LDS)
@@ -332,16 +336,17 @@ ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, c
 }
 
 ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
-                                  const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, const float* alpha,
-                                  void* out, void* y3_out, void* stream) {
+                                  const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
+                                  const float* alpha, void* out, void* y3_out, void* stream) {
   SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_fwd: 16 -> 64 or 32 -> 128 channel expansions only");
   SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd && bn3->gamma &&
                bn3->beta && skip && alpha && out, SSMI_E_INVALID_ARG, "expand_merge_fwd: NULL argument");
+  SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE, "expand_merge_fwd: skip channels must be a multiple of 4 within the output's");
   SSMI_REQUIRE(aligned16({x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma, bn3->beta,
                           drop, skip, alpha, out}), SSMI_E_INVALID_ARG, "expand_merge_fwd: pointers must be 16-byte aligned");
   ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
   a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
-  a.drop = drop; a.skip = skip; a.out = out;
+  a.drop = drop; a.skip = skip; a.c_skip = c_skip; a.out = out;
   a.y3_out = y3_out;
   SSMI_REQUIRE(aligned16({y3_out}), SSMI_E_INVALID_ARG, "expand_merge_fwd: pointers must be 16-byte aligned");
   return launch_expand<1>(d, a, nullptr, as_stream(stream));
@@ -349,12 +354,13 @@ ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, 
 
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
                                   const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
-                                  const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
+                                  int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
                                   size_t ws_bytes, void* stream) {
   SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_bwd: 16 -> 64 or 32 -> 128 channel expansions only");
   SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
                bn3->gamma && bn3->beta && skip && alpha && dmain && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
                "expand_merge_bwd: NULL argument");
+  SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE, "expand_merge_bwd: skip channels must be a multiple of 4 within the output's");
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "expand_merge_bwd: workspace too small");
   SSMI_REQUIRE(aligned16({dout, x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma,
                           bn3->beta, drop, skip, alpha, dmain, dsum, ws}), SSMI_E_INVALID_ARG,
@@ -362,7 +368,7 @@ ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, c
   hipStream_t st = as_stream(stream);
   ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
   a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
-  a.drop = drop; a.skip = skip; a.dout = dout;
+  a.drop = drop; a.skip = skip; a.c_skip = c_skip; a.dout = dout;
   a.out = dsum;
   a.part = static_cast<float*>(ws);
   float* coef = a.part + (size_t)kExpandMaxGrid * 3 * d->cout;

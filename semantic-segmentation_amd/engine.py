@@ -707,13 +707,13 @@ class Bottleneck(Block):
         md.dtype = self.store.dtype_code
         self.md = md
         self._mref = C.byref(md)
-        # Regular bottleneck, training phase: the expansion's output y3 is never stored - statistics, merge
+        # Regular and downsampling bottlenecks, training phase: the expansion's output y3 is never stored - statistics, merge
         # forward and both merge-backward passes recompute it from the raw output of conv2 (ssmi_expand_*).  SSMI_NO_EXPAND=1
         # keeps the stored route; keep_y3 (tests) has the forward kernel store y3 as well.
         self.expand = None
         # (bfloat16 storage: built and tested, but measured slower than the stored route - 6.89 against 6.67 ms per ENet step: the
         # recomputation costs what it costs with float32 while the tensors it avoids are half the size; SSMI_EXPAND_BF16=1 opts in)
-        if (self.mode == 0 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok
+        if (self.mode <= 1 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok
                 and (self.store.dtype_code == F32 or os.environ.get("SSMI_EXPAND_BF16"))):
             ed = ExpandDesc()
             ed.n, ed.h, ed.w, ed.cin, ed.cout, ed.dtype = n, h2, w2, i, c, self.store.dtype_code
@@ -774,8 +774,12 @@ class Bottleneck(Block):
             L0.expand_bn_stats(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), BN_EPS, BN_MOMENTUM,
                                1 if ub else 0, _ptr(bn3.mm) if um else None, _ptr(bn3.mv) if um else None, _ptr(bn3.mean),
                                _ptr(bn3.invstd), _ptr(ws), ws.numel() * 4, st)
+            skip, c_skip = x, self.cout
+            if self.mode == 1:      # downsampling block: the skip branch is the max-pooled input, channel-padded with zeros
+                L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin, _ptr(self.idx), None, st)
+                skip, c_skip = self.pooled, self.cin
             L0.expand_merge_fwd(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), bn3._pref, _ptr(drop),
-                                _ptr(x), _ptr(self.alpha3), _ptr(self.out), _ptr(self.y3) if self.keep_y3 else None, st)
+                                _ptr(skip), c_skip, _ptr(self.alpha3), _ptr(self.out), _ptr(self.y3) if self.keep_y3 else None, st)
             return self.out
         if tr and getattr(self, "_pre3", False):
             self.conv3.fwd_bn_prebn(self.y2, self.bn2, self.y3, self.bn3, um, ub, ws, st)
@@ -806,7 +810,8 @@ class Bottleneck(Block):
         before3 = None
         if self._expanded:
             lib().expand_merge_bwd(self._eref, _ptr(dout), _ptr(self.y2), self.bn2._pref, _ptr(self.bn2.alpha), _ptr(self.conv3.w),
-                                   self.bn3._pref, _ptr(self._drop_used), _ptr(self.x), _ptr(self.alpha3), _ptr(self.dy3),
+                                   self.bn3._pref, _ptr(self._drop_used), _ptr(self.x if self.mode == 0 else self.pooled),
+                                   self.cout if self.mode == 0 else self.cin, _ptr(self.alpha3), _ptr(self.dy3),
                                    _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
         elif premerge:
             L.merge_bwd_deferred(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o,
