@@ -667,7 +667,13 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *   ssmi_expand_merge_fwd  out = PReLU_alpha(drop * BN3(y3) + skip); y3_out (nullable): also store y3 (tests, debugging)
  *   ssmi_expand_merge_bwd  dsum = gradient of the pre-activation sum (= gradient of the skip branch), dmain = gradient of
  *                          y3, dgamma3 / dbeta3 / dalpha overwritten - as ssmi_merge_bwd
- * Outputs equal the stored route's up to the order of the float32 sums inside y3. */
+ *   ssmi_expand_merge_bwd_chained  the same with dout FORMED per tile instead of read: the block that follows a regular
+ *                          bottleneck starts with a 1x1 reduction of that block's output (src/models.py:1090-1096), so
+ *                          dout = dy_next * w_next^T + dsum_next (dy_next [n,h,w,cin]: the gradient at that reduction's output,
+ *                          w_next [cout][cin]: its kernel, dsum_next [n,h,w,cout]: the following block's skip gradient) - the
+ *                          transposed product has the expansion's shape, and dout is neither written nor read.  Replaces the
+ *                          following block's ssmi_conv2d_bwd_data(add = dsum_next) + this block's ssmi_expand_merge_bwd.
+ * Outputs equal the stored route's up to the order of the float32 sums inside y3 (and inside dout). */
 typedef struct ssmi_expand_desc {
   int32_t n, h, w, cin, cout;
   int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x_raw, skip, out, dout, dsum, dmain, y3_out */
@@ -684,6 +690,11 @@ ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, c
                                   const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
                                   int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
                                   size_t ws_bytes, void* stream);
+ssmi_status ssmi_expand_merge_bwd_chained(const ssmi_expand_desc* d, const void* dy_next, const float* w_next, const void* dsum_next,
+                                          const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha, const float* w,
+                                          const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
+                                          void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
+                                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -8,6 +8,9 @@
 //   mode F   out = PReLU3(drop * BN3(y3) + skip)                                      (ssmi_merge_fwd, identity skip)
 //   mode B1  dsum = dout * PReLU3'(s), column sums of dz, dz * xhat3, dout * min(s, 0) (ssmi_merge_bwd, reducing pass)
 //   mode B2  dmain = k1 * (dsum * drop - m1 - xhat3 * m2)                              (ssmi_merge_bwd, apply pass)
+//   mode B1c mode B1 whose dout is not read but formed in place: dout = dy1' * W1'^T + dsum', the data gradient of the NEXT
+//            block's 1x1 reduction (src/models.py:1090-1096) plus that block's skip gradient - the same (C/4 -> C) product
+//            shape as the expansion, so the tile loop runs two products and dout is neither written nor read
 // with the arithmetic of the merge kernels per element.  A 256-thread workgroup walks 64-pixel (64 channels) or 32-pixel (128 channels) tiles: the raw input tile is
 // normalised on its way into LDS, four waves multiply (pixel blocks x channel groups, kernel matrix resident in LDS), the
 // accumulators go through LDS, and the elementwise phase runs in the merge kernels' layout - a thread owns four consecutive
@@ -27,7 +30,9 @@ struct ExpandArgs {
   const float* drop;        // [n][C] or nullptr
   const void* skip;         // [npix][c_skip]: the first c_skip channels of the skip branch, zeros beyond   (F, B1)
   int c_skip;
-  const void* dout;         // [npix][C]                       (B1)
+  const void* dout;         // [npix][C]                       (B1; B1c: the next block's skip gradient dsum')
+  const void* dy_next;      // [npix][C4] gradient at the output of the next block's 1x1 reduction   (B1c)
+  const float* w_next;      // [C][C4] that reduction's kernel                                       (B1c)
   const void* dsum_in;      // [npix][C]                       (B2)
   const float* coef;        // k1 | m1 | m2, C floats each     (B2)
   void* out;                // F: block output; B1: dsum; B2: dmain
@@ -46,12 +51,16 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   constexpr int NT = C / (32 * CWN);          // 32-column tiles per wave
   constexpr int P4 = C4 / 4, NY = TP * P4 / 256;
   constexpr int NS = MODE == 0 ? 2 : 3;
-  constexpr bool kSums = MODE == 0 || MODE == 2;
+  constexpr bool kB1 = MODE == 2 || MODE == 4, kChain = MODE == 4;
+  constexpr bool kSums = MODE == 0 || kB1;
   static_assert(NY >= 1 && 256 % P4 == 0 && 256 % G == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* const Wl = sm;                       // [C4][C]
   float* const Al = Wl + C4 * C;              // [TP][AS]
   float* const St = Al + ((TP * AS + 3) & ~3);      // [TP][SS], later the reduction scratch
+  float* const Wn = St + TP * SS;             // B1c: [C4][C], the next block's reduction kernel transposed
+  float* const An = Wn + C4 * C;              // B1c: [TP][AS]
+  float* const Sn = An + ((TP * AS + 3) & ~3);      // B1c: [TP][SS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int pw = wave % PWN, cw = wave / PWN;
@@ -60,6 +69,15 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e);
     if constexpr (kBf) wv = unpack_bf16x4(pack_bf16x4(wv));      // the bf16 route multiplies bf16-rounded kernels (its packs)
     *reinterpret_cast<f32x4*>(Wl + e) = wv;
+  }
+  if constexpr (kChain) {
+    for (int e = tid * 4; e < C4 * C; e += 1024) {      // w_next[c][k..k+3] -> Wn[k..k+3][c]
+      f32x4 wv = *reinterpret_cast<const f32x4*>(a.w_next + e);
+      if constexpr (kBf) wv = unpack_bf16x4(pack_bf16x4(wv));
+      const int cc = e / C4, k0 = e % C4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Wn[(k0 + j) * C + cc] = wv[j];
+    }
   }
 
   // the thread's four input channels (normalise-on-load role) and their BN2 / PReLU2 parameters
@@ -78,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     m3 = *reinterpret_cast<const f32x4*>(a.mean3 + c);
     is3 = *reinterpret_cast<const f32x4*>(a.invstd3 + c);
   }
-  if constexpr (MODE == 1 || MODE == 2) {
+  if constexpr (MODE == 1 || kB1) {
     g3 = *reinterpret_cast<const f32x4*>(a.gamma3 + c);
     b3 = *reinterpret_cast<const f32x4*>(a.beta3 + c);
     al3 = *reinterpret_cast<const f32x4*>(a.alpha3 + c);
@@ -98,10 +116,11 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   // offsets below are byte offsets of a float32 tensor; the bf16 accessors halve them (common.h)
   const unsigned wide_bytes = (unsigned)a.npix * (unsigned)C * 4u;
   const __amdgpu_buffer_rsrc_t ry2 = Act<T>::rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
-  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(MODE == 1 || MODE == 2 ? a.skip : a.y2,
-                                                    MODE == 1 || MODE == 2 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(MODE == 1 || kB1 ? a.skip : a.y2,
+                                                    MODE == 1 || kB1 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rdn = Act<T>::rsrc(kChain ? a.dy_next : a.y2, kChain ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
   const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
-  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(MODE == 2 ? a.dout : (MODE == 3 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (MODE == 3 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 ? a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(MODE == 1 && a.y3_out ? a.y3_out : (void*)a.part, MODE == 1 && a.y3_out ? wide_bytes : 0u);
   auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off4, const f32x4& val) {      // out-of-range offsets are dropped
@@ -113,18 +132,20 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const unsigned p0 = (unsigned)t * TP;
     // every global operand of the tile, requested up front
-    typename Act<T>::raw4 yv[NY];      // raw while in flight, widened at the use
+    typename Act<T>::raw4 yv[NY], nv[kChain ? NY : 1];      // raw while in flight, widened at the use
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const unsigned p = p0 + (unsigned)((tid + 256 * j) / P4);
-      yv[j] = Act<T>::ld4r(ry2, p < (unsigned)a.npix ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB);
+      const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB;
+      yv[j] = Act<T>::ld4r(ry2, off);
+      if constexpr (kChain) nv[j] = Act<T>::ld4r(rdn, off);
     }
-    typename Act<T>::raw4 xs[MODE == 1 || MODE == 2 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
+    typename Act<T>::raw4 xs[MODE == 1 || kB1 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       const unsigned p = p0 + (unsigned)(q * PL + pl);
       const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB;
-      if constexpr (MODE == 1 || MODE == 2)
+      if constexpr (MODE == 1 || kB1)
         xs[q] = Act<T>::ld4r(rskip, (p < (unsigned)a.npix && has_skip) ? (p * (unsigned)a.c_skip + (unsigned)c) * 4u : kOOB);
       if constexpr (MODE >= 2) dv[q] = Act<T>::ld4r(rd, off);
     }
@@ -139,6 +160,11 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         if constexpr (kBf) av = (float)(bf16)av;      // as the stored normalised tensor would have been rounded
         Al[px * AS + yc + e] = av;
       }
+      if constexpr (kChain) {
+        const f32x4 nw = Act<T>::up4(nv[j]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) An[px * AS + yc + e] = nw[e];
+      }
     }
     __syncthreads();
     f32x16 acc[NT];
@@ -152,6 +178,24 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       const float av = Al[(pw * 32 + r) * AS + k];
 #pragma unroll
       for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / CWN) + u * 32 + r], acc[u], 0, 0, 0);
+    }
+    if constexpr (kChain) {      // the data gradient of the next block's reduction, staged beside y3
+      f32x16 accn[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accn[u][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C4 / 2; ++s) {
+        const int k = 2 * s + hh;
+        const float av = An[(pw * 32 + r) * AS + k];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) accn[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wn[k * C + cw * (C / CWN) + u * 32 + r], accn[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Sn[(pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * SS + cw * (C / CWN) + u * 32 + r] = accn[u][i];
     }
     if constexpr (MODE == 0) {      // statistics straight from the accumulators: a lane owns 16 pixels of one channel per tile
       const bool full = p0 + TP <= (unsigned)a.npix;      // uniform
@@ -182,8 +226,16 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       const bool live = p < (unsigned)a.npix;
       const f32x4 y3 = *reinterpret_cast<const f32x4*>(St + lp * SS + c);
       f32x4 xq = {0.f, 0.f, 0.f, 0.f}, dq = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (MODE == 1 || MODE == 2) xq = Act<T>::up4(xs[q]);
+      if constexpr (MODE == 1 || kB1) xq = Act<T>::up4(xs[q]);
       if constexpr (MODE >= 2) dq = Act<T>::up4(dv[q]);
+      if constexpr (kChain) {      // dout = data gradient + the next block's skip gradient (bfloat16: rounded as the stored dout was)
+        const f32x4 dg = *reinterpret_cast<const f32x4*>(Sn + lp * SS + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dq[e] += dg[e];
+          if constexpr (kBf) dq[e] = (float)(bf16)dq[e];
+        }
+      }
       f32x4 dr = {1.f, 1.f, 1.f, 1.f};
       if constexpr (MODE != 0) {
         if (a.drop) dr = *reinterpret_cast<const f32x4*>(a.drop + (size_t)((live ? p : 0u) / (unsigned)a.hw) * C + c);
@@ -275,12 +327,12 @@ static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a,
     using T = decltype(tag);
     if (d->cin == 16) {
       constexpr int C4 = 16, C = 64, TP = 64;
-      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4;
+      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1);
       hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
     } else {
       constexpr int C4 = 32, C = 128, TP = 32;
       // (the reduction scratch of the summing modes, 3 sums x 8 pixel lanes x 128 channels, fits the staged tile)
-      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4;
+      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1);
       hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
     }
     SSMI_LAUNCH_CHECK();
@@ -352,28 +404,32 @@ ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, 
   return launch_expand<1>(d, a, nullptr, as_stream(stream));
 }
 
-ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
-                                  const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
-                                  int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
-                                  size_t ws_bytes, void* stream) {
-  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_bwd: 16 -> 64 or 32 -> 128 channel expansions only");
+// dout given (dy_next, w_next null): the reducing pass reads it; dy_next and w_next given: dout is formed per tile as
+// dy_next * w_next^T + dout_or_dsum_next and never stored.
+static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc* d, const void* dout, const void* dy_next, const float* w_next,
+                                         const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha, const float* w,
+                                         const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
+                                         void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
+                                         void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "%s: 16 -> 64 or 32 -> 128 channel expansions only", who);
   SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
                bn3->gamma && bn3->beta && skip && alpha && dmain && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
-               "expand_merge_bwd: NULL argument");
-  SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE, "expand_merge_bwd: skip channels must be a multiple of 4 within the output's");
-  SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "expand_merge_bwd: workspace too small");
-  SSMI_REQUIRE(aligned16({dout, x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma,
-                          bn3->beta, drop, skip, alpha, dmain, dsum, ws}), SSMI_E_INVALID_ARG,
-               "expand_merge_bwd: pointers must be 16-byte aligned");
+               "%s: NULL argument", who);
+  SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE, "%s: skip channels must be a multiple of 4 within the output's", who);
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "%s: workspace too small", who);
+  SSMI_REQUIRE(aligned16({dout, dy_next, w_next, x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd,
+                          bn3->gamma, bn3->beta, drop, skip, alpha, dmain, dsum, ws}), SSMI_E_INVALID_ARG,
+               "%s: pointers must be 16-byte aligned", who);
   hipStream_t st = as_stream(stream);
   ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
   a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
   a.drop = drop; a.skip = skip; a.c_skip = c_skip; a.dout = dout;
+  a.dy_next = dy_next; a.w_next = w_next;
   a.out = dsum;
   a.part = static_cast<float*>(ws);
   float* coef = a.part + (size_t)kExpandMaxGrid * 3 * d->cout;
   int rows = 0;
-  ssmi_status s = launch_expand<2>(d, a, &rows, st);
+  ssmi_status s = dy_next ? launch_expand<4>(d, a, &rows, st) : launch_expand<2>(d, a, &rows, st);
   if (s) return s;
   s = launch_bn_bwd_final(a.part, rows, d->cout, a.npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
   if (s) return s;
@@ -381,6 +437,24 @@ ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, c
   b.mean3 = bn3->mean; b.invstd3 = bn3->invstd;
   b.drop = drop; b.dsum_in = dsum; b.coef = coef; b.out = dmain;
   return launch_expand<3>(d, b, nullptr, st);
+}
+
+ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
+                                  const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
+                                  int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  return expand_merge_bwd_impl("expand_merge_bwd", d, dout, nullptr, nullptr, x_raw, pre, pre_alpha, w, bn3, drop, skip, c_skip, alpha, dmain,
+                               dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream);
+}
+
+ssmi_status ssmi_expand_merge_bwd_chained(const ssmi_expand_desc* d, const void* dy_next, const float* w_next, const void* dsum_next,
+                                          const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha, const float* w,
+                                          const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
+                                          void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  SSMI_REQUIRE(dy_next && w_next && dsum_next, SSMI_E_INVALID_ARG, "expand_merge_bwd_chained: NULL argument");
+  return expand_merge_bwd_impl("expand_merge_bwd_chained", d, dsum_next, dy_next, w_next, x_raw, pre, pre_alpha, w, bn3, drop, skip, c_skip,
+                               alpha, dmain, dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -576,6 +576,32 @@ class InitialBlock(Block):
 _NO_FUSED_INFER_MERGE = os.environ.get("SSMI_NO_FUSED_INFER_MERGE") is not None    # A/B switch for measurements
 
 
+class DeferredInputGradient:
+    """The input gradient of a regular bottleneck, not formed yet: dx = dy1 * W1^T + dsum (the data gradient of its 1x1
+    reduction, src/models.py:1090-1096, plus its skip gradient).  A bottleneck in front that recomputes its expansion consumes
+    the three operands in its own merge backward (ssmi_expand_merge_bwd_chained: dx is neither written nor read); any other
+    consumer gets the tensor from materialise()."""
+
+    def __init__(self, block):
+        self.block = block
+
+    def materialise(self, cfg):
+        b = self.block
+        b.conv1.bwd_data(b.da1, b.dx, cfg.st, add=b.dsum)
+        return b.dx
+
+
+def run_backward(blocks_last_to_first, d, cfg):
+    """Backward pass over blocks (given last block first), weight gradients flushed to the side chain after every block.
+    Returns the gradient of the first block's input (a tensor)."""
+    for b in blocks_last_to_first:
+        if isinstance(d, DeferredInputGradient) and not (isinstance(b, Bottleneck) and b.accepts(d)):
+            d = d.materialise(cfg)
+        d = b.bwd(d, cfg)
+        cfg.flush()
+    return d.materialise(cfg) if isinstance(d, DeferredInputGradient) else d
+
+
 class Bottleneck(Block):
     """Encoder bottleneck (src/models.py:1069-1174 / 1373-1481) and decoder bottleneck (1208-1299 / 1520-1610).
 
@@ -722,7 +748,15 @@ class Bottleneck(Block):
                 self._eref = C.byref(ed)
         self._expanded = False
         self.keep_y3 = bool(os.environ.get("SSMI_KEEP_Y3"))
+        # A regular bottleneck whose own expansion is recomputed has the shapes the chained merge backward of the block in front
+        # needs (cin -> cin/4 reduction): it hands its input gradient over unformed (DeferredInputGradient).  SSMI_NO_CHAIN=1: never.
+        self.defers = self.mode == 0 and self.expand is not None and self.cin == self.cout and not os.environ.get("SSMI_NO_CHAIN")
         return (h2, w2, c)
+
+    def accepts(self, d: DeferredInputGradient):
+        nb = d.block
+        return (self._expanded and self.cout == nb.cin and self.expand.cin == nb.internal
+                and (self.n, self.ho, self.wo) == (nb.n, nb.hin, nb.win))
 
     def _merge_other(self):
         if self.mode == 0:
@@ -808,7 +842,15 @@ class Bottleneck(Block):
         # on its stream.
         premerge = self.conv3.premerge_ok and self.conv3.wrot is not None
         before3 = None
-        if self._expanded:
+        self._chained = self._expanded and isinstance(dout, DeferredInputGradient)
+        if self._chained:
+            nb = dout.block
+            lib().expand_merge_bwd_chained(self._eref, _ptr(nb.da1), _ptr(nb.conv1.w), _ptr(nb.dsum), _ptr(self.y2), self.bn2._pref,
+                                           _ptr(self.bn2.alpha), _ptr(self.conv3.w), self.bn3._pref, _ptr(self._drop_used),
+                                           _ptr(self.x if self.mode == 0 else self.pooled), self.cout if self.mode == 0 else self.cin,
+                                           _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta),
+                                           _ptr(self.dalpha3), _ptr(ws), wsb, st)
+        elif self._expanded:
             lib().expand_merge_bwd(self._eref, _ptr(dout), _ptr(self.y2), self.bn2._pref, _ptr(self.bn2.alpha), _ptr(self.conv3.w),
                                    self.bn3._pref, _ptr(self._drop_used), _ptr(self.x if self.mode == 0 else self.pooled),
                                    self.cout if self.mode == 0 else self.cin, _ptr(self.alpha3), _ptr(self.dy3),
@@ -854,6 +896,8 @@ class Bottleneck(Block):
         # conv1 + skip branch
         cfg.wgrad(self.conv1, self.x, self.da1)
         if self.mode == 0:
+            if self.defers and self._expanded:
+                return DeferredInputGradient(self)
             self.conv1.bwd_data(self.da1, self.dx, st, add=self.dsum)
         elif self.mode == 1:
             self.conv1.bwd_data(self.da1, self.dx, st)
@@ -1234,10 +1278,7 @@ class GraphBase:
     def backward(self, dlogits: torch.Tensor):
         cfg = self._cfg
         self.rotate_weights(cfg.st)
-        d = dlogits
-        for b in reversed(self.blocks):
-            d = b.bwd(d, cfg)
-            cfg.flush()
+        run_backward(reversed(self.blocks), dlogits, cfg)
         cfg.join()
 
     def refresh_dropout(self, seed: int, step_block: torch.Tensor, stream: Optional[int] = None):

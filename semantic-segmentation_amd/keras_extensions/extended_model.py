@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .._lib import lib
-from ..engine import ENetGraph, _ptr
+from ..engine import ENetGraph, _ptr, run_backward
 from .. import metrics as metrics_mod
 
 
@@ -500,10 +500,7 @@ class ExtendedModel(object):
 
         def seg_bwd(j):
             def run(st):
-                d = carry["d"]
-                for b in reversed(blocks[bounds[j + 1]:bounds[j]]):
-                    d = b.bwd(d, g._cfg)
-                    g._cfg.flush()
+                d = run_backward(reversed(blocks[bounds[j + 1]:bounds[j]]), carry["d"], g._cfg)
                 if self.grad_sync is not None or j == len(bounds) - 2:
                     g._cfg.join()       # a bucket must be complete before its all-reduce starts
                 carry["d"] = d

@@ -20,6 +20,8 @@ float32.  Three layers of checks:
     exact oracle than 1.5x the bfloat16-storage oracle's; pooling indices bit-exact against the oracle's pooling of the
     kernel's own (rounded) input, confusion matrix bit-exact against the argmax of the kernel's own logits;
   * training: the loss falls over 30 steps, HIP-graph replay equals eager launches bit for bit."""
+import types
+
 import numpy as np
 import pytest
 import torch
@@ -593,6 +595,15 @@ def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed, expand, mon
     assert np.array_equal(outs[4], K.confusion_matrix_np(labels, hip_logits, NC, [0]))
     # --- block by block on the kernels' own tensors, rtol 2e-2 -----------------------------------------------------------
     blocks = g.blocks
+    # a block whose merge backward formed its dout inside the kernel (chained route) left the next block's input gradient
+    # unformed: form it now from the operands the step left behind, so that the replay below has every block's dout - the
+    # chained kernels themselves are then held to the oracle through their blocks' gradients
+    chained = [i for i, blk in enumerate(blocks) if getattr(blk, "_chained", False)]
+    assert bool(chained) == expand
+    for i in chained:
+        pkg("engine").DeferredInputGradient(blocks[i + 1]).materialise(
+            types.SimpleNamespace(st=torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
     worst = {"out": (0.0, ""), "dx": (0.0, ""), "grad": (0.0, "")}
 
     def note(kind, e, what):
