@@ -673,7 +673,13 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *                          w_next [cout][cin]: its kernel, dsum_next [n,h,w,cout]: the following block's skip gradient) - the
  *                          transposed product has the expansion's shape, and dout is neither written nor read.  Replaces the
  *                          following block's ssmi_conv2d_bwd_data(add = dsum_next) + this block's ssmi_expand_merge_bwd.
- * Outputs equal the stored route's up to the order of the float32 sums inside y3 (and inside dout). */
+ *   ssmi_expand_merge_bwd_through  either of the two (dout, or dy_next + w_next + dsum_next; the others NULL) carried through
+ *                          the expansion's own data gradient and the backward of the BatchNormalization + PReLU in front of it:
+ *                          dy2 [n,h,w,cin] = gradient at x_raw, dgamma2 / dbeta2 / dalpha2 (NULL without pre_alpha) overwritten.
+ *                          The apply pass multiplies its dmain tile with w^T in place and takes BN2's column sums there; dmain
+ *                          is still stored (the weight gradient of the expansion reads it).  Replaces ssmi_expand_merge_bwd +
+ *                          ssmi_conv2d_bwd_data_bn_bwd of the expansion.
+ * Outputs equal the stored route's up to the order of the float32 sums inside y3 (and inside dout, da2). */
 typedef struct ssmi_expand_desc {
   int32_t n, h, w, cin, cout;
   int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x_raw, skip, out, dout, dsum, dmain, y3_out */
@@ -694,6 +700,12 @@ ssmi_status ssmi_expand_merge_bwd_chained(const ssmi_expand_desc* d, const void*
                                           const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha, const float* w,
                                           const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
                                           void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
+                                          void* stream);
+ssmi_status ssmi_expand_merge_bwd_through(const ssmi_expand_desc* d, const void* dout, const void* dy_next, const float* w_next,
+                                          const void* dsum_next, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                          const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
+                                          const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha,
+                                          void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, void* ws, size_t ws_bytes,
                                           void* stream);
 
 #ifdef __cplusplus

@@ -115,6 +115,8 @@ _PROTOS = {
     "ssmi_expand_merge_bwd": (_i32, [_PE, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_expand_merge_bwd_chained": (_i32, [_PE, _vp, _vp, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _sz, _vp]),
+    "ssmi_expand_merge_bwd_through": (_i32, [_PE, _vp, _vp, _vp, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_merge_bwd": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_maxpool_argmax_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "ssmi_maxpool_argmax_bwd": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -8,6 +8,10 @@
 //   mode F   out = PReLU3(drop * BN3(y3) + skip)                                      (ssmi_merge_fwd, identity skip)
 //   mode B1  dsum = dout * PReLU3'(s), column sums of dz, dz * xhat3, dout * min(s, 0) (ssmi_merge_bwd, reducing pass)
 //   mode B2  dmain = k1 * (dsum * drop - m1 - xhat3 * m2)                              (ssmi_merge_bwd, apply pass)
+//   mode B2t mode B2 carried THROUGH the expansion's own data gradient: the dmain tile goes back into LDS and is multiplied
+//            with W3^T (split over the waves along its 64 / 128 channels), da2 = dmain * W3^T is stored together with the column
+//            sums BN2's backward needs (sum dz, sum dz * xhat2, sum da2 * min(z2, 0): ssmi_conv2d_bwd_data_bn_bwd's) - dmain
+//            is still stored (the expansion's weight gradient reads it) but not read again on the main chain
 //   mode B1c mode B1 whose dout is not read but formed in place: dout = dy1' * W1'^T + dsum', the data gradient of the NEXT
 //            block's 1x1 reduction (src/models.py:1090-1096) plus that block's skip gradient - the same (C/4 -> C) product
 //            shape as the expansion, so the tile loop runs two products and dout is neither written nor read
@@ -38,6 +42,8 @@ struct ExpandArgs {
   void* out;                // F: block output; B1: dsum; B2: dmain
   void* y3_out;             // F only, nullable: also store the recomputed expansion output (tests, debugging)
   float* part;              // S: [grid][2][C]; B1: [grid][3][C]
+  void* da2;                // B2t: [npix][C4] gradient at the expansion's (normalised) input
+  float* part2;             // B2t: [grid][3][C4]
 };
 
 template <typename T, int C4, int C, int MODE>
@@ -52,6 +58,10 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   constexpr int P4 = C4 / 4, NY = TP * P4 / 256;
   constexpr int NS = MODE == 0 ? 2 : 3;
   constexpr bool kB1 = MODE == 2 || MODE == 4, kChain = MODE == 4;
+  constexpr bool kB2 = MODE == 3 || MODE == 5, kThru = MODE == 5;
+  constexpr int KS = CWN, KW = C / KS;        // B2t: the waves of a pixel block split the reduction over the C channels
+  constexpr int WTS = 33;                     // B2t: row stride of W3^T (columns beyond C4 are zero) and of the partial products
+  static_assert(!kThru || (NY == 1 && KW % 2 == 0), "shape");
   constexpr bool kSums = MODE == 0 || kB1;
   static_assert(NY >= 1 && 256 % P4 == 0 && 256 % G == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -61,6 +71,8 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   float* const Wn = St + TP * SS;             // B1c: [C4][C], the next block's reduction kernel transposed
   float* const An = Wn + C4 * C;              // B1c: [TP][AS]
   float* const Sn = An + ((TP * AS + 3) & ~3);      // B1c: [TP][SS]
+  float* const Wt = St + TP * SS;             // B2t: [C][WTS]
+  float* const Pn = Wt + C * WTS;             // B2t: [KS][TP][WTS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int pw = wave % PWN, cw = wave / PWN;
@@ -69,6 +81,13 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e);
     if constexpr (kBf) wv = unpack_bf16x4(pack_bf16x4(wv));      // the bf16 route multiplies bf16-rounded kernels (its packs)
     *reinterpret_cast<f32x4*>(Wl + e) = wv;
+  }
+  if constexpr (kThru) {
+    __syncthreads();
+    for (int e = tid; e < C * 32; e += 256) {
+      const int cc = e >> 5, n = e & 31;
+      Wt[cc * WTS + n] = n < C4 ? Wl[n * C + cc] : 0.f;
+    }
   }
   if constexpr (kChain) {
     for (int e = tid * 4; e < C4 * C; e += 1024) {      // w_next[c][k..k+3] -> Wn[k..k+3][c]
@@ -101,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     b3 = *reinterpret_cast<const f32x4*>(a.beta3 + c);
     al3 = *reinterpret_cast<const f32x4*>(a.alpha3 + c);
   }
-  if constexpr (MODE == 3) {
+  if constexpr (kB2) {
     k1 = *reinterpret_cast<const f32x4*>(a.coef + c);
     q1 = *reinterpret_cast<const f32x4*>(a.coef + C + c);
     q2 = *reinterpret_cast<const f32x4*>(a.coef + 2 * C + c);
@@ -109,6 +128,9 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   f32x4 v[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 v2[3];              // mode B2t: this thread's sums over its four input channels
+#pragma unroll
+  for (int k = 0; k < 3; ++k) v2[k] = f32x4{0.f, 0.f, 0.f, 0.f};
   float lane_s[NT][2];      // mode S: this lane's column sums (channel cw * C/2 + u * 32 + r)
 #pragma unroll
   for (int u = 0; u < NT; ++u) lane_s[u][0] = lane_s[u][1] = 0.f;
@@ -120,7 +142,8 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
                                                     MODE == 1 || kB1 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
   const __amdgpu_buffer_rsrc_t rdn = Act<T>::rsrc(kChain ? a.dy_next : a.y2, kChain ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
   const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
-  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (MODE == 3 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (kB2 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rda = Act<T>::rsrc(kThru ? a.da2 : (void*)a.part, kThru ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
   const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 ? a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(MODE == 1 && a.y3_out ? a.y3_out : (void*)a.part, MODE == 1 && a.y3_out ? wide_bytes : 0u);
   auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off4, const f32x4& val) {      // out-of-range offsets are dropped
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       if constexpr (MODE != 0) {
         if (a.drop) dr = *reinterpret_cast<const f32x4*>(a.drop + (size_t)((live ? p : 0u) / (unsigned)a.hw) * C + c);
       }
-      if constexpr (MODE == 3) {
+      if constexpr (kB2) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -248,6 +271,11 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           o[e] = k1[e] * (dq[e] * dr[e] - q1[e] - xh * q2[e]);
         }
         store4(ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, o);
+        if constexpr (kThru) {      // the tile goes back where this thread read y3 from (bfloat16: as the stored dmain is rounded)
+          if constexpr (kBf) o = unpack_bf16x4(pack_bf16x4(o));
+          if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          *reinterpret_cast<f32x4*>(St + lp * SS + c) = o;
+        }
       } else {
         f32x4 o;
 #pragma unroll
@@ -268,6 +296,56 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         }
         store4(ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, o);
         if constexpr (MODE == 1) store4(ry3, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, y3);      // (empty descriptor: dropped)
+      }
+    }
+    if constexpr (kThru) {
+      __syncthreads();
+      f32x16 acd;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acd[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KW / 2; ++s) {
+        const int k = cw * KW + 2 * s + hh;
+        acd = __builtin_amdgcn_mfma_f32_32x32x2f32(St[(pw * 32 + r) * SS + k], Wt[k * WTS + r], acd, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) Pn[(cw * TP + pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * WTS + r] = acd[i];
+      __syncthreads();
+      // the thread that normalised (pixel, four input channels) on the way in finishes them: raw y2 is still in its registers
+      const int px = tid / P4;
+      const bool live2 = p0 + (unsigned)px < (unsigned)a.npix;
+      const f32x4 yw = Act<T>::up4(yv[0]);
+      f32x4 da;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = Pn[px * WTS + yc + e];
+#pragma unroll
+        for (int k2 = 1; k2 < KS; ++k2) d += Pn[(k2 * TP + px) * WTS + yc + e];
+        da[e] = d;
+        const float xh = (yw[e] - m2[e]) * is2[e];
+        const float z = g2[e] * xh + b2[e];
+        const float gr = !act2 ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al2[e] : 0.f));
+        const float dz = live2 ? d * gr : 0.f;
+        v2[0][e] += dz;
+        v2[1][e] += dz * xh;
+        v2[2][e] += (live2 && act2) ? d * (z < 0.f ? z : 0.f) : 0.f;
+      }
+      store4(rda, live2 ? ((p0 + (unsigned)px) * (unsigned)C4 + (unsigned)yc) * 4u : kOOB, da);
+    }
+  }
+  if constexpr (kThru) {      // one row of BN2-backward sums per workgroup, pixels added in a fixed order
+    __syncthreads();
+    float* red = St;          // [3][TP][C4]
+    const int px = tid / P4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(red + (k * TP + px) * C4 + yc) = v2[k];
+    __syncthreads();
+    if (tid < C4) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float t2 = 0.f;
+        for (int p2 = 0; p2 < TP; ++p2) t2 += red[(k * TP + p2) * C4 + tid];
+        a.part2[((size_t)blockIdx.x * 3 + k) * C4 + tid] = t2;
       }
     }
   }
@@ -327,12 +405,14 @@ static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a,
     using T = decltype(tag);
     if (d->cin == 16) {
       constexpr int C4 = 16, C = 64, TP = 64;
-      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1);
+      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1) +
+                         (MODE == 5 ? (size_t)(C * 33 + 4 * 32 * 33) * 4 : 0);
       hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
     } else {
       constexpr int C4 = 32, C = 128, TP = 32;
       // (the reduction scratch of the summing modes, 3 sums x 8 pixel lanes x 128 channels, fits the staged tile)
-      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1);
+      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1) +
+                         (MODE == 5 ? (size_t)(C * 33 + 4 * 32 * 33) * 4 : 0);
       hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
     }
     SSMI_LAUNCH_CHECK();
@@ -366,7 +446,8 @@ int32_t ssmi_expand_supported(const ssmi_expand_desc* d) { return expand_shape_o
 
 size_t ssmi_expand_workspace_bytes(const ssmi_expand_desc* d) {
   if (!expand_shape_ok(d)) return 0;
-  return ((size_t)kExpandMaxGrid * 3 + 3) * (size_t)d->cout * sizeof(float);      // partial rows + the apply pass's coefficients
+  // partial rows + the apply pass's coefficients, for BN3 and (ssmi_expand_merge_bwd_through) for BN2
+  return ((size_t)kExpandMaxGrid * 3 + 3) * (size_t)(d->cout + d->cin) * sizeof(float);
 }
 
 ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
@@ -410,7 +491,8 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
                                          const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha, const float* w,
                                          const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
                                          void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
-                                         void* stream) {
+                                         void* stream, void* dy2 = nullptr, float* dgamma2 = nullptr, float* dbeta2 = nullptr,
+                                         float* dalpha2 = nullptr) {
   SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "%s: 16 -> 64 or 32 -> 128 channel expansions only", who);
   SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
                bn3->gamma && bn3->beta && skip && alpha && dmain && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
@@ -436,7 +518,18 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
   ExpandArgs b = expand_args(d, x_raw, pre, pre_alpha, w);
   b.mean3 = bn3->mean; b.invstd3 = bn3->invstd;
   b.drop = drop; b.dsum_in = dsum; b.coef = coef; b.out = dmain;
-  return launch_expand<3>(d, b, nullptr, st);
+  if (!dy2) return launch_expand<3>(d, b, nullptr, st);
+  b.da2 = dy2;
+  b.part2 = coef + 3 * d->cout;
+  float* coef2 = b.part2 + (size_t)kExpandMaxGrid * 3 * d->cin;
+  s = launch_expand<5>(d, b, &rows, st);
+  if (s) return s;
+  return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {      // BN2 / PReLU2 backward in place: da2 -> dy2
+    using T = decltype(tag);
+    return launch_bn_bwd_tail<T>(b.part2, rows, static_cast<const T*>(dy2), d->cin, static_cast<const T*>(x_raw), d->cin, pre->mean,
+                                 pre->invstd, pre->gamma, pre->beta, pre_alpha ? SSMI_ACT_PRELU : SSMI_ACT_NONE, pre_alpha, 0.f, nullptr,
+                                 (int64_t)a.hw, static_cast<T*>(dy2), dgamma2, dbeta2, dalpha2, (int64_t)a.npix, d->cin, coef2, st);
+  });
 }
 
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
@@ -455,6 +548,20 @@ ssmi_status ssmi_expand_merge_bwd_chained(const ssmi_expand_desc* d, const void*
   SSMI_REQUIRE(dy_next && w_next && dsum_next, SSMI_E_INVALID_ARG, "expand_merge_bwd_chained: NULL argument");
   return expand_merge_bwd_impl("expand_merge_bwd_chained", d, dsum_next, dy_next, w_next, x_raw, pre, pre_alpha, w, bn3, drop, skip, c_skip,
                                alpha, dmain, dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream);
+}
+
+ssmi_status ssmi_expand_merge_bwd_through(const ssmi_expand_desc* d, const void* dout, const void* dy_next, const float* w_next,
+                                          const void* dsum_next, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                          const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
+                                          const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha,
+                                          void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, void* ws, size_t ws_bytes,
+                                          void* stream) {
+  SSMI_REQUIRE((dout != nullptr) != (dy_next != nullptr) && (!dy_next || (w_next && dsum_next)), SSMI_E_INVALID_ARG,
+               "expand_merge_bwd_through: give dout, or dy_next + w_next + dsum_next");
+  SSMI_REQUIRE(dy2 && dgamma2 && dbeta2 && (dalpha2 || !pre_alpha), SSMI_E_INVALID_ARG, "expand_merge_bwd_through: NULL argument");
+  SSMI_REQUIRE(aligned16({dy2}), SSMI_E_INVALID_ARG, "expand_merge_bwd_through: pointers must be 16-byte aligned");
+  return expand_merge_bwd_impl("expand_merge_bwd_through", d, dout ? dout : dsum_next, dy_next, w_next, x_raw, pre, pre_alpha, w, bn3, drop,
+                               skip, c_skip, alpha, dmain, dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream, dy2, dgamma2, dbeta2, dalpha2);
 }
 
 }  // extern "C"

@@ -750,6 +750,11 @@ class Bottleneck(Block):
         self.keep_y3 = bool(os.environ.get("SSMI_KEEP_Y3"))
         # A regular bottleneck whose own expansion is recomputed has the shapes the chained merge backward of the block in front
         # needs (cin -> cin/4 reduction): it hands its input gradient over unformed (DeferredInputGradient).  SSMI_NO_CHAIN=1: never.
+        # The expansion's data gradient + BN2 backward sums inside the merge backward's apply pass (ssmi_expand_merge_bwd_through):
+        # on for the 64-channel blocks.  Measured on the ENet 512x512 batch-16 step (ms): neither 8.06, 64 only 8.01, 128 only
+        # 8.20, both 8.13 - for 128 channels the main chain alone gets 0.15 ms shorter but the expansion's weight gradient no
+        # longer reads dy3 alongside the data gradient it used to overlap with, and the step gets longer.
+        self.through = not os.environ.get("SSMI_NO_THROUGH") and str(c) in os.environ.get("SSMI_THROUGH_C", "64").split(",")
         self.defers = self.mode == 0 and self.expand is not None and self.cin == self.cout and not os.environ.get("SSMI_NO_CHAIN")
         return (h2, w2, c)
 
@@ -843,18 +848,22 @@ class Bottleneck(Block):
         premerge = self.conv3.premerge_ok and self.conv3.wrot is not None
         before3 = None
         self._chained = self._expanded and isinstance(dout, DeferredInputGradient)
-        if self._chained:
-            nb = dout.block
-            lib().expand_merge_bwd_chained(self._eref, _ptr(nb.da1), _ptr(nb.conv1.w), _ptr(nb.dsum), _ptr(self.y2), self.bn2._pref,
-                                           _ptr(self.bn2.alpha), _ptr(self.conv3.w), self.bn3._pref, _ptr(self._drop_used),
-                                           _ptr(self.x if self.mode == 0 else self.pooled), self.cout if self.mode == 0 else self.cin,
-                                           _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta),
-                                           _ptr(self.dalpha3), _ptr(ws), wsb, st)
-        elif self._expanded:
-            lib().expand_merge_bwd(self._eref, _ptr(dout), _ptr(self.y2), self.bn2._pref, _ptr(self.bn2.alpha), _ptr(self.conv3.w),
-                                   self.bn3._pref, _ptr(self._drop_used), _ptr(self.x if self.mode == 0 else self.pooled),
-                                   self.cout if self.mode == 0 else self.cin, _ptr(self.alpha3), _ptr(self.dy3),
-                                   _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
+        # (SSMI_NO_THROUGH=1: the expansion's data gradient as its own launch)
+        through = self._expanded and self.through
+        if self._expanded:
+            nb = dout.block if self._chained else None
+            head = (self._eref,) + ((None, _ptr(nb.da1), _ptr(nb.conv1.w), _ptr(nb.dsum)) if self._chained else (_ptr(dout), None, None, None))
+            body = (_ptr(self.y2), self.bn2._pref, _ptr(self.bn2.alpha), _ptr(self.conv3.w), self.bn3._pref, _ptr(self._drop_used),
+                    _ptr(self.x if self.mode == 0 else self.pooled), self.cout if self.mode == 0 else self.cin, _ptr(self.alpha3),
+                    _ptr(self.dy3), _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3))
+            if through:
+                bn2 = self.bn2
+                lib().expand_merge_bwd_through(*head, *body, _ptr(self.da2), _ptr(bn2.dgamma), _ptr(bn2.dbeta), _ptr(bn2.dalpha),
+                                               _ptr(ws), wsb, st)
+            elif self._chained:
+                lib().expand_merge_bwd_chained(head[0], *head[2:], *body, _ptr(ws), wsb, st)
+            else:
+                lib().expand_merge_bwd(head[0], head[1], *body, _ptr(ws), wsb, st)
         elif premerge:
             L.merge_bwd_deferred(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o,
                                  _ptr(idx), _ptr(self.alpha3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
@@ -873,7 +882,9 @@ class Bottleneck(Block):
             cfg.wgrad(self.conv3, self.y2, self.dy3, pre=self.bn2, before=before3)
         else:
             cfg.wgrad(self.conv3, self.a2, self.dy3, before=before3)
-        if premerge:
+        if through:
+            pass      # da2 -> dy2 came out of the merge backward
+        elif premerge:
             pm = Premerge(_ptr(self.dsum), _ptr(self.y3), _ptr(self.bn3.mean), _ptr(self.bn3.invstd), _ptr(self.coef3),
                           _ptr(self._drop_used), self.ho * self.wo)
             self.conv3.bwd_data_bn_premerge(pm, self.da2, self.bn2, self.y2, i, self.da2, ws, st)      # da2 -> dy2 (in place)
@@ -1216,6 +1227,9 @@ class GraphBase:
                 need2 = max(need2, cv.ws_bytes)
         npix = n * h * w
         need = max(L.bn_workspace_bytes(0, 1024), L.softmax_xent_workspace_bytes(npix), need2)
+        for b in self.blocks:
+            if getattr(b, "expand", None) is not None:
+                need = max(need, L.expand_workspace_bytes(C.byref(b.expand)))
         self.ws = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
         self.ws2 = torch.empty((need2 + 3) // 4 + 64, dtype=torch.float32, device=dev) if self.overlap_weight_gradients \
             else self.ws
