@@ -20,10 +20,23 @@
 // accumulators go through LDS, and the elementwise phase runs in the merge kernels' layout - a thread owns four consecutive
 // channels of a pixel, 16-byte accesses - with every global operand of the tile requested before the multiply phase.
 // Both storage types (bfloat16: the operand, the kernel and y3 take the roundings the stored route's tensors and packs have, so
-// the values equal that route's up to summation order); (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
+// the values equal that route's up to summation order; its products run on v_mfma_f32_32x32x16_bf16 - the operand tiles sit in
+// LDS as bfloat16 rows, the kernel matrices stay in registers as matrix-instruction operands for the whole launch); (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
 #include "common.h"
 
 namespace ssmi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// eight float32 values as the bfloat16 operand of v_mfma_f32_32x32x16_bf16 (round to nearest even, element 0 lowest)
+__device__ __forceinline__ bf16x8 pack_bf16x8(const f32x4& lo, const f32x4& hi) {
+  u32x4 w;
+  w[0] = pack_bf16x2(lo[0], lo[1]);
+  w[1] = pack_bf16x2(lo[2], lo[3]);
+  w[2] = pack_bf16x2(hi[0], hi[1]);
+  w[3] = pack_bf16x2(hi[2], hi[3]);
+  return __builtin_bit_cast(bf16x8, w);
+}
 
 struct ExpandArgs {
   int npix, hw;
@@ -72,27 +85,63 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   float* const An = Wn + C4 * C;              // B1c: [TP][AS]
   float* const Sn = An + ((TP * AS + 3) & ~3);      // B1c: [TP][SS]
   float* const Wt = St + TP * SS;             // B2t: [C][WTS]
-  float* const Pn = Wt + C * WTS;             // B2t: [KS][TP][WTS]
+  float* const Pn = Wt + C * 36;              // B2t: [KS][TP][WTS] (C * 36 floats in front: W3^T, or the bfloat16 dmain tile [TP][2 C + 16 bytes])
+  static_assert(C * 36 >= C * WTS && C * 36 * 4 >= TP * (C * 2 + 16), "B2t regions");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int pw = wave % PWN, cw = wave / PWN;
 
-  for (int e = tid * 4; e < C4 * C; e += 1024) {
-    f32x4 wv = *reinterpret_cast<const f32x4*>(a.w + e);
-    if constexpr (kBf) wv = unpack_bf16x4(pack_bf16x4(wv));      // the bf16 route multiplies bf16-rounded kernels (its packs)
-    *reinterpret_cast<f32x4*>(Wl + e) = wv;
+  // bfloat16: the kernel matrices as matrix-instruction operands in registers (lane (r, hh) of a 32-wide column tile holds rows
+  // 16 s + 8 hh .. + 7 of column r), rounded as the stored route's packs are
+  constexpr int ABS = C4 * 2 + 16, DBS = C * 2 + 16;      // row strides (bytes) of the bfloat16 operand tiles in LDS
+  constexpr int K1 = C4 / 16, K3 = KW / 16;
+  unsigned char* const Alb = reinterpret_cast<unsigned char*>(Al);
+  unsigned char* const Anb = reinterpret_cast<unsigned char*>(An);
+  unsigned char* const Dtb = reinterpret_cast<unsigned char*>(Wt);      // B2t: the dmain tile [TP][DBS]
+  bf16x8 wf[kBf ? NT : 1][kBf ? K1 : 1], wnf[kBf && kChain ? NT : 1][kBf && kChain ? K1 : 1], wtf[kBf && kThru ? K3 : 1];
+  if constexpr (kBf) {
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+      for (int s2 = 0; s2 < K1; ++s2) {
+        const int col = cw * (C / CWN) + u * 32 + r;
+        f32x4 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          lo[j] = a.w[(16 * s2 + 8 * hh + j) * C + col];
+          hi[j] = a.w[(16 * s2 + 8 * hh + 4 + j) * C + col];
+        }
+        wf[u][s2] = pack_bf16x8(lo, hi);
+        if constexpr (kChain) {
+          const float* q = a.w_next + col * C4 + 16 * s2 + 8 * hh;
+          wnf[u][s2] = pack_bf16x8(*reinterpret_cast<const f32x4*>(q), *reinterpret_cast<const f32x4*>(q + 4));
+        }
+      }
+    if constexpr (kThru) {
+#pragma unroll
+      for (int s2 = 0; s2 < K3; ++s2) {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (r < C4) {
+          const float* q = a.w + r * C + cw * KW + 16 * s2 + 8 * hh;
+          lo = *reinterpret_cast<const f32x4*>(q);
+          hi = *reinterpret_cast<const f32x4*>(q + 4);
+        }
+        wtf[s2] = pack_bf16x8(lo, hi);
+      }
+    }
+  } else {
+    for (int e = tid * 4; e < C4 * C; e += 1024) *reinterpret_cast<f32x4*>(Wl + e) = *reinterpret_cast<const f32x4*>(a.w + e);
   }
-  if constexpr (kThru) {
+  if constexpr (kThru && !kBf) {
     __syncthreads();
     for (int e = tid; e < C * 32; e += 256) {
       const int cc = e >> 5, n = e & 31;
       Wt[cc * WTS + n] = n < C4 ? Wl[n * C + cc] : 0.f;
     }
   }
-  if constexpr (kChain) {
+  if constexpr (kChain && !kBf) {
     for (int e = tid * 4; e < C4 * C; e += 1024) {      // w_next[c][k..k+3] -> Wn[k..k+3][c]
-      f32x4 wv = *reinterpret_cast<const f32x4*>(a.w_next + e);
-      if constexpr (kBf) wv = unpack_bf16x4(pack_bf16x4(wv));
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w_next + e);
       const int cc = e / C4, k0 = e % C4;
 #pragma unroll
       for (int j = 0; j < 4; ++j) Wn[(k0 + j) * C + cc] = wv[j];
@@ -152,16 +201,26 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   };
 
   const int ntiles = (a.npix + TP - 1) / TP;
-  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-    const unsigned p0 = (unsigned)t * TP;
-    // every global operand of the tile, requested up front
-    typename Act<T>::raw4 yv[NY], nv[kChain ? NY : 1];      // raw while in flight, widened at the use
+  // the narrow operands (the expansion's input, B1c: the next block's dy1) are needed first in a tile, in front of a barrier:
+  // they are requested one tile ahead (tiles beyond the last: out-of-range offsets, nothing is fetched)
+  typename Act<T>::raw4 yv_next[NY], nv_next[kChain ? NY : 1];      // raw while in flight, widened at the use
+  auto request_narrow = [&](int t) {
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
-      const unsigned p = p0 + (unsigned)((tid + 256 * j) / P4);
-      const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB;
-      yv[j] = Act<T>::ld4r(ry2, off);
-      if constexpr (kChain) nv[j] = Act<T>::ld4r(rdn, off);
+      const unsigned p = (unsigned)t * TP + (unsigned)((tid + 256 * j) / P4);
+      const unsigned off = (t < ntiles && p < (unsigned)a.npix) ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB;
+      yv_next[j] = Act<T>::ld4r(ry2, off);
+      if constexpr (kChain) nv_next[j] = Act<T>::ld4r(rdn, off);
+    }
+  };
+  request_narrow(blockIdx.x);
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const unsigned p0 = (unsigned)t * TP;
+    typename Act<T>::raw4 yv[NY], nv[kChain ? NY : 1];
+#pragma unroll
+    for (int j = 0; j < NY; ++j) {
+      yv[j] = yv_next[j];
+      if constexpr (kChain) nv[j] = nv_next[j];
     }
     typename Act<T>::raw4 xs[MODE == 1 || kB1 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
 #pragma unroll
@@ -172,21 +231,26 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         xs[q] = Act<T>::ld4r(rskip, (p < (unsigned)a.npix && has_skip) ? (p * (unsigned)a.c_skip + (unsigned)c) * 4u : kOOB);
       if constexpr (MODE >= 2) dv[q] = Act<T>::ld4r(rd, off);
     }
+    request_narrow(t + (int)gridDim.x);
     __syncthreads();                           // the previous tile's staged accumulators have been read (first tile: W is in LDS)
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const int px = (tid + 256 * j) / P4;
       const f32x4 yw = Act<T>::up4(yv[j]);
+      f32x4 avv;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float av = pre_bn_act(yw[e], m2[e], is2[e], g2[e], b2[e], al2[e], act2);
-        if constexpr (kBf) av = (float)(bf16)av;      // as the stored normalised tensor would have been rounded
-        Al[px * AS + yc + e] = av;
-      }
-      if constexpr (kChain) {
-        const f32x4 nw = Act<T>::up4(nv[j]);
+      for (int e = 0; e < 4; ++e) avv[e] = pre_bn_act(yw[e], m2[e], is2[e], g2[e], b2[e], al2[e], act2);
+      if constexpr (kBf) {      // rounded as the stored normalised tensor would have been
+        *reinterpret_cast<u32x2*>(Alb + px * ABS + yc * 2) = pack_bf16x4(avv);
+        if constexpr (kChain) *reinterpret_cast<typename Act<T>::raw4*>(Anb + px * ABS + yc * 2) = nv[j];
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) An[px * AS + yc + e] = nw[e];
+        for (int e = 0; e < 4; ++e) Al[px * AS + yc + e] = avv[e];
+        if constexpr (kChain) {
+          const f32x4 nw = Act<T>::up4(nv[j]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) An[px * AS + yc + e] = nw[e];
+        }
       }
     }
     __syncthreads();
@@ -195,12 +259,21 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     for (int u = 0; u < NT; ++u)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[u][i] = 0.f;
+    if constexpr (kBf) {
 #pragma unroll
-    for (int s = 0; s < C4 / 2; ++s) {
-      const int k = 2 * s + hh;
-      const float av = Al[(pw * 32 + r) * AS + k];
+      for (int s2 = 0; s2 < K1; ++s2) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(Alb + (pw * 32 + r) * ABS + 32 * s2 + 16 * hh);
 #pragma unroll
-      for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / CWN) + u * 32 + r], acc[u], 0, 0, 0);
+        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[u][s2], acc[u], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < C4 / 2; ++s) {
+        const int k = 2 * s + hh;
+        const float av = Al[(pw * 32 + r) * AS + k];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / CWN) + u * 32 + r], acc[u], 0, 0, 0);
+      }
     }
     if constexpr (kChain) {      // the data gradient of the next block's reduction, staged beside y3
       f32x16 accn[NT];
@@ -208,12 +281,21 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       for (int u = 0; u < NT; ++u)
 #pragma unroll
         for (int i = 0; i < 16; ++i) accn[u][i] = 0.f;
+      if constexpr (kBf) {
 #pragma unroll
-      for (int s = 0; s < C4 / 2; ++s) {
-        const int k = 2 * s + hh;
-        const float av = An[(pw * 32 + r) * AS + k];
+        for (int s2 = 0; s2 < K1; ++s2) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(Anb + (pw * 32 + r) * ABS + 32 * s2 + 16 * hh);
 #pragma unroll
-        for (int u = 0; u < NT; ++u) accn[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wn[k * C + cw * (C / CWN) + u * 32 + r], accn[u], 0, 0, 0);
+          for (int u = 0; u < NT; ++u) accn[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wnf[u][s2], accn[u], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < C4 / 2; ++s) {
+          const int k = 2 * s + hh;
+          const float av = An[(pw * 32 + r) * AS + k];
+#pragma unroll
+          for (int u = 0; u < NT; ++u) accn[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wn[k * C + cw * (C / CWN) + u * 32 + r], accn[u], 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int u = 0; u < NT; ++u)
@@ -272,9 +354,9 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         }
         store4(ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, o);
         if constexpr (kThru) {      // the tile goes back where this thread read y3 from (bfloat16: as the stored dmain is rounded)
-          if constexpr (kBf) o = unpack_bf16x4(pack_bf16x4(o));
           if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
-          *reinterpret_cast<f32x4*>(St + lp * SS + c) = o;
+          if constexpr (kBf) *reinterpret_cast<u32x2*>(Dtb + lp * DBS + c * 2) = pack_bf16x4(o);      // (its own region: a bfloat16 row is narrower)
+          else *reinterpret_cast<f32x4*>(St + lp * SS + c) = o;
         }
       } else {
         f32x4 o;
@@ -303,10 +385,17 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       f32x16 acd;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acd[i] = 0.f;
+      if constexpr (kBf) {
 #pragma unroll
-      for (int s = 0; s < KW / 2; ++s) {
-        const int k = cw * KW + 2 * s + hh;
-        acd = __builtin_amdgcn_mfma_f32_32x32x2f32(St[(pw * 32 + r) * SS + k], Wt[k * WTS + r], acd, 0, 0, 0);
+        for (int s2 = 0; s2 < K3; ++s2)
+          acd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Dtb + (pw * 32 + r) * DBS + (cw * KW + 16 * s2 + 8 * hh) * 2),
+                                                        wtf[s2], acd, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < KW / 2; ++s) {
+          const int k = cw * KW + 2 * s + hh;
+          acd = __builtin_amdgcn_mfma_f32_32x32x2f32(St[(pw * 32 + r) * SS + k], Wt[k * WTS + r], acd, 0, 0, 0);
+        }
       }
 #pragma unroll
       for (int i = 0; i < 16; ++i) Pn[(cw * TP + pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * WTS + r] = acd[i];
@@ -406,13 +495,13 @@ static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a,
     if (d->cin == 16) {
       constexpr int C4 = 16, C = 64, TP = 64;
       const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1) +
-                         (MODE == 5 ? (size_t)(C * 33 + 4 * 32 * 33) * 4 : 0);
+                         (MODE == 5 ? (size_t)(C * 36 + 4 * 32 * 33) * 4 : 0);
       hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
     } else {
       constexpr int C4 = 32, C = 128, TP = 32;
       // (the reduction scratch of the summing modes, 3 sums x 8 pixel lanes x 128 channels, fits the staged tile)
       const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1) +
-                         (MODE == 5 ? (size_t)(C * 33 + 4 * 32 * 33) * 4 : 0);
+                         (MODE == 5 ? (size_t)(C * 36 + 4 * 32 * 33) * 4 : 0);
       hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
     }
     SSMI_LAUNCH_CHECK();

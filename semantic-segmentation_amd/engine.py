@@ -737,10 +737,8 @@ class Bottleneck(Block):
         # forward and both merge-backward passes recompute it from the raw output of conv2 (ssmi_expand_*).  SSMI_NO_EXPAND=1
         # keeps the stored route; keep_y3 (tests) has the forward kernel store y3 as well.
         self.expand = None
-        # (bfloat16 storage: built and tested, but measured slower than the stored route - 6.89 against 6.67 ms per ENet step: the
-        # recomputation costs what it costs with float32 while the tensors it avoids are half the size; SSMI_EXPAND_BF16=1 opts in)
-        if (self.mode <= 1 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok
-                and (self.store.dtype_code == F32 or os.environ.get("SSMI_EXPAND_BF16"))):
+        # (both storage types; with bfloat16 storage the products run on the bfloat16 matrix instructions)
+        if self.mode <= 1 and not os.environ.get("SSMI_NO_EXPAND") and not self.conv3.premerge_ok:
             ed = ExpandDesc()
             ed.n, ed.h, ed.w, ed.cin, ed.cout, ed.dtype = n, h2, w2, i, c, self.store.dtype_code
             if lib().expand_supported(C.byref(ed)):

@@ -548,11 +548,12 @@ def _rel_l2(got, ref):
                                                     ("enet-naive-upsampling-enhanced", 2, 48, 80, 9, False),
                                                     ("enet-naive-upsampling", 2, 64, 64, 3, True)])
 def test_bf16_training_step_against_fp64_oracle(name, B, H, W, seed, expand, monkeypatch):
-    """expand: the regular bottlenecks recompute their expansion instead of storing it (ssmi_expand_*, opt-in for bf16)."""
+    """expand: the regular bottlenecks recompute their expansion instead of storing it (ssmi_expand_*, the default); False:
+    the stored route (SSMI_NO_EXPAND=1)."""
     from test_parity_step_gpu import _hip_branches
     monkeypatch.setenv("SSMI_KEEP_Y3", "1")      # the branch replay reads y3
-    if expand:
-        monkeypatch.setenv("SSMI_EXPAND_BF16", "1")
+    if not expand:
+        monkeypatch.setenv("SSMI_NO_EXPAND", "1")
     w0 = E.init_weights(name, NC, seed=seed, perturb=True)
     m = _compiled(name, w0)
     cw = np.ones(NC, dtype=np.float32)
