@@ -679,7 +679,16 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *                          The apply pass multiplies its dmain tile with w^T in place and takes BN2's column sums there; dmain
  *                          is still stored (the weight gradient of the expansion reads it).  Replaces ssmi_expand_merge_bwd +
  *                          ssmi_conv2d_bwd_data_bn_bwd of the expansion.
- * Outputs equal the stored route's up to the order of the float32 sums inside y3 (and inside dout, da2). */
+ *                          (dy2 NULL with wpart1_next given: the plain apply pass, dmain required.)
+ *                          wpart3 / wpart1_next (each nullable, ssmi_expand_weight_partial_bytes(d) bytes, 16-byte aligned):
+ *                          the weight gradients of the two 1x1 layers whose operands the passes hold in LDS anyway, as
+ *                          per-workgroup partial matrices - wpart3: of the expansion itself (dW3 = a2^T * dmain; dmain may then
+ *                          be NULL and is not stored), wpart1_next (needs dy_next): of the following block's reduction
+ *                          (dW1' = out^T * dy_next; out, this block's output, is recomputed by the reducing pass).
+ *                          ssmi_expand_weight_reduce(d, wpart, dw) sums a partial buffer in a fixed order into the layer's
+ *                          gradient ([cin][cout] for wpart3, [cout][cin] for wpart1_next; any stream ordered behind the call).
+ *                          Replace ssmi_conv2d_bwd_weight of these layers.
+ * Outputs equal the stored route's up to the order of the float32 sums inside y3 (and inside dout, da2, dW). */
 typedef struct ssmi_expand_desc {
   int32_t n, h, w, cin, cout;
   int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x_raw, skip, out, dout, dsum, dmain, y3_out */
@@ -705,8 +714,10 @@ ssmi_status ssmi_expand_merge_bwd_through(const ssmi_expand_desc* d, const void*
                                           const void* dsum_next, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
                                           const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
                                           const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha,
-                                          void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, void* ws, size_t ws_bytes,
-                                          void* stream);
+                                          void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, float* wpart3, float* wpart1_next,
+                                          void* ws, size_t ws_bytes, void* stream);
+size_t ssmi_expand_weight_partial_bytes(const ssmi_expand_desc* d);
+ssmi_status ssmi_expand_weight_reduce(const ssmi_expand_desc* d, const float* wpart, float* dw, void* stream);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,8 @@ ssmi_status launch_bn_stats_final(const float* part, int rows, int c, int64_t np
                                   int unbiased_moving, float* moving_mean, float* moving_var, float* save_mean,
                                   float* save_invstd, hipStream_t stream);
 
+// sums partial weight gradients part[nstrips][K_aug * cout] in a fixed order into dw[K * cout] (+ dbias[cout]: row K); conv.hip
+void launch_wg_reduce(const float* part, int nstrips, int K, int K_aug, int cout, float* dw, float* dbias, hipStream_t st);
 // Finalises per-workgroup sums part[rows][3][c] (dz, dz*xhat, d*min(z,0)) into dgamma / dbeta / dalpha and the three
 // coefficient vectors of the apply pass, coef = k1 | m1 | m2 (bn.hip)
 ssmi_status launch_bn_bwd_final(const float* part, int rows, int c, int64_t npix, const float* gamma, const float* invstd,

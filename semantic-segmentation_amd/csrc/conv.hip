@@ -2118,7 +2118,7 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce_wide(const float* 
 }
 
 // Picks the reduction kernel by the shape of the partial-sum matrix.
-static void launch_wg_reduce(const float* part, int nstrips, int K, int K_aug, int cout, float* dw, float* dbias, hipStream_t st) {
+void launch_wg_reduce(const float* part, int nstrips, int K, int K_aug, int cout, float* dw, float* dbias, hipStream_t st) {
   const int E = K_aug * cout;
   static const bool ablate = getenv("SSMI_ABLATE_WG_REDUCE") != nullptr;     // timing experiment only: results are meaningless
   if (ablate) return;

@@ -12,6 +12,10 @@
 //            with W3^T (split over the waves along its 64 / 128 channels), da2 = dmain * W3^T is stored together with the column
 //            sums BN2's backward needs (sum dz, sum dz * xhat2, sum da2 * min(z2, 0): ssmi_conv2d_bwd_data_bn_bwd's) - dmain
 //            is still stored (the expansion's weight gradient reads it) but not read again on the main chain
+//   WG       (B2t and B1c) the weight gradient of a 1x1 layer formed where its operands already sit in LDS, accumulated in
+//            registers over the workgroup's tiles and written as one partial matrix per workgroup (per pixel-block wave pair
+//            for 64 channels), summed by ssmi_expand_weight_reduce:  B2t: dW3 = a2^T * dmain (dmain is then not stored at
+//            all);  B1c: dW1' = out^T * dy1', the NEXT block's reduction - out = PReLU3(s) is what this pass computes anyway
 //   mode B1c mode B1 whose dout is not read but formed in place: dout = dy1' * W1'^T + dsum', the data gradient of the NEXT
 //            block's 1x1 reduction (src/models.py:1090-1096) plus that block's skip gradient - the same (C/4 -> C) product
 //            shape as the expansion, so the tile loop runs two products and dout is neither written nor read
@@ -57,10 +61,28 @@ struct ExpandArgs {
   float* part;              // S: [grid][2][C]; B1: [grid][3][C]
   void* da2;                // B2t: [npix][C4] gradient at the expansion's (normalised) input
   float* part2;             // B2t: [grid][3][C4]
+  float* wpart;             // WG: [rows][C4][C] (B2t) / [rows][C][C4] (B1c), rows = grid * (pixel blocks per tile)
 };
 
-template <typename T, int C4, int C, int MODE>
+// LDS layout (floats), shared by the kernel and its launcher
+template <typename T, int C4, int C, int MODE, bool WG>
+struct ExpandLds {
+  static constexpr bool kBf = sizeof(T) == 2;
+  static constexpr int TP = C == 128 ? 32 : 64;
+  static constexpr int W = kBf ? 0 : C4 * C;                    // a kernel matrix (bfloat16: register operands instead)
+  static constexpr int A = (TP * (C4 + 1) + 3) & ~3;            // a narrow operand tile
+  static constexpr int S = TP * (C + 4);                        // a staged accumulator tile
+  static constexpr int D = (TP * (C * 2 + 16) + 3) / 4;         // a bfloat16 wide tile
+  static constexpr int Wl = 0, Al = W, St = Al + A, X = St + S; // X: start of the mode's own regions
+  static constexpr int Wn = X, An = Wn + W, Sn = An + A, Ot = Sn + S;                 // B1c
+  static constexpr int Wt = X, WtN = kBf ? D : C * 36, Pn = Wt + WtN;                 // B2t
+  static constexpr int total = MODE == 4 ? Ot + (WG && kBf ? D : 0) : (MODE == 5 ? Pn + 4 * 32 * 33 : X);
+};
+
+template <typename T, int C4, int C, int MODE, bool WG = false>
 __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
+  using L = ExpandLds<T, C4, C, MODE, WG>;
+  static_assert(!WG || MODE == 4 || MODE == 5, "the fused weight gradients belong to the B1c and B2t modes");
   constexpr bool kBf = sizeof(T) == 2;      // bfloat16 storage: operands and y3 take the roundings the stored route's tensors have
   constexpr int TP = C == 128 ? 32 : 64;      // pixels per tile (eight elementwise passes per tile cost the 128-wide variant > 256 registers)
   constexpr int PWN = TP / 32, CWN = 4 / PWN; // waves along pixels / along channels
@@ -78,15 +100,15 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   constexpr bool kSums = MODE == 0 || kB1;
   static_assert(NY >= 1 && 256 % P4 == 0 && 256 % G == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* const Wl = sm;                       // [C4][C]
-  float* const Al = Wl + C4 * C;              // [TP][AS]
-  float* const St = Al + ((TP * AS + 3) & ~3);      // [TP][SS], later the reduction scratch
-  float* const Wn = St + TP * SS;             // B1c: [C4][C], the next block's reduction kernel transposed
-  float* const An = Wn + C4 * C;              // B1c: [TP][AS]
-  float* const Sn = An + ((TP * AS + 3) & ~3);      // B1c: [TP][SS]
-  float* const Wt = St + TP * SS;             // B2t: [C][WTS]
-  float* const Pn = Wt + C * 36;              // B2t: [KS][TP][WTS] (C * 36 floats in front: W3^T, or the bfloat16 dmain tile [TP][2 C + 16 bytes])
-  static_assert(C * 36 >= C * WTS && C * 36 * 4 >= TP * (C * 2 + 16), "B2t regions");
+  float* const Wl = sm + L::Wl;               // [C4][C] (float32 storage only)
+  float* const Al = sm + L::Al;               // [TP][AS]
+  float* const St = sm + L::St;               // [TP][SS], later the reduction scratch
+  float* const Wn = sm + L::Wn;               // B1c: [C4][C], the next block's reduction kernel transposed (float32 storage only)
+  float* const An = sm + L::An;               // B1c: [TP][AS]
+  float* const Sn = sm + L::Sn;               // B1c: [TP][SS]
+  float* const Wt = sm + L::Wt;               // B2t: W3^T [C][WTS] (float32 storage) / the bfloat16 dmain tile [TP][2 C + 16 bytes]
+  float* const Pn = sm + L::Pn;               // B2t: [KS][TP][WTS]
+  static_assert(C * 36 >= C * WTS, "B2t regions");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int pw = wave % PWN, cw = wave / PWN;
@@ -98,6 +120,21 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   unsigned char* const Alb = reinterpret_cast<unsigned char*>(Al);
   unsigned char* const Anb = reinterpret_cast<unsigned char*>(An);
   unsigned char* const Dtb = reinterpret_cast<unsigned char*>(Wt);      // B2t: the dmain tile [TP][DBS]
+  unsigned char* const Otb = reinterpret_cast<unsigned char*>(sm + L::Ot);      // B1c + WG: the block-output tile [TP][DBS]
+  f32x16 accw;              // WG: this wave's 32 x 32 block of the weight gradient, over all tiles of the workgroup
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accw[i] = 0.f;
+  // a matrix-instruction operand (16 pixels x 32 channels, pixels as the reduction dimension) out of a pixel-major bfloat16
+  // tile in LDS through the transposing read; p points at (first pixel, first channel) of the block
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  const int sq = (lane & 15) >> 2, sp = lane & 3, gh = (lane >> 4) & 1;
+  auto operand_t = [&](const unsigned char* p, int rowb) {
+    struct Pair { s16x4 lo, hi; } pr;
+    const unsigned char* q = p + (8 * hh + sq) * rowb + (16 * gh + 4 * sp) * 2;
+    pr.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q));
+    pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 4 * rowb));
+    return __builtin_bit_cast(bf16x8, pr);
+  };
   bf16x8 wf[kBf ? NT : 1][kBf ? K1 : 1], wnf[kBf && kChain ? NT : 1][kBf && kChain ? K1 : 1], wtf[kBf && kThru ? K3 : 1];
   if constexpr (kBf) {
 #pragma unroll
@@ -193,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
   const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (kB2 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rda = Act<T>::rsrc(kThru ? a.da2 : (void*)a.part, kThru ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
-  const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 ? a.out : (void*)a.part, MODE != 0 ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 && a.out ? a.out : (void*)a.part, MODE != 0 && a.out ? wide_bytes : 0u);      // (B2t + WG: dmain may be NULL, nothing is stored)
   const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(MODE == 1 && a.y3_out ? a.y3_out : (void*)a.part, MODE == 1 && a.y3_out ? wide_bytes : 0u);
   auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off4, const f32x4& val) {      // out-of-range offsets are dropped
     if constexpr (kBf) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(val), rs, off4 >> 1, 0, 0);
@@ -359,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           else *reinterpret_cast<f32x4*>(St + lp * SS + c) = o;
         }
       } else {
-        f32x4 o;
+        f32x4 o, ov = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float xh = (y3[e] - m3[e]) * is3[e];
@@ -368,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           if constexpr (MODE == 1) {
             o[e] = s > 0.f ? s : al3[e] * s;
           } else {
+            if constexpr (WG) ov[e] = live ? (s > 0.f ? s : al3[e] * s) : 0.f;      // the block's output = the next block's input
             const float d = live ? dq[e] : 0.f;
             o[e] = d * (s > 0.f ? 1.f : (s < 0.f ? al3[e] : 0.f));
             const float dz = o[e] * dr[e];
@@ -377,11 +415,44 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           }
         }
         store4(ro, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, o);
+        if constexpr (WG && kChain) {      // where this thread read y3 from (bfloat16: its own region, rounded as the stored output is)
+          if constexpr (kBf) *reinterpret_cast<u32x2*>(Otb + lp * DBS + c * 2) = pack_bf16x4(ov);
+          else *reinterpret_cast<f32x4*>(St + lp * SS + c) = ov;
+        }
         if constexpr (MODE == 1) store4(ry3, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, y3);      // (empty descriptor: dropped)
+      }
+    }
+    if constexpr (WG && kChain) {      // dW1' += out^T * dy1': rows = this wave's 32 output channels, columns = the C4 reduced ones
+      __syncthreads();
+      if constexpr (kBf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(operand_t(Otb + (pw * 32 + 16 * s2) * DBS + cw * 32 * 2, DBS),
+                                                         operand_t(Anb + (pw * 32 + 16 * s2) * ABS, ABS), accw, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int k = pw * 32 + 2 * s + hh;
+          accw = __builtin_amdgcn_mfma_f32_32x32x2f32(St[k * SS + cw * 32 + r], r < C4 ? An[k * AS + r] : 0.f, accw, 0, 0, 0);
+        }
       }
     }
     if constexpr (kThru) {
       __syncthreads();
+      if constexpr (WG) {      // dW3 += a2^T * dmain: rows = the C4 input channels, columns = this wave's 32 output channels
+        if constexpr (kBf) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(operand_t(Alb + (pw * 32 + 16 * s2) * ABS, ABS),
+                                                           operand_t(Dtb + (pw * 32 + 16 * s2) * DBS + cw * 32 * 2, DBS), accw, 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            const int k = pw * 32 + 2 * s + hh;
+            accw = __builtin_amdgcn_mfma_f32_32x32x2f32(r < C4 ? Al[k * AS + r] : 0.f, St[k * SS + cw * 32 + r], accw, 0, 0, 0);
+          }
+        }
+      }
       f32x16 acd;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acd[i] = 0.f;
@@ -420,6 +491,18 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         v2[2][e] += (live2 && act2) ? d * (z < 0.f ? z : 0.f) : 0.f;
       }
       store4(rda, live2 ? ((p0 + (unsigned)px) * (unsigned)C4 + (unsigned)yc) * 4u : kOOB, da);
+    }
+  }
+  if constexpr (WG) {         // this wave's block of the workgroup's partial weight gradient (C4 = 16: half of the block is padding)
+    float* wp = a.wpart + ((size_t)blockIdx.x * PWN + pw) * (size_t)(C4 * C);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if constexpr (kThru) {
+        if (row < C4) wp[row * C + cw * 32 + r] = accw[i];
+      } else {
+        if (r < C4) wp[(cw * 32 + row) * C4 + r] = accw[i];
+      }
     }
   }
   if constexpr (kThru) {      // one row of BN2-backward sums per workgroup, pixels added in a fixed order
@@ -482,27 +565,30 @@ static bool expand_shape_ok(const ssmi_expand_desc* d) {
          (int64_t)d->n * d->h * d->w * d->cout * 4 < 0x7FFFFFFFLL && (d->dtype == SSMI_F32 || d->dtype == SSMI_BF16);
 }
 
-template <int MODE>
-static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
+static int expand_grid(const ssmi_expand_desc* d) {
   const int tp = d->cout == 128 ? 32 : 64;
-  const int ntiles = (a.npix + tp - 1) / tp;
+  const int ntiles = (d->n * d->h * d->w + tp - 1) / tp;
   static const int gmax = getenv("SSMI_EXPAND_GRID") ? atoi(getenv("SSMI_EXPAND_GRID")) : 512;      // measurement switch; ENet step with 256 / 384 / 512 / 768 / 1024: 8.81 / 8.70 / 8.49 / 8.51 / 8.52 ms
   const int cap = gmax < kExpandMaxGrid ? gmax : kExpandMaxGrid;
-  const int grid = ntiles < cap ? ntiles : cap;
+  return ntiles < cap ? ntiles : cap;
+}
+
+// rows of a fused weight gradient's partial sums: one per workgroup and 32-pixel block of its tiles
+static int expand_weight_rows(const ssmi_expand_desc* d) { return expand_grid(d) * (d->cout == 128 ? 1 : 2); }
+
+template <int MODE, bool WG = false>
+static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
+  const int grid = expand_grid(d);
   if (rows) *rows = grid;
   return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {
     using T = decltype(tag);
     if (d->cin == 16) {
-      constexpr int C4 = 16, C = 64, TP = 64;
-      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1) +
-                         (MODE == 5 ? (size_t)(C * 36 + 4 * 32 * 33) * 4 : 0);
-      hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
+      constexpr size_t lds = (size_t)ExpandLds<T, 16, 64, MODE, WG>::total * 4;
+      hipLaunchKernelGGL((expand_kernel<T, 16, 64, MODE, WG>), dim3(grid), dim3(256), lds, st, a);
     } else {
-      constexpr int C4 = 32, C = 128, TP = 32;
       // (the reduction scratch of the summing modes, 3 sums x 8 pixel lanes x 128 channels, fits the staged tile)
-      const size_t lds = (size_t)(C4 * C + ((TP * (C4 + 1) + 3) & ~3) + TP * (C + 4)) * 4 * (MODE == 4 ? 2 : 1) +
-                         (MODE == 5 ? (size_t)(C * 36 + 4 * 32 * 33) * 4 : 0);
-      hipLaunchKernelGGL((expand_kernel<T, C4, C, MODE>), dim3(grid), dim3(256), lds, st, a);
+      constexpr size_t lds = (size_t)ExpandLds<T, 32, 128, MODE, WG>::total * 4;
+      hipLaunchKernelGGL((expand_kernel<T, 32, 128, MODE, WG>), dim3(grid), dim3(256), lds, st, a);
     }
     SSMI_LAUNCH_CHECK();
     return SSMI_OK;
@@ -581,15 +667,17 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
                                          const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
                                          void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
                                          void* stream, void* dy2 = nullptr, float* dgamma2 = nullptr, float* dbeta2 = nullptr,
-                                         float* dalpha2 = nullptr) {
+                                         float* dalpha2 = nullptr, float* wpart3 = nullptr, float* wpart1n = nullptr) {
   SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "%s: 16 -> 64 or 32 -> 128 channel expansions only", who);
   SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
-               bn3->gamma && bn3->beta && skip && alpha && dmain && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
+               bn3->gamma && bn3->beta && skip && alpha && (dmain || wpart3) && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
                "%s: NULL argument", who);
+  SSMI_REQUIRE((!wpart3 || dy2) && (!wpart1n || dy_next), SSMI_E_INVALID_ARG,
+               "%s: a fused weight gradient needs the data gradient it rides on (dy2 for wpart3, dy_next for wpart1_next)", who);
   SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE, "%s: skip channels must be a multiple of 4 within the output's", who);
   SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "%s: workspace too small", who);
   SSMI_REQUIRE(aligned16({dout, dy_next, w_next, x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd,
-                          bn3->gamma, bn3->beta, drop, skip, alpha, dmain, dsum, ws}), SSMI_E_INVALID_ARG,
+                          bn3->gamma, bn3->beta, drop, skip, alpha, dmain, dsum, ws, wpart3, wpart1n}), SSMI_E_INVALID_ARG,
                "%s: pointers must be 16-byte aligned", who);
   hipStream_t st = as_stream(stream);
   ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
@@ -600,7 +688,9 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
   a.part = static_cast<float*>(ws);
   float* coef = a.part + (size_t)kExpandMaxGrid * 3 * d->cout;
   int rows = 0;
-  ssmi_status s = dy_next ? launch_expand<4>(d, a, &rows, st) : launch_expand<2>(d, a, &rows, st);
+  a.wpart = wpart1n;
+  ssmi_status s = dy_next ? (wpart1n ? launch_expand<4, true>(d, a, &rows, st) : launch_expand<4>(d, a, &rows, st))
+                          : launch_expand<2>(d, a, &rows, st);
   if (s) return s;
   s = launch_bn_bwd_final(a.part, rows, d->cout, a.npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
   if (s) return s;
@@ -611,7 +701,8 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
   b.da2 = dy2;
   b.part2 = coef + 3 * d->cout;
   float* coef2 = b.part2 + (size_t)kExpandMaxGrid * 3 * d->cin;
-  s = launch_expand<5>(d, b, &rows, st);
+  b.wpart = wpart3;
+  s = wpart3 ? launch_expand<5, true>(d, b, &rows, st) : launch_expand<5>(d, b, &rows, st);
   if (s) return s;
   return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {      // BN2 / PReLU2 backward in place: da2 -> dy2
     using T = decltype(tag);
@@ -643,14 +734,29 @@ ssmi_status ssmi_expand_merge_bwd_through(const ssmi_expand_desc* d, const void*
                                           const void* dsum_next, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
                                           const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
                                           const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha,
-                                          void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, void* ws, size_t ws_bytes,
-                                          void* stream) {
+                                          void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, float* wpart3, float* wpart1_next,
+                                          void* ws, size_t ws_bytes, void* stream) {
   SSMI_REQUIRE((dout != nullptr) != (dy_next != nullptr) && (!dy_next || (w_next && dsum_next)), SSMI_E_INVALID_ARG,
                "expand_merge_bwd_through: give dout, or dy_next + w_next + dsum_next");
-  SSMI_REQUIRE(dy2 && dgamma2 && dbeta2 && (dalpha2 || !pre_alpha), SSMI_E_INVALID_ARG, "expand_merge_bwd_through: NULL argument");
+  SSMI_REQUIRE((dy2 || wpart1_next) && (!dy2 || (dgamma2 && dbeta2 && (dalpha2 || !pre_alpha))), SSMI_E_INVALID_ARG,
+               "expand_merge_bwd_through: NULL argument");
   SSMI_REQUIRE(aligned16({dy2}), SSMI_E_INVALID_ARG, "expand_merge_bwd_through: pointers must be 16-byte aligned");
   return expand_merge_bwd_impl("expand_merge_bwd_through", d, dout ? dout : dsum_next, dy_next, w_next, x_raw, pre, pre_alpha, w, bn3, drop,
-                               skip, c_skip, alpha, dmain, dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream, dy2, dgamma2, dbeta2, dalpha2);
+                               skip, c_skip, alpha, dmain, dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream, dy2, dgamma2, dbeta2, dalpha2, wpart3,
+                               wpart1_next);
+}
+
+size_t ssmi_expand_weight_partial_bytes(const ssmi_expand_desc* d) {
+  if (!expand_shape_ok(d)) return 0;
+  return (size_t)kExpandMaxGrid * 2 * d->cin * d->cout * sizeof(float);
+}
+
+ssmi_status ssmi_expand_weight_reduce(const ssmi_expand_desc* d, const float* wpart, float* dw, void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_weight_reduce: 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(wpart && dw && aligned16({wpart, dw}), SSMI_E_INVALID_ARG, "expand_weight_reduce: NULL or misaligned argument");
+  launch_wg_reduce(wpart, expand_weight_rows(d), d->cin * d->cout, d->cin * d->cout, 1, dw, nullptr, as_stream(stream));
+  SSMI_LAUNCH_CHECK();
+  return SSMI_OK;
 }
 
 }  // extern "C"

@@ -441,6 +441,22 @@ class RunCfg:
             ev.record(self.main)
         self._pending.append((conv, x, dy, pre, before, ev))
 
+    def side_job(self, fn, conv=None):
+        """`fn(stream)`: work of the weight-gradient chain that is not a weight-gradient launch (the reduction of partial sums a
+        main-chain kernel left behind); scheduled like wgrad().  `conv`: the layer it belongs to (ablation switches)."""
+        if _ABLATE_WGRAD:
+            return
+        if _ABLATE_WGRAD_KIND and conv is not None and "1x1" in _ABLATE_WGRAD_KIND.split(","):
+            return
+        if self.side is None:
+            fn(self.st)
+            return
+        ev = None
+        if _WGRAD_FORK_PER_CONV:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+        self._pending.append((None, None, None, None, fn, ev))
+
     def flush(self):
         """Puts the weight gradients collected since the last flush on the side stream, each behind its own fork point (or,
         with SSMI_WGRAD_FORK=block, behind everything the main stream has queued so far).  The launches themselves are
@@ -478,6 +494,8 @@ class RunCfg:
                 side.wait_event(own)
             if before is not None:
                 before(side.cuda_stream)
+            if conv is None:      # side_job
+                continue
             if pre is not None:
                 conv.bwd_weight_prebn(x, pre, dy, ws2, side.cuda_stream)
             else:
@@ -585,8 +603,15 @@ class DeferredInputGradient:
     def __init__(self, block):
         self.block = block
 
-    def materialise(self, cfg):
+    def weight_gradient(self, cfg):
+        """The reduction's weight gradient as its own launch (a consumer that forms it itself does not call this)."""
         b = self.block
+        cfg.wgrad(b.conv1, b.x, b.da1)
+
+    def materialise(self, cfg, weight_gradient=True):
+        b = self.block
+        if weight_gradient:
+            self.weight_gradient(cfg)
         b.conv1.bwd_data(b.da1, b.dx, cfg.st, add=b.dsum)
         return b.dx
 
@@ -755,6 +780,19 @@ class Bottleneck(Block):
         # (bfloat16 storage, where the extra product is nearly free: both on, 5.93 against 5.98 ms)
         self.through = (not os.environ.get("SSMI_NO_THROUGH") and
                         str(c) in os.environ.get("SSMI_THROUGH_C", "64" if self.store.dtype_code == F32 else "64,128").split(","))
+        # SSMI_FUSED_WGRAD=1: the weight gradients of the two 1x1 layers around a chained / through merge backward are formed inside
+        # it (per-workgroup partial matrices in wpart3 / wpart1, summed on the weight-gradient chain) instead of by their own
+        # launches.  Off by default: it removes 0.8 GB and ~45 launches from the weight-gradient chain but lengthens the main
+        # chain's kernels, and the main chain is the critical path - ENet step 8.11 against 8.00 ms (float32), 5.93 against 5.85
+        # (bfloat16).
+        self.fuse_wg = self.expand is not None and os.environ.get("SSMI_FUSED_WGRAD", "0") == "1"
+        self.wpart3 = self.wpart1 = None
+        if self.fuse_wg:
+            nfl = lib().expand_weight_partial_bytes(self._eref) // 4
+            if self.through:
+                self.wpart3 = torch.empty(nfl, dtype=torch.float32, device=dev)
+            if self.mode == 0 and self.cin == self.cout:
+                self.wpart1 = torch.empty(nfl, dtype=torch.float32, device=dev)      # filled by the block in front (chained)
         self.defers = self.mode == 0 and self.expand is not None and self.cin == self.cout and not os.environ.get("SSMI_NO_CHAIN")
         return (h2, w2, c)
 
@@ -856,14 +894,25 @@ class Bottleneck(Block):
             body = (_ptr(self.y2), self.bn2._pref, _ptr(self.bn2.alpha), _ptr(self.conv3.w), self.bn3._pref, _ptr(self._drop_used),
                     _ptr(self.x if self.mode == 0 else self.pooled), self.cout if self.mode == 0 else self.cin, _ptr(self.alpha3),
                     _ptr(self.dy3), _ptr(self.dsum), _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3))
-            if through:
+            # fused weight gradients: conv3's own rides on the through route, the next block's conv1's on the chained route
+            # (which then has to take the through entry point as well - only it carries the partial buffers)
+            wp3 = self.wpart3 if through else None
+            wp1 = nb.wpart1 if self._chained else None
+            if self._chained and wp1 is None:
+                dout.weight_gradient(cfg)
+            if through or wp1 is not None:
                 bn2 = self.bn2
-                lib().expand_merge_bwd_through(*head, *body, _ptr(self.da2), _ptr(bn2.dgamma), _ptr(bn2.dbeta), _ptr(bn2.dalpha),
-                                               _ptr(ws), wsb, st)
+                if wp3 is not None:
+                    body = body[:9] + (None,) + body[10:]      # dmain is not stored
+                thru = (_ptr(self.da2), _ptr(bn2.dgamma), _ptr(bn2.dbeta), _ptr(bn2.dalpha)) if through else (None, None, None, None)
+                lib().expand_merge_bwd_through(*head, *body, *thru, _ptr(wp3), _ptr(wp1), _ptr(ws), wsb, st)
             elif self._chained:
                 lib().expand_merge_bwd_chained(head[0], *head[2:], *body, _ptr(ws), wsb, st)
             else:
                 lib().expand_merge_bwd(head[0], head[1], *body, _ptr(ws), wsb, st)
+            if wp1 is not None:      # behind the launch that left the partial sums
+                cfg.side_job(lambda stream, e=nb._eref, wp=wp1, dw=nb.conv1.dw: lib().expand_weight_reduce(e, _ptr(wp), _ptr(dw), stream),
+                             conv=nb.conv1)
         elif premerge:
             L.merge_bwd_deferred(self._mref, _ptr(dout), _ptr(self.y3), self.bn3._pref, _ptr(self._drop_used), _ptr(other), bn_o,
                                  _ptr(idx), _ptr(self.alpha3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
@@ -878,7 +927,10 @@ class Bottleneck(Block):
                         _ptr(self.alpha3), _ptr(self.dy3), _ptr(self.dsum), _ptr(self.dyo_bn if self.mode >= 2 else None),
                         _ptr(self.bn3.dgamma), _ptr(self.bn3.dbeta), _ptr(self.dalpha3), _ptr(ws), wsb, st)
         # conv3
-        if getattr(self, "_pre3", False):
+        if self._expanded and through and self.wpart3 is not None:
+            cfg.side_job(lambda stream, e=self._eref, wp=self.wpart3, dw=self.conv3.dw: lib().expand_weight_reduce(e, _ptr(wp), _ptr(dw), stream),
+                         conv=self.conv3)
+        elif getattr(self, "_pre3", False):
             cfg.wgrad(self.conv3, self.y2, self.dy3, pre=self.bn2, before=before3)
         else:
             cfg.wgrad(self.conv3, self.a2, self.dy3, before=before3)
@@ -905,10 +957,10 @@ class Bottleneck(Block):
             cfg.wgrad(self.conv2, self.a1, self.da2)
             self.conv2.bwd_data_bn(self.da2, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)   # da1 -> dy1
         # conv1 + skip branch
+        if self.mode == 0 and self.defers and self._expanded:
+            return DeferredInputGradient(self)      # (conv1's weight gradient: by whoever forms the input gradient)
         cfg.wgrad(self.conv1, self.x, self.da1)
         if self.mode == 0:
-            if self.defers and self._expanded:
-                return DeferredInputGradient(self)
             self.conv1.bwd_data(self.da1, self.dx, st, add=self.dsum)
         elif self.mode == 1:
             self.conv1.bwd_data(self.da1, self.dx, st)

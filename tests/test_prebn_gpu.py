@@ -165,7 +165,7 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
     w0 = E.init_weights(name, NC, seed=12, perturb=True)
     images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=13, block=8)
     res = {}
-    for mode in ("stored", "expand", "expand+keep", "expand-unchained", "expand-two-launches"):
+    for mode in ("stored", "expand", "expand+keep", "expand-unchained", "expand-two-launches", "expand-fused-weight-gradients"):
         monkeypatch.delenv("SSMI_NO_EXPAND", raising=False)
         monkeypatch.delenv("SSMI_KEEP_Y3", raising=False)
         monkeypatch.delenv("SSMI_NO_CHAIN", raising=False)
@@ -175,6 +175,9 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
         monkeypatch.setenv("SSMI_THROUGH_C", "64,128")      # (the 128-channel instantiation is off by default: measured slower)
         if mode == "expand-two-launches":
             monkeypatch.setenv("SSMI_NO_THROUGH", "1")
+        monkeypatch.delenv("SSMI_FUSED_WGRAD", raising=False)
+        if mode == "expand-fused-weight-gradients":
+            monkeypatch.setenv("SSMI_FUSED_WGRAD", "1")
         if mode == "stored":
             monkeypatch.setenv("SSMI_NO_EXPAND", "1")
         if mode == "expand+keep":
@@ -192,7 +195,7 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
         if mode != "stored":
             assert len(used) >= 15, used
         chained = [b.name for b in g.blocks if getattr(b, "_chained", False)]
-        assert (len(chained) >= 14) == (mode in ("expand", "expand+keep", "expand-two-launches")), (mode, chained)
+        assert (len(chained) >= 14) == (mode in ("expand", "expand+keep", "expand-two-launches", "expand-fused-weight-gradients")), (mode, chained)
         res[mode] = dict(loss=out[0], grad=g.store.grad.clone(), outs={b.name: b.out.clone() for b in g.blocks if hasattr(b, "bn3")},
                          stats={b.name: (b.bn3.mean.clone(), b.bn3.invstd.clone()) for b in g.blocks if hasattr(b, "bn3")},
                          views={k: (v.data_ptr() - g.store.grad.data_ptr()) // 4 for k, v in g.store.gviews.items()},
@@ -203,7 +206,8 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
     # the chained merge backward (the next block's first data gradient formed inside it, never stored) against the two-kernel
     # route: the forward pass is the same kernels, and the gradients differ by the summation order inside dout only
     # the same for the expansion's data gradient inside the apply pass against its own launch
-    for u in (res["expand-unchained"], res["expand-two-launches"]):
+    # and for the weight gradients of the 1x1 layers formed inside those passes (opt-in) against their own launches
+    for u in (res["expand-unchained"], res["expand-two-launches"], res["expand-fused-weight-gradients"]):
         assert b["loss"] == u["loss"] and all(torch.equal(b["outs"][k], u["outs"][k]) for k in b["outs"])
         gb_, gu_ = b["grad"].double(), u["grad"].double()
         assert float((gb_ - gu_).norm() / gu_.norm()) <= 1e-5, float((gb_ - gu_).norm() / gu_.norm())
