@@ -665,6 +665,11 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *   ssmi_expand_bn_stats   training-phase statistics of the BatchNormalization behind the expansion (save_mean /
  *                          save_invstd, moving-average update); stores no activation
  *   ssmi_expand_merge_fwd  out = PReLU_alpha(drop * BN3(y3) + skip); y3_out (nullable): also store y3 (tests, debugging)
+ *   ssmi_expand_merge_fwd_through  the same carried through the NEXT block's 1x1 reduction (src/models.py:1090-1100; kernel
+ *                          w_next [cout][cin], no bias): y1_next [n,h,w,cin] = out * w_next and the training-phase statistics
+ *                          of the BatchNormalization behind it (save_mean1 / save_invstd1, moving averages when given) - the
+ *                          output tile is multiplied where it was formed; replaces the next block's
+ *                          ssmi_conv2d_fwd_bn_stats, whose read of `out` it saves
  *   ssmi_expand_merge_bwd  dsum = gradient of the pre-activation sum (= gradient of the skip branch), dmain = gradient of
  *                          y3, dgamma3 / dbeta3 / dalpha overwritten - as ssmi_merge_bwd
  *   ssmi_expand_merge_bwd_chained  the same with dout FORMED per tile instead of read: the block that follows a regular
@@ -701,6 +706,11 @@ ssmi_status ssmi_expand_bn_stats(const ssmi_expand_desc* d, const void* x_raw, c
 ssmi_status ssmi_expand_merge_fwd(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
                                   const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
                                   const float* alpha, void* out, void* y3_out, void* stream);
+ssmi_status ssmi_expand_merge_fwd_through(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                          const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
+                                          const float* alpha, void* out, void* y3_out, const float* w_next, void* y1_next, float eps,
+                                          float momentum, int32_t unbiased_moving, float* moving_mean1, float* moving_var1,
+                                          float* save_mean1, float* save_invstd1, void* ws, size_t ws_bytes, void* stream);
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
                                   const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
                                   int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,

@@ -112,6 +112,8 @@ _PROTOS = {
     "ssmi_expand_workspace_bytes": (_sz, [_PE]),
     "ssmi_expand_bn_stats": (_i32, [_PE, _vp, _PB, _vp, _vp, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_expand_merge_fwd": (_i32, [_PE, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "ssmi_expand_merge_fwd_through": (_i32, [_PE, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _vp,
+                                             _vp, _vp, _vp, _sz, _vp]),
     "ssmi_expand_merge_bwd": (_i32, [_PE, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_expand_merge_bwd_chained": (_i32, [_PE, _vp, _vp, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _sz, _vp]),

@@ -12,6 +12,9 @@
 //            with W3^T (split over the waves along its 64 / 128 channels), da2 = dmain * W3^T is stored together with the column
 //            sums BN2's backward needs (sum dz, sum dz * xhat2, sum da2 * min(z2, 0): ssmi_conv2d_bwd_data_bn_bwd's) - dmain
 //            is still stored (the expansion's weight gradient reads it) but not read again on the main chain
+//   mode Ft  mode F carried THROUGH the next block's 1x1 reduction (src/models.py:1090-1100): the output tile goes back into LDS
+//            and is multiplied with that layer's kernel (same split as B2t); y1' = out * W1' is stored with the column sums of y1'
+//            and y1'^2 (BN1' statistics) - the next block starts with its BatchNormalization apply instead of a convolution
 //   WG       (B2t and B1c) the weight gradient of a 1x1 layer formed where its operands already sit in LDS, accumulated in
 //            registers over the workgroup's tiles and written as one partial matrix per workgroup (per pixel-block wave pair
 //            for 64 channels), summed by ssmi_expand_weight_reduce:  B2t: dW3 = a2^T * dmain (dmain is then not stored at
@@ -59,8 +62,8 @@ struct ExpandArgs {
   void* out;                // F: block output; B1: dsum; B2: dmain
   void* y3_out;             // F only, nullable: also store the recomputed expansion output (tests, debugging)
   float* part;              // S: [grid][2][C]; B1: [grid][3][C]
-  void* da2;                // B2t: [npix][C4] gradient at the expansion's (normalised) input
-  float* part2;             // B2t: [grid][3][C4]
+  void* da2;                // B2t: [npix][C4] gradient at the expansion's (normalised) input; Ft: [npix][C4] output of the next block's reduction
+  float* part2;             // B2t: [grid][3][C4]; Ft: [grid][2][C4]
   float* wpart;             // WG: [rows][C4][C] (B2t) / [rows][C][C4] (B1c), rows = grid * (pixel blocks per tile)
 };
 
@@ -76,7 +79,7 @@ struct ExpandLds {
   static constexpr int Wl = 0, Al = W, St = Al + A, X = St + S; // X: start of the mode's own regions
   static constexpr int Wn = X, An = Wn + W, Sn = An + A, Ot = Sn + S;                 // B1c
   static constexpr int Wt = X, WtN = kBf ? D : C * 36, Pn = Wt + WtN;                 // B2t
-  static constexpr int total = MODE == 4 ? Ot + (WG && kBf ? D : 0) : (MODE == 5 ? Pn + 4 * 32 * 33 : X);
+  static constexpr int total = MODE == 4 ? Ot + (WG && kBf ? D : 0) : (MODE == 5 || MODE == 6 ? Pn + 4 * 32 * 33 : X);
 };
 
 template <typename T, int C4, int C, int MODE, bool WG = false>
@@ -94,9 +97,11 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   constexpr int NS = MODE == 0 ? 2 : 3;
   constexpr bool kB1 = MODE == 2 || MODE == 4, kChain = MODE == 4;
   constexpr bool kB2 = MODE == 3 || MODE == 5, kThru = MODE == 5;
+  constexpr bool kF = MODE == 1 || MODE == 6, kFt = MODE == 6;
+  constexpr bool kHasD = kB1 || kB2;          // a wide gradient operand (dout / dsum)
   constexpr int KS = CWN, KW = C / KS;        // B2t: the waves of a pixel block split the reduction over the C channels
   constexpr int WTS = 33;                     // B2t: row stride of W3^T (columns beyond C4 are zero) and of the partial products
-  static_assert(!kThru || (NY == 1 && KW % 2 == 0), "shape");
+  static_assert(!(kThru || kFt) || (NY == 1 && KW % 2 == 0), "shape");
   constexpr bool kSums = MODE == 0 || kB1;
   static_assert(NY >= 1 && 256 % P4 == 0 && 256 % G == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     pr.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(q + 4 * rowb));
     return __builtin_bit_cast(bf16x8, pr);
   };
-  bf16x8 wf[kBf ? NT : 1][kBf ? K1 : 1], wnf[kBf && kChain ? NT : 1][kBf && kChain ? K1 : 1], wtf[kBf && kThru ? K3 : 1];
+  bf16x8 wf[kBf ? NT : 1][kBf ? K1 : 1], wnf[kBf && kChain ? NT : 1][kBf && kChain ? K1 : 1], wtf[kBf && (kThru || kFt) ? K3 : 1];
   if constexpr (kBf) {
 #pragma unroll
     for (int u = 0; u < NT; ++u)
@@ -166,6 +171,21 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         wtf[s2] = pack_bf16x8(lo, hi);
       }
     }
+    if constexpr (kFt) {      // column r of the next block's reduction kernel [C][C4], this wave's share of its rows
+#pragma unroll
+      for (int s2 = 0; s2 < K3; ++s2) {
+        f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = {0.f, 0.f, 0.f, 0.f};
+        if (r < C4) {
+          const float* q = a.w_next + (cw * KW + 16 * s2 + 8 * hh) * C4 + r;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lo[j] = q[j * C4];
+            hi[j] = q[(4 + j) * C4];
+          }
+        }
+        wtf[s2] = pack_bf16x8(lo, hi);
+      }
+    }
   } else {
     for (int e = tid * 4; e < C4 * C; e += 1024) *reinterpret_cast<f32x4*>(Wl + e) = *reinterpret_cast<const f32x4*>(a.w + e);
   }
@@ -174,6 +194,12 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     for (int e = tid; e < C * 32; e += 256) {
       const int cc = e >> 5, n = e & 31;
       Wt[cc * WTS + n] = n < C4 ? Wl[n * C + cc] : 0.f;
+    }
+  }
+  if constexpr (kFt && !kBf) {
+    for (int e = tid; e < C * 32; e += 256) {
+      const int cc = e >> 5, n = e & 31;
+      Wt[cc * WTS + n] = n < C4 ? a.w_next[cc * C4 + n] : 0.f;
     }
   }
   if constexpr (kChain && !kBf) {
@@ -201,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     m3 = *reinterpret_cast<const f32x4*>(a.mean3 + c);
     is3 = *reinterpret_cast<const f32x4*>(a.invstd3 + c);
   }
-  if constexpr (MODE == 1 || kB1) {
+  if constexpr (kF || kB1) {
     g3 = *reinterpret_cast<const f32x4*>(a.gamma3 + c);
     b3 = *reinterpret_cast<const f32x4*>(a.beta3 + c);
     al3 = *reinterpret_cast<const f32x4*>(a.alpha3 + c);
@@ -224,14 +250,14 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   // offsets below are byte offsets of a float32 tensor; the bf16 accessors halve them (common.h)
   const unsigned wide_bytes = (unsigned)a.npix * (unsigned)C * 4u;
   const __amdgpu_buffer_rsrc_t ry2 = Act<T>::rsrc(a.y2, (unsigned)a.npix * (unsigned)C4 * 4u);
-  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(MODE == 1 || kB1 ? a.skip : a.y2,
-                                                    MODE == 1 || kB1 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(kF || kB1 ? a.skip : a.y2,
+                                                    kF || kB1 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
   const __amdgpu_buffer_rsrc_t rdn = Act<T>::rsrc(kChain ? a.dy_next : a.y2, kChain ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
   const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
-  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (kB2 ? a.dsum_in : a.y2), MODE >= 2 ? wide_bytes : 0u);
-  const __amdgpu_buffer_rsrc_t rda = Act<T>::rsrc(kThru ? a.da2 : (void*)a.part, kThru ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (kB2 ? a.dsum_in : a.y2), kHasD ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t rda = Act<T>::rsrc(kThru || kFt ? a.da2 : (void*)a.part, kThru || kFt ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
   const __amdgpu_buffer_rsrc_t ro = Act<T>::rsrc(MODE != 0 && a.out ? a.out : (void*)a.part, MODE != 0 && a.out ? wide_bytes : 0u);      // (B2t + WG: dmain may be NULL, nothing is stored)
-  const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(MODE == 1 && a.y3_out ? a.y3_out : (void*)a.part, MODE == 1 && a.y3_out ? wide_bytes : 0u);
+  const __amdgpu_buffer_rsrc_t ry3 = Act<T>::rsrc(kF && a.y3_out ? a.y3_out : (void*)a.part, kF && a.y3_out ? wide_bytes : 0u);
   auto store4 = [&](__amdgpu_buffer_rsrc_t rs, unsigned off4, const f32x4& val) {      // out-of-range offsets are dropped
     if constexpr (kBf) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(val), rs, off4 >> 1, 0, 0);
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rs, off4, 0, 0);
@@ -259,14 +285,14 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       yv[j] = yv_next[j];
       if constexpr (kChain) nv[j] = nv_next[j];
     }
-    typename Act<T>::raw4 xs[MODE == 1 || kB1 ? NPASS : 1], dv[MODE >= 2 ? NPASS : 1];
+    typename Act<T>::raw4 xs[kF || kB1 ? NPASS : 1], dv[kHasD ? NPASS : 1];
 #pragma unroll
     for (int q = 0; q < NPASS; ++q) {
       const unsigned p = p0 + (unsigned)(q * PL + pl);
       const unsigned off = p < (unsigned)a.npix ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB;
-      if constexpr (MODE == 1 || kB1)
+      if constexpr (kF || kB1)
         xs[q] = Act<T>::ld4r(rskip, (p < (unsigned)a.npix && has_skip) ? (p * (unsigned)a.c_skip + (unsigned)c) * 4u : kOOB);
-      if constexpr (MODE >= 2) dv[q] = Act<T>::ld4r(rd, off);
+      if constexpr (kHasD) dv[q] = Act<T>::ld4r(rd, off);
     }
     request_narrow(t + (int)gridDim.x);
     __syncthreads();                           // the previous tile's staged accumulators have been read (first tile: W is in LDS)
@@ -368,8 +394,8 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       const bool live = p < (unsigned)a.npix;
       const f32x4 y3 = *reinterpret_cast<const f32x4*>(St + lp * SS + c);
       f32x4 xq = {0.f, 0.f, 0.f, 0.f}, dq = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (MODE == 1 || kB1) xq = Act<T>::up4(xs[q]);
-      if constexpr (MODE >= 2) dq = Act<T>::up4(dv[q]);
+      if constexpr (kF || kB1) xq = Act<T>::up4(xs[q]);
+      if constexpr (kHasD) dq = Act<T>::up4(dv[q]);
       if constexpr (kChain) {      // dout = data gradient + the next block's skip gradient (bfloat16: rounded as the stored dout was)
         const f32x4 dg = *reinterpret_cast<const f32x4*>(Sn + lp * SS + c);
 #pragma unroll
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           const float xh = (y3[e] - m3[e]) * is3[e];
           float s = (g3[e] * xh + b3[e]) * dr[e];
           s += xq[e];
-          if constexpr (MODE == 1) {
+          if constexpr (kF) {
             o[e] = s > 0.f ? s : al3[e] * s;
           } else {
             if constexpr (WG) ov[e] = live ? (s > 0.f ? s : al3[e] * s) : 0.f;      // the block's output = the next block's input
@@ -419,7 +445,12 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           if constexpr (kBf) *reinterpret_cast<u32x2*>(Otb + lp * DBS + c * 2) = pack_bf16x4(ov);
           else *reinterpret_cast<f32x4*>(St + lp * SS + c) = ov;
         }
-        if constexpr (MODE == 1) store4(ry3, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, y3);      // (empty descriptor: dropped)
+        if constexpr (kF) store4(ry3, live ? (p * (unsigned)C + (unsigned)c) * 4u : kOOB, y3);      // (empty descriptor: dropped)
+        if constexpr (kFt) {      // the output tile, where this thread read y3 from (bfloat16: its own region, rounded as stored)
+          if (!live) o = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (kBf) *reinterpret_cast<u32x2*>(Dtb + lp * DBS + c * 2) = pack_bf16x4(o);
+          else *reinterpret_cast<f32x4*>(St + lp * SS + c) = o;
+        }
       }
     }
     if constexpr (WG && kChain) {      // dW1' += out^T * dy1': rows = this wave's 32 output channels, columns = the C4 reduced ones
@@ -437,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         }
       }
     }
-    if constexpr (kThru) {
+    if constexpr (kThru || kFt) {
       __syncthreads();
       if constexpr (WG) {      // dW3 += a2^T * dmain: rows = the C4 input channels, columns = this wave's 32 output channels
         if constexpr (kBf) {
@@ -482,6 +513,12 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int k2 = 1; k2 < KS; ++k2) d += Pn[(k2 * TP + px) * WTS + yc + e];
         da[e] = d;
+        if constexpr (kFt) {      // BN1' statistics of the next block, from the unrounded values as the convolution kernels take them
+          const float yy = live2 ? d : 0.f;
+          v2[0][e] += yy;
+          v2[1][e] += yy * yy;
+          continue;
+        }
         const float xh = (yw[e] - m2[e]) * is2[e];
         const float z = g2[e] * xh + b2[e];
         const float gr = !act2 ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al2[e] : 0.f));
@@ -505,19 +542,20 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       }
     }
   }
-  if constexpr (kThru) {      // one row of BN2-backward sums per workgroup, pixels added in a fixed order
+  if constexpr (kThru || kFt) {      // one row of BN2-backward sums (B2t) / BN1' statistics (Ft) per workgroup, pixels added in a fixed order
+    constexpr int N2 = kThru ? 3 : 2;
     __syncthreads();
-    float* red = St;          // [3][TP][C4]
+    float* red = St;          // [N2][TP][C4]
     const int px = tid / P4;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<f32x4*>(red + (k * TP + px) * C4 + yc) = v2[k];
+    for (int k = 0; k < N2; ++k) *reinterpret_cast<f32x4*>(red + (k * TP + px) * C4 + yc) = v2[k];
     __syncthreads();
     if (tid < C4) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
+      for (int k = 0; k < N2; ++k) {
         float t2 = 0.f;
         for (int p2 = 0; p2 < TP; ++p2) t2 += red[(k * TP + p2) * C4 + tid];
-        a.part2[((size_t)blockIdx.x * 3 + k) * C4 + tid] = t2;
+        a.part2[((size_t)blockIdx.x * N2 + k) * C4 + tid] = t2;
       }
     }
   }
@@ -710,6 +748,33 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
                                  pre->invstd, pre->gamma, pre->beta, pre_alpha ? SSMI_ACT_PRELU : SSMI_ACT_NONE, pre_alpha, 0.f, nullptr,
                                  (int64_t)a.hw, static_cast<T*>(dy2), dgamma2, dbeta2, dalpha2, (int64_t)a.npix, d->cin, coef2, st);
   });
+}
+
+ssmi_status ssmi_expand_merge_fwd_through(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                          const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
+                                          const float* alpha, void* out, void* y3_out, const float* w_next, void* y1_next, float eps,
+                                          float momentum, int32_t unbiased_moving, float* moving_mean1, float* moving_var1,
+                                          float* save_mean1, float* save_invstd1, void* ws, size_t ws_bytes, void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_fwd_through: 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd && bn3->gamma &&
+               bn3->beta && skip && alpha && out && w_next && y1_next && save_mean1 && save_invstd1, SSMI_E_INVALID_ARG,
+               "expand_merge_fwd_through: NULL argument");
+  SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE, "expand_merge_fwd_through: skip channels must be a multiple of 4 within the output's");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_expand_workspace_bytes(d), SSMI_E_WORKSPACE, "expand_merge_fwd_through: workspace too small");
+  SSMI_REQUIRE(aligned16({x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma, bn3->beta,
+                          drop, skip, alpha, out, y3_out, w_next, y1_next, ws}), SSMI_E_INVALID_ARG,
+               "expand_merge_fwd_through: pointers must be 16-byte aligned");
+  ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
+  a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
+  a.drop = drop; a.skip = skip; a.c_skip = c_skip; a.out = out;
+  a.y3_out = y3_out;
+  a.w_next = w_next; a.da2 = y1_next;
+  a.part2 = static_cast<float*>(ws);
+  int rows = 0;
+  ssmi_status s = launch_expand<6>(d, a, &rows, as_stream(stream));
+  if (s) return s;
+  return launch_bn_stats_final(a.part2, rows, d->cin, a.npix, eps, momentum, unbiased_moving, moving_mean1, moving_var1, save_mean1,
+                               save_invstd1, as_stream(stream));
 }
 
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,

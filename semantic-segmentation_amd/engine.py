@@ -770,6 +770,7 @@ class Bottleneck(Block):
                 self.expand = ed
                 self._eref = C.byref(ed)
         self._expanded = False
+        self._y1_ready = False
         self.keep_y3 = bool(os.environ.get("SSMI_KEEP_Y3"))
         # A regular bottleneck whose own expansion is recomputed has the shapes the chained merge backward of the block in front
         # needs (cin -> cin/4 reduction): it hands its input gradient over unformed (DeferredInputGradient).  SSMI_NO_CHAIN=1: never.
@@ -820,7 +821,10 @@ class Bottleneck(Block):
         if fuse1:
             self.conv1.fwd_bn_act_infer(x, self.a1, self.bn1, st)
         else:
-            self.conv1.fwd_bn(x, self.y1, self.bn1, self.np1, tr, um, ub, ws, st)
+            if tr and self._y1_ready:      # the block in front has left y1 and BN1's statistics (merge forward carried through)
+                self._y1_ready = False
+            else:
+                self.conv1.fwd_bn(x, self.y1, self.bn1, self.np1, tr, um, ub, ws, st)
             self.bn1.act_fwd(self.y1, i, self.a1, self.np1, st)
         src2 = self.a1
         if self.conv2a is not None:
@@ -855,6 +859,16 @@ class Bottleneck(Block):
             if self.mode == 1:      # downsampling block: the skip branch is the max-pooled input, channel-padded with zeros
                 L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin, _ptr(self.idx), None, st)
                 skip, c_skip = self.pooled, self.cin
+            nb = getattr(self, "next_fwd", None)
+            if nb is not None:
+                b1 = nb.bn1
+                L0.expand_merge_fwd_through(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), bn3._pref, _ptr(drop),
+                                            _ptr(skip), c_skip, _ptr(self.alpha3), _ptr(self.out), _ptr(self.y3) if self.keep_y3 else None,
+                                            _ptr(nb.conv1.w), _ptr(nb.y1), BN_EPS, BN_MOMENTUM, 1 if ub else 0,
+                                            _ptr(b1.mm) if um else None, _ptr(b1.mv) if um else None, _ptr(b1.mean), _ptr(b1.invstd),
+                                            _ptr(ws), ws.numel() * 4, st)
+                nb._y1_ready = True
+                return self.out
             L0.expand_merge_fwd(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), bn3._pref, _ptr(drop),
                                 _ptr(skip), c_skip, _ptr(self.alpha3), _ptr(self.out), _ptr(self.y3) if self.keep_y3 else None, st)
             return self.out
@@ -1411,3 +1425,11 @@ class ENetGraph(GraphBase):
                 hh, ww, c = b.plan(n, hh, ww, dev, unpool_idx=uidx)
             else:
                 hh, ww, c = b.plan(n, hh, ww, dev)
+        # A bottleneck that recomputes its expansion carries its merge forward through the 1x1 reduction the next regular
+        # bottleneck starts with (ssmi_expand_merge_fwd_through).  SSMI_NO_FWD_THROUGH=1: the reduction as its own launch.
+        for a, b in zip(self.blocks, self.blocks[1:]):
+            if isinstance(a, Bottleneck):
+                a.next_fwd = None
+                if (isinstance(b, Bottleneck) and a.expand is not None and b.mode == 0 and b.cin == a.cout and b.internal == a.expand.cin
+                        and (b.hin, b.win) == (a.ho, a.wo) and not os.environ.get("SSMI_NO_FWD_THROUGH")):
+                    a.next_fwd = b

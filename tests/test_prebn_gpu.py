@@ -165,8 +165,12 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
     w0 = E.init_weights(name, NC, seed=12, perturb=True)
     images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=13, block=8)
     res = {}
-    for mode in ("stored", "expand", "expand+keep", "expand-unchained", "expand-two-launches", "expand-fused-weight-gradients"):
+    for mode in ("stored", "expand", "expand+keep", "expand-unchained", "expand-two-launches", "expand-fused-weight-gradients",
+                 "expand-own-reductions"):
         monkeypatch.delenv("SSMI_NO_EXPAND", raising=False)
+        monkeypatch.delenv("SSMI_NO_FWD_THROUGH", raising=False)
+        if mode == "expand-own-reductions":
+            monkeypatch.setenv("SSMI_NO_FWD_THROUGH", "1")
         monkeypatch.delenv("SSMI_KEEP_Y3", raising=False)
         monkeypatch.delenv("SSMI_NO_CHAIN", raising=False)
         monkeypatch.delenv("SSMI_NO_THROUGH", raising=False)
@@ -195,13 +199,13 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
         if mode != "stored":
             assert len(used) >= 15, used
         chained = [b.name for b in g.blocks if getattr(b, "_chained", False)]
-        assert (len(chained) >= 14) == (mode in ("expand", "expand+keep", "expand-two-launches", "expand-fused-weight-gradients")), (mode, chained)
+        assert (len(chained) >= 14) == (mode in ("expand", "expand+keep", "expand-two-launches", "expand-fused-weight-gradients", "expand-own-reductions")), (mode, chained)
         res[mode] = dict(loss=out[0], grad=g.store.grad.clone(), outs={b.name: b.out.clone() for b in g.blocks if hasattr(b, "bn3")},
                          stats={b.name: (b.bn3.mean.clone(), b.bn3.invstd.clone()) for b in g.blocks if hasattr(b, "bn3")},
                          views={k: (v.data_ptr() - g.store.grad.data_ptr()) // 4 for k, v in g.store.gviews.items()},
                          sizes={k: v.numel() for k, v in g.store.gviews.items()})
         m.close()
-    a, b, c = res["stored"], res["expand"], res["expand+keep"]
+    b, c = res["expand"], res["expand+keep"]
     assert b["loss"] == c["loss"] and torch.equal(b["grad"], c["grad"])
     # the chained merge backward (the next block's first data gradient formed inside it, never stored) against the two-kernel
     # route: the forward pass is the same kernels, and the gradients differ by the summation order inside dout only
@@ -215,17 +219,20 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
             tb_, tu_ = b["grad"][off:off + b["sizes"][k]], u["grad"][off:off + u["sizes"][k]]
             # (floor: biases in front of a BatchNormalization have gradients that are rounding residue, 1e-8 against 1e-1 elsewhere)
             assert float((tb_ - tu_).abs().max()) <= 1e-4 * float(tu_.abs().max()) + 1e-6 * float(gu_.abs().max()), k
-    assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])
-    for k in a["outs"]:
-        s_ = float(a["outs"][k].abs().max())
-        assert float((a["outs"][k] - b["outs"][k]).abs().max()) <= 1e-4 * s_, k      # (differences compound over the blocks)
-        for u, v in zip(a["stats"][k], b["stats"][k]):
-            assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max()), k
-    # gradients: a last-bit difference in y3 flips PReLU / pooling branches of elements that sit at a kink, which moves single
-    # entries of small tensors by percents (the oracle tests replay the device's branches and hold THIS route to 1e-3); here
-    # the whole arena must agree in norm and no tensor may be off grossly
-    ga, gb = a["grad"].double(), b["grad"].double()
-    assert float((ga - gb).norm() / ga.norm()) <= 1e-2, float((ga - gb).norm() / ga.norm())
-    for k, off in a["views"].items():
-        ta, tb = a["grad"][off:off + a["sizes"][k]], b["grad"][off:off + a["sizes"][k]]
-        assert float((ta - tb).abs().max()) <= 1e-1 * float(ta.abs().max()) + 1e-6, k
+    # routes whose forward values are the same products summed in another order: the stored expansion output, and the next
+    # block's 1x1 reduction as its own launch instead of inside the merge forward
+    for a in (res["stored"], res["expand-own-reductions"]):
+        assert abs(a["loss"] - b["loss"]) <= 1e-6 * abs(a["loss"])
+        for k in a["outs"]:
+            s_ = float(a["outs"][k].abs().max())
+            assert float((a["outs"][k] - b["outs"][k]).abs().max()) <= 1e-4 * s_, k      # (differences compound over the blocks)
+            for u, v in zip(a["stats"][k], b["stats"][k]):
+                assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max()), k
+        # gradients: a last-bit difference in y3 flips PReLU / pooling branches of elements that sit at a kink, which moves single
+        # entries of small tensors by percents (the oracle tests replay the device's branches and hold THIS route to 1e-3); here
+        # the whole arena must agree in norm and no tensor may be off grossly
+        ga, gb = a["grad"].double(), b["grad"].double()
+        assert float((ga - gb).norm() / ga.norm()) <= 1e-2, float((ga - gb).norm() / ga.norm())
+        for k, off in a["views"].items():
+            ta, tb = a["grad"][off:off + a["sizes"][k]], b["grad"][off:off + a["sizes"][k]]
+            assert float((ta - tb).abs().max()) <= 1e-1 * float(ta.abs().max()) + 1e-6, k
