@@ -177,6 +177,16 @@ typedef struct ssmi_premerge {
  * main chain of the backward pass does not wait for (or read back) the stored tensor.  Results are bit-identical to
  * ssmi_merge_bwd followed by ssmi_conv2d_bwd_data_bn_bwd_rot.  float32; ssmi_conv2d_bwd_data_premerge_supported(d) says
  * whether the layer qualifies (1x1, stride 1, forward-form data gradient, at most 32 input and 128 output channels). */
+/* ssmi_conv2d_bwd_data_bn_bwd_rot stopped after the reduction: da = the plain data gradient (behind the BatchNormalization +
+ * activation), dgamma / dbeta / dalpha written, coef = k1 | m1 | m2 (3 * cin floats) for a consumer that runs the apply pass
+ *   dx_bn = k1 * (da * act'(z) - m1 - xhat * m2)
+ * itself (ssmi_expand_next_apply).  _supported: the layer takes the fused reduction (stride 1, cin % 4 == 0, ...). */
+int32_t ssmi_conv2d_bwd_data_bn_bwd_deferred_supported(const ssmi_conv_desc* d, int32_t ld_x);
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot_deferred(const ssmi_conv_desc* d, const void* dy, const float* w, const float* w_rot,
+                                                     void* da, const void* bn_x, int32_t ld_x, const float* mean, const float* invstd,
+                                                     const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                                     float* dgamma, float* dbeta, float* dalpha, float* coef, void* ws, size_t ws_bytes,
+                                                     void* stream);
 int32_t ssmi_conv2d_bwd_data_premerge_supported(const ssmi_conv_desc* d);
 ssmi_status ssmi_conv2d_bwd_data_bn_bwd_premerge(const ssmi_conv_desc* d, const ssmi_premerge* pm, const float* w,
                                                  const float* w_rot, void* da, const void* bn_x, int32_t ld_x,
@@ -684,7 +694,8 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *                          The apply pass multiplies its dmain tile with w^T in place and takes BN2's column sums there; dmain
  *                          is still stored (the weight gradient of the expansion reads it).  Replaces ssmi_expand_merge_bwd +
  *                          ssmi_conv2d_bwd_data_bn_bwd of the expansion.
- *                          (dy2 NULL with wpart1_next given: the plain apply pass, dmain required.)
+ *                          (dy2 NULL with wpart1_next or next_apply given: the plain apply pass, dmain required.)
+ *                          next_apply (nullable, chained form only): see ssmi_expand_next_apply.
  *                          wpart3 / wpart1_next (each nullable, ssmi_expand_weight_partial_bytes(d) bytes, 16-byte aligned):
  *                          the weight gradients of the two 1x1 layers whose operands the passes hold in LDS anyway, as
  *                          per-workgroup partial matrices - wpart3: of the expansion itself (dW3 = a2^T * dmain; dmain may then
@@ -694,6 +705,16 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *                          gradient ([cin][cout] for wpart3, [cout][cin] for wpart1_next; any stream ordered behind the call).
  *                          Replace ssmi_conv2d_bwd_weight of these layers.
  * Outputs equal the stored route's up to the order of the float32 sums inside y3 (and inside dout, da2, dW). */
+/* ssmi_expand_merge_bwd_through, chained form: the backward of the BatchNormalization + PReLU behind the next block's
+ * reduction has stopped after its reduction (ssmi_conv2d_bwd_data_bn_bwd_rot_deferred: coef = k1 | m1 | m2, 3 * cin floats) and
+ * dy_next still holds the gradient behind them; the reducing pass runs their apply pass (ssmi_bn_act_bwd's arithmetic) on the
+ * operand as it stages it and writes the result back to dy_next in place (the reduction's weight gradient reads it there). */
+typedef struct ssmi_expand_next_apply {
+  const void* y1;               /* [n,h,w,cin] raw output of the next block's reduction (activation type) */
+  const ssmi_bn_params* bn1;    /* its BatchNormalization */
+  const float* alpha;           /* PReLU slopes [cin], or NULL */
+  const float* coef;            /* 3 * cin floats */
+} ssmi_expand_next_apply;
 typedef struct ssmi_expand_desc {
   int32_t n, h, w, cin, cout;
   int32_t dtype;   /* SSMI_F32 (0) or SSMI_BF16: element type of x_raw, skip, out, dout, dsum, dmain, y3_out */
@@ -725,7 +746,7 @@ ssmi_status ssmi_expand_merge_bwd_through(const ssmi_expand_desc* d, const void*
                                           const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
                                           const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha,
                                           void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, float* wpart3, float* wpart1_next,
-                                          void* ws, size_t ws_bytes, void* stream);
+                                          const ssmi_expand_next_apply* next_apply, void* ws, size_t ws_bytes, void* stream);
 size_t ssmi_expand_weight_partial_bytes(const ssmi_expand_desc* d);
 ssmi_status ssmi_expand_weight_reduce(const ssmi_expand_desc* d, const float* wpart, float* dw, void* stream);
 

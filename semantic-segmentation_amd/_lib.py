@@ -35,6 +35,11 @@ class BnParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("mean", "invstd", "gamma", "beta")]
 
 
+class ExpandNextApply(C.Structure):
+    """ssmi_expand_next_apply"""
+    _fields_ = [("y1", C.c_void_p), ("bn1", C.POINTER(BnParams)), ("alpha", C.c_void_p), ("coef", C.c_void_p)]
+
+
 class Premerge(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("dsum", "main", "mean", "invstd", "coef", "drop")] + [("hw", C.c_int64)]
 
@@ -45,6 +50,7 @@ _PP = C.POINTER(Premerge)
 _PM = C.POINTER(MergeDesc)
 _PB = C.POINTER(BnParams)
 _PE = C.POINTER(ExpandDesc)
+_PNA = C.POINTER(ExpandNextApply)
 
 # name -> (restype, argtypes); status-returning functions are wrapped to raise SsmiError
 _PROTOS = {
@@ -70,6 +76,9 @@ _PROTOS = {
     "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes": (_sz, [_PD]),
     "ssmi_conv2d_bwd_data_bn_bwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64,
                                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_conv2d_bwd_data_bn_bwd_deferred_supported": (_i32, [_PD, _i32]),
+    "ssmi_conv2d_bwd_data_bn_bwd_rot_deferred": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp,
+                                                        _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_bwd_data_bn_bwd_rot": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64,
                                                _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_conv2d_bwd_data_rot": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -118,7 +127,7 @@ _PROTOS = {
     "ssmi_expand_merge_bwd_chained": (_i32, [_PE, _vp, _vp, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _sz, _vp]),
     "ssmi_expand_merge_bwd_through": (_i32, [_PE, _vp, _vp, _vp, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
-                                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                             _vp, _vp, _vp, _vp, _vp, _vp, _PNA, _vp, _sz, _vp]),
     "ssmi_expand_weight_partial_bytes": (_sz, [_PE]),
     "ssmi_expand_weight_reduce": (_i32, [_PE, _vp, _vp, _vp]),
     "ssmi_merge_bwd": (_i32, [_PM, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -179,7 +188,7 @@ _PROTOS["ssmi_cast_bf16_to_f32"] = (_i32, [_vp, _vp, _i64, _vp])
 F32, BF16 = 0, 1      # ssmi dtype codes of activation tensors
 
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
-_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_expand_supported", "ssmi_expand_workspace_bytes", "ssmi_expand_weight_partial_bytes", "ssmi_conv2d_bwd_data_premerge_supported", "ssmi_conv2d_prebn_supported", "ssmi_logits_tconv2x2_xent_supported", "ssmi_profile_bracket_overhead_ms", "ssmi_device_timestamp_khz", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
+_NOT_STATUS = {"ssmi_softmax_xent_static_max_pixels", "ssmi_conv2d_bwd_data_bn_bwd_deferred_supported", "ssmi_expand_supported", "ssmi_expand_workspace_bytes", "ssmi_expand_weight_partial_bytes", "ssmi_conv2d_bwd_data_premerge_supported", "ssmi_conv2d_prebn_supported", "ssmi_logits_tconv2x2_xent_supported", "ssmi_profile_bracket_overhead_ms", "ssmi_device_timestamp_khz", "ssmi_last_error", "ssmi_last_kernel", "ssmi_conv2d_fwd_bn_stats_workspace_bytes", "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes", "ssmi_conv2d_bwd_data_workspace_bytes", "ssmi_conv2d_bwd_data_uses_rotated", "ssmi_conv2d_pack_usage", "ssmi_comm_size", "ssmi_comm_rank", "ssmi_version", "ssmi_conv2d_bwd_weight_workspace_bytes",
                "ssmi_conv2d_transpose_bwd_weight_workspace_bytes", "ssmi_bn_workspace_bytes", "ssmi_merge_workspace_bytes",
                "ssmi_softmax_xent_workspace_bytes", "ssmi_mt_consistency_workspace_bytes", "ssmi_superpixel_workspace_bytes"}
 

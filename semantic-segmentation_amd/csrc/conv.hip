@@ -3722,7 +3722,7 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
                                                const float* gamma, const float* beta, int32_t act, const float* alpha,
                                                float slope, const float* drop, int64_t hw, T* dx_bn, float* dgamma,
                                                float* dbeta, float* dalpha, void* ws, size_t ws_bytes, void* stream,
-                                               const ssmi_premerge* pm = nullptr) {
+                                               const ssmi_premerge* pm = nullptr, float* coef_out = nullptr) {
   const Geo g = to_geo(d);
   const int64_t npix = (int64_t)d->n * d->h * d->w;
   const int c = d->cin;
@@ -3732,6 +3732,7 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
   static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;   // A/B switch for measurements
   if (no_fuse || d->stride != 1 || c % 4 != 0 || c > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < c ||
       npix * ld_x * 4 >= 0x7FFFFFFFLL || (drop && (hw <= 0 || npix % hw != 0))) {
+    SSMI_REQUIRE(!coef_out, SSMI_E_UNSUPPORTED, "conv2d_bwd_data_bn_bwd (deferred apply): layer not supported by the fused reduction");
     ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, BnBwdArgs{}, nullptr, wt, w_rot);   // unfused: two plain passes
     if (s) return s;
     return bn_act_drop_bwd_impl<T>(da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn, dgamma,
@@ -3749,6 +3750,8 @@ static ssmi_status conv2d_bwd_data_bn_bwd_impl(const ssmi_conv_desc* d, const T*
   int rows = 0;
   ssmi_status s = launch_bwd_data<T>(g, dy, w, add, nullptr, da, st, bb, &rows, wt, w_rot);
   if (s) return s;
+  if (coef_out)      // the caller's consumer runs the apply pass: parameter gradients and the three coefficient vectors only
+    return launch_bn_bwd_final(part, rows, c, npix, gamma, invstd, dgamma, dbeta, act == SSMI_ACT_PRELU ? dalpha : nullptr, coef_out, st);
   float* coef = part + (size_t)rows * 3 * c;
   return launch_bn_bwd_tail<T>(part, rows, da, d->x_ld, bn_x, ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop, hw, dx_bn,
                                dgamma, dbeta, dalpha, npix, c, coef, st);
@@ -3797,6 +3800,35 @@ ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot(const ssmi_conv_desc* d, const void*
     return conv2d_bwd_data_bn_bwd_impl<T>(d, static_cast<const T*>(dy), w, w_rot, static_cast<const T*>(add), static_cast<T*>(da),
                                           static_cast<const T*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop,
                                           hw, static_cast<T*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream);
+  });
+}
+
+int32_t ssmi_conv2d_bwd_data_bn_bwd_deferred_supported(const ssmi_conv_desc* d, int32_t ld_x) {
+  if (check_desc(d) != SSMI_OK) return 0;
+  static const bool no_fuse = getenv("SSMI_NO_FUSED_BN_BWD") != nullptr;
+  const int64_t npix = (int64_t)d->n * d->h * d->w;
+  return !(no_fuse || d->stride != 1 || d->cin % 4 != 0 || d->cin > 1024 || ld_x % 4 != 0 || d->x_ld % 4 != 0 || ld_x < d->cin ||
+           npix * ld_x * 4 >= 0x7FFFFFFFLL);
+}
+
+ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot_deferred(const ssmi_conv_desc* d, const void* dy, const float* w, const float* w_rot,
+                                                     void* da, const void* bn_x, int32_t ld_x, const float* mean, const float* invstd,
+                                                     const float* gamma, const float* beta, int32_t act, const float* alpha, float slope,
+                                                     float* dgamma, float* dbeta, float* dalpha, float* coef, void* ws, size_t ws_bytes,
+                                                     void* stream) {
+  ssmi_status s = check_desc(d);
+  if (s) return s;
+  SSMI_REQUIRE(dy && w && da && bn_x && mean && invstd && gamma && beta && dgamma && dbeta && coef, SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd_rot_deferred: NULL argument");
+  SSMI_REQUIRE(ws && ws_bytes >= ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes(d), SSMI_E_WORKSPACE,
+               "conv2d_bwd_data_bn_bwd_rot_deferred: workspace too small");
+  SSMI_REQUIRE(act >= SSMI_ACT_NONE && act <= SSMI_ACT_LEAKY && (act != SSMI_ACT_PRELU || (alpha && dalpha)), SSMI_E_INVALID_ARG,
+               "conv2d_bwd_data_bn_bwd_rot_deferred: bad activation");
+  return dispatch_dtype(d->dtype, [&](auto tag) {
+    using T = decltype(tag);
+    return conv2d_bwd_data_bn_bwd_impl<T>(d, static_cast<const T*>(dy), w, w_rot, nullptr, static_cast<T*>(da), static_cast<const T*>(bn_x),
+                                          ld_x, mean, invstd, gamma, beta, act, alpha, slope, nullptr, 1, static_cast<T*>(da), dgamma, dbeta,
+                                          dalpha, ws, ws_bytes, stream, nullptr, coef);
   });
 }
 

@@ -57,6 +57,12 @@ struct ExpandArgs {
   const void* dout;         // [npix][C]                       (B1; B1c: the next block's skip gradient dsum')
   const void* dy_next;      // [npix][C4] gradient at the output of the next block's 1x1 reduction   (B1c)
   const float* w_next;      // [C][C4] that reduction's kernel                                       (B1c)
+  // B1c, optional (y1_next != nullptr): dy_next is still the gradient BEHIND that block's BN1 + PReLU1 - their backward's
+  // apply pass (ssmi_bn_act_bwd's arithmetic, coefficients k1 | m1 | m2 in coef_next) runs on the operand as it is staged,
+  // and the result goes back to dy_next in place (that block's weight gradient reads it)
+  const void* y1_next;      // [npix][C4] raw output of that reduction
+  const float* bn1_next[5]; // mean, invstd, gamma, beta, alpha (alpha nullptr: no activation)
+  const float* coef_next;
   const void* dsum_in;      // [npix][C]                       (B2)
   const float* coef;        // k1 | m1 | m2, C floats each     (B2)
   void* out;                // F: block output; B1: dsum; B2: dmain
@@ -82,8 +88,9 @@ struct ExpandLds {
   static constexpr int total = MODE == 4 ? Ot + (WG && kBf ? D : 0) : (MODE == 5 || MODE == 6 ? Pn + 4 * 32 * 33 : X);
 };
 
-template <typename T, int C4, int C, int MODE, bool WG = false>
+template <typename T, int C4, int C, int MODE, bool WG = false, bool NA = false>
 __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
+  static_assert(!NA || MODE == 4, "the next block's apply pass belongs to the B1c mode");
   using L = ExpandLds<T, C4, C, MODE, WG>;
   static_assert(!WG || MODE == 4 || MODE == 5, "the fused weight gradients belong to the B1c and B2t modes");
   constexpr bool kBf = sizeof(T) == 2;      // bfloat16 storage: operands and y3 take the roundings the stored route's tensors have
@@ -253,6 +260,26 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   const __amdgpu_buffer_rsrc_t rskip = Act<T>::rsrc(kF || kB1 ? a.skip : a.y2,
                                                     kF || kB1 ? (unsigned)a.npix * (unsigned)a.c_skip * 4u : 0u);
   const __amdgpu_buffer_rsrc_t rdn = Act<T>::rsrc(kChain ? a.dy_next : a.y2, kChain ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
+  constexpr bool apply_next = NA;
+  const __amdgpu_buffer_rsrc_t ry1n = Act<T>::rsrc(apply_next ? a.y1_next : a.y2, apply_next ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
+  const __amdgpu_buffer_rsrc_t rdno = Act<T>::rsrc(apply_next ? const_cast<void*>(a.dy_next) : (void*)a.part,
+                                                   apply_next ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
+  f32x4 n_m, n_is, n_g, n_b, n_al, n_k1, n_m1, n_m2;      // B1c apply pass: the next block's BN1 / PReLU1 parameters of this thread's four channels
+  n_m = n_is = n_g = n_b = n_al = n_k1 = n_m1 = n_m2 = f32x4{0.f, 0.f, 0.f, 0.f};
+  bool n_act = false;
+  if constexpr (NA) {
+    {
+      n_m = *reinterpret_cast<const f32x4*>(a.bn1_next[0] + yc);
+      n_is = *reinterpret_cast<const f32x4*>(a.bn1_next[1] + yc);
+      n_g = *reinterpret_cast<const f32x4*>(a.bn1_next[2] + yc);
+      n_b = *reinterpret_cast<const f32x4*>(a.bn1_next[3] + yc);
+      n_act = a.bn1_next[4] != nullptr;
+      if (n_act) n_al = *reinterpret_cast<const f32x4*>(a.bn1_next[4] + yc);
+      n_k1 = *reinterpret_cast<const f32x4*>(a.coef_next + yc);
+      n_m1 = *reinterpret_cast<const f32x4*>(a.coef_next + C4 + yc);
+      n_m2 = *reinterpret_cast<const f32x4*>(a.coef_next + 2 * C4 + yc);
+    }
+  }
   const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
   const __amdgpu_buffer_rsrc_t rd = Act<T>::rsrc(kB1 ? a.dout : (kB2 ? a.dsum_in : a.y2), kHasD ? wide_bytes : 0u);
   const __amdgpu_buffer_rsrc_t rda = Act<T>::rsrc(kThru || kFt ? a.da2 : (void*)a.part, kThru || kFt ? (unsigned)a.npix * (unsigned)C4 * 4u : 0u);
@@ -266,24 +293,30 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   const int ntiles = (a.npix + TP - 1) / TP;
   // the narrow operands (the expansion's input, B1c: the next block's dy1) are needed first in a tile, in front of a barrier:
   // they are requested one tile ahead (tiles beyond the last: out-of-range offsets, nothing is fetched)
-  typename Act<T>::raw4 yv_next[NY], nv_next[kChain ? NY : 1];      // raw while in flight, widened at the use
+  typename Act<T>::raw4 yv_next[NY], nv_next[kChain ? NY : 1], y1_nx[NA ? NY : 1];      // raw while in flight, widened at the use
   auto request_narrow = [&](int t) {
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       const unsigned p = (unsigned)t * TP + (unsigned)((tid + 256 * j) / P4);
       const unsigned off = (t < ntiles && p < (unsigned)a.npix) ? (p * (unsigned)C4 + (unsigned)yc) * 4u : kOOB;
       yv_next[j] = Act<T>::ld4r(ry2, off);
-      if constexpr (kChain) nv_next[j] = Act<T>::ld4r(rdn, off);
+      if constexpr (kChain) {
+        nv_next[j] = Act<T>::ld4r(rdn, off);
+        if constexpr (NA) y1_nx[j] = Act<T>::ld4r(ry1n, off);
+      }
     }
   };
   request_narrow(blockIdx.x);
   for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
     const unsigned p0 = (unsigned)t * TP;
-    typename Act<T>::raw4 yv[NY], nv[kChain ? NY : 1];
+    typename Act<T>::raw4 yv[NY], nv[kChain ? NY : 1], y1v[NA ? NY : 1];
 #pragma unroll
     for (int j = 0; j < NY; ++j) {
       yv[j] = yv_next[j];
-      if constexpr (kChain) nv[j] = nv_next[j];
+      if constexpr (kChain) {
+        nv[j] = nv_next[j];
+        if constexpr (NA) y1v[j] = y1_nx[j];
+      }
     }
     typename Act<T>::raw4 xs[kF || kB1 ? NPASS : 1], dv[kHasD ? NPASS : 1];
 #pragma unroll
@@ -303,14 +336,30 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       f32x4 avv;
 #pragma unroll
       for (int e = 0; e < 4; ++e) avv[e] = pre_bn_act(yw[e], m2[e], is2[e], g2[e], b2[e], al2[e], act2);
+      f32x4 nw = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (kChain) {
+        nw = Act<T>::up4(nv[j]);
+        if constexpr (NA) {      // BN1' + PReLU1' backward, apply pass: dy1' = k1 * (d * act'(z) - m1 - xhat * m2)
+          const f32x4 y1w = Act<T>::up4(y1v[j]);
+          const unsigned pg = p0 + (unsigned)px;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (y1w[e] - n_m[e]) * n_is[e];
+            const float z = n_g[e] * xh + n_b[e];
+            const float gr = !n_act ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? n_al[e] : 0.f));
+            nw[e] = n_k1[e] * (nw[e] * gr - n_m1[e] - xh * n_m2[e]);
+          }
+          if constexpr (kBf) nw = unpack_bf16x4(pack_bf16x4(nw));
+          store4(rdno, pg < (unsigned)a.npix ? (pg * (unsigned)C4 + (unsigned)yc) * 4u : kOOB, nw);
+        }
+      }
       if constexpr (kBf) {      // rounded as the stored normalised tensor would have been
         *reinterpret_cast<u32x2*>(Alb + px * ABS + yc * 2) = pack_bf16x4(avv);
-        if constexpr (kChain) *reinterpret_cast<typename Act<T>::raw4*>(Anb + px * ABS + yc * 2) = nv[j];
+        if constexpr (kChain) *reinterpret_cast<u32x2*>(Anb + px * ABS + yc * 2) = pack_bf16x4(nw);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) Al[px * AS + yc + e] = avv[e];
         if constexpr (kChain) {
-          const f32x4 nw = Act<T>::up4(nv[j]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) An[px * AS + yc + e] = nw[e];
         }
@@ -614,7 +663,7 @@ static int expand_grid(const ssmi_expand_desc* d) {
 // rows of a fused weight gradient's partial sums: one per workgroup and 32-pixel block of its tiles
 static int expand_weight_rows(const ssmi_expand_desc* d) { return expand_grid(d) * (d->cout == 128 ? 1 : 2); }
 
-template <int MODE, bool WG = false>
+template <int MODE, bool WG = false, bool NA = false>
 static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
   const int grid = expand_grid(d);
   if (rows) *rows = grid;
@@ -622,11 +671,11 @@ static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a,
     using T = decltype(tag);
     if (d->cin == 16) {
       constexpr size_t lds = (size_t)ExpandLds<T, 16, 64, MODE, WG>::total * 4;
-      hipLaunchKernelGGL((expand_kernel<T, 16, 64, MODE, WG>), dim3(grid), dim3(256), lds, st, a);
+      hipLaunchKernelGGL((expand_kernel<T, 16, 64, MODE, WG, NA>), dim3(grid), dim3(256), lds, st, a);
     } else {
       // (the reduction scratch of the summing modes, 3 sums x 8 pixel lanes x 128 channels, fits the staged tile)
       constexpr size_t lds = (size_t)ExpandLds<T, 32, 128, MODE, WG>::total * 4;
-      hipLaunchKernelGGL((expand_kernel<T, 32, 128, MODE, WG>), dim3(grid), dim3(256), lds, st, a);
+      hipLaunchKernelGGL((expand_kernel<T, 32, 128, MODE, WG, NA>), dim3(grid), dim3(256), lds, st, a);
     }
     SSMI_LAUNCH_CHECK();
     return SSMI_OK;
@@ -705,7 +754,8 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
                                          const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip, const float* alpha,
                                          void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws, size_t ws_bytes,
                                          void* stream, void* dy2 = nullptr, float* dgamma2 = nullptr, float* dbeta2 = nullptr,
-                                         float* dalpha2 = nullptr, float* wpart3 = nullptr, float* wpart1n = nullptr) {
+                                         float* dalpha2 = nullptr, float* wpart3 = nullptr, float* wpart1n = nullptr,
+                                         const ssmi_expand_next_apply* na = nullptr) {
   SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "%s: 16 -> 64 or 32 -> 128 channel expansions only", who);
   SSMI_REQUIRE(dout && x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd &&
                bn3->gamma && bn3->beta && skip && alpha && (dmain || wpart3) && dsum && dgamma3 && dbeta3 && dalpha, SSMI_E_INVALID_ARG,
@@ -722,13 +772,25 @@ static ssmi_status expand_merge_bwd_impl(const char* who, const ssmi_expand_desc
   a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
   a.drop = drop; a.skip = skip; a.c_skip = c_skip; a.dout = dout;
   a.dy_next = dy_next; a.w_next = w_next;
+  if (na) {
+    SSMI_REQUIRE(dy_next && na->y1 && na->bn1 && na->bn1->mean && na->bn1->invstd && na->bn1->gamma && na->bn1->beta && na->coef,
+                 SSMI_E_INVALID_ARG, "%s: the deferred apply pass needs dy_next, y1, bn1 and coef", who);
+    SSMI_REQUIRE(aligned16({na->y1, na->bn1->mean, na->bn1->invstd, na->bn1->gamma, na->bn1->beta, na->alpha, na->coef}), SSMI_E_INVALID_ARG,
+                 "%s: pointers must be 16-byte aligned", who);
+    a.y1_next = na->y1;
+    a.bn1_next[0] = na->bn1->mean; a.bn1_next[1] = na->bn1->invstd; a.bn1_next[2] = na->bn1->gamma; a.bn1_next[3] = na->bn1->beta;
+    a.bn1_next[4] = na->alpha;
+    a.coef_next = na->coef;
+  }
   a.out = dsum;
   a.part = static_cast<float*>(ws);
   float* coef = a.part + (size_t)kExpandMaxGrid * 3 * d->cout;
   int rows = 0;
   a.wpart = wpart1n;
-  ssmi_status s = dy_next ? (wpart1n ? launch_expand<4, true>(d, a, &rows, st) : launch_expand<4>(d, a, &rows, st))
-                          : launch_expand<2>(d, a, &rows, st);
+  ssmi_status s;
+  if (!dy_next) s = launch_expand<2>(d, a, &rows, st);
+  else if (wpart1n) s = na ? launch_expand<4, true, true>(d, a, &rows, st) : launch_expand<4, true>(d, a, &rows, st);
+  else s = na ? launch_expand<4, false, true>(d, a, &rows, st) : launch_expand<4>(d, a, &rows, st);
   if (s) return s;
   s = launch_bn_bwd_final(a.part, rows, d->cout, a.npix, bn3->gamma, bn3->invstd, dgamma3, dbeta3, dalpha, coef, st);
   if (s) return s;
@@ -800,15 +862,15 @@ ssmi_status ssmi_expand_merge_bwd_through(const ssmi_expand_desc* d, const void*
                                           const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip, int32_t c_skip,
                                           const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha,
                                           void* dy2, float* dgamma2, float* dbeta2, float* dalpha2, float* wpart3, float* wpart1_next,
-                                          void* ws, size_t ws_bytes, void* stream) {
+                                          const ssmi_expand_next_apply* next_apply, void* ws, size_t ws_bytes, void* stream) {
   SSMI_REQUIRE((dout != nullptr) != (dy_next != nullptr) && (!dy_next || (w_next && dsum_next)), SSMI_E_INVALID_ARG,
                "expand_merge_bwd_through: give dout, or dy_next + w_next + dsum_next");
-  SSMI_REQUIRE((dy2 || wpart1_next) && (!dy2 || (dgamma2 && dbeta2 && (dalpha2 || !pre_alpha))), SSMI_E_INVALID_ARG,
+  SSMI_REQUIRE((dy2 || wpart1_next || next_apply) && (!dy2 || (dgamma2 && dbeta2 && (dalpha2 || !pre_alpha))), SSMI_E_INVALID_ARG,
                "expand_merge_bwd_through: NULL argument");
   SSMI_REQUIRE(aligned16({dy2}), SSMI_E_INVALID_ARG, "expand_merge_bwd_through: pointers must be 16-byte aligned");
   return expand_merge_bwd_impl("expand_merge_bwd_through", d, dout ? dout : dsum_next, dy_next, w_next, x_raw, pre, pre_alpha, w, bn3, drop,
                                skip, c_skip, alpha, dmain, dsum, dgamma3, dbeta3, dalpha, ws, ws_bytes, stream, dy2, dgamma2, dbeta2, dalpha2, wpart3,
-                               wpart1_next);
+                               wpart1_next, next_apply);
 }
 
 size_t ssmi_expand_weight_partial_bytes(const ssmi_expand_desc* d) {

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional, Tuple
 import numpy as np
 import torch
 
-from ._lib import BF16, F32, BnParams, ConvDesc, ExpandDesc, MergeDesc, Premerge, lib, lib_for
+from ._lib import BF16, F32, BnParams, ConvDesc, ExpandDesc, ExpandNextApply, MergeDesc, Premerge, lib, lib_for
 
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.1   # src/models.py:1064 (weight of the OLD moving value)
@@ -279,6 +279,14 @@ class Conv:
             L.conv2d_bwd_data_ws(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), _ptr(ws), ws.numel() * 4, st)
         else:
             L.conv2d_bwd_data(self._dref, _ptr(dy), _ptr(self.w), _ptr(add), _ptr(dx), st)
+
+    def bwd_data_bn_deferred(self, dy, da, bn: "BatchNorm", bn_x, ld_x, coef, ws, st):
+        """bwd_data_bn stopped after its reduction: `da` keeps the plain data gradient, the parameter gradients are written and
+        `coef` (3 * cin floats) receives what the apply pass needs - its consumer runs it (ssmi_expand_next_apply)."""
+        act = ACT_PRELU if bn.alpha is not None else ACT_NONE
+        lib().conv2d_bwd_data_bn_bwd_rot_deferred(self._dref, _ptr(dy), _ptr(self.w), _ptr(self.wrot), _ptr(da), _ptr(bn_x), ld_x,
+                                                  _ptr(bn.mean), _ptr(bn.invstd), _ptr(bn.gamma), _ptr(bn.beta), act, _ptr(bn.alpha), 0.0,
+                                                  _ptr(bn.dgamma), _ptr(bn.dbeta), _ptr(bn.dalpha), _ptr(coef), _ptr(ws), ws.numel() * 4, st)
 
     def bwd_data_bn(self, dy, da, bn: "BatchNorm", bn_x, ld_x, dx_bn, npix, ws, st, act=None, slope=0.0, drop=None, hw=1):
         """Data gradient `da` (gradient of the output of `bn` + activation, which is this convolution's input) followed by
@@ -600,8 +608,11 @@ class DeferredInputGradient:
     the three operands in its own merge backward (ssmi_expand_merge_bwd_chained: dx is neither written nor read); any other
     consumer gets the tensor from materialise()."""
 
-    def __init__(self, block):
+    def __init__(self, block, apply_pending=False):
         self.block = block
+        # the backward of the block's BN1 + PReLU1 stopped after its reduction (block.coef1): block.da1 still holds the gradient
+        # BEHIND them, and the consumer's reducing pass applies them (ssmi_expand_next_apply) and writes dy1 back to block.da1
+        self.apply_pending = apply_pending
 
     def weight_gradient(self, cfg):
         """The reduction's weight gradient as its own launch (a consumer that forms it itself does not call this)."""
@@ -610,6 +621,9 @@ class DeferredInputGradient:
 
     def materialise(self, cfg, weight_gradient=True):
         b = self.block
+        if self.apply_pending:
+            raise RuntimeError("the input gradient of {} was deferred together with its BN1 backward's apply pass, which only the "
+                               "chained merge backward of the block in front can run".format(b.name))
         if weight_gradient:
             self.weight_gradient(cfg)
         b.conv1.bwd_data(b.da1, b.dx, cfg.st, add=b.dsum)
@@ -770,6 +784,17 @@ class Bottleneck(Block):
                 self.expand = ed
                 self._eref = C.byref(ed)
         self._expanded = False
+        self.prev_block = None
+        last2 = self.conv2a if self.conv2a is not None else self.conv2      # the layer whose data gradient meets BN1
+        # (on for bfloat16 storage only: 5.67 against 5.72 ms per ENet step; float32 7.94 against 7.87 - the chained kernel gets
+        # heavier and the reduction's weight gradient can no longer start beside it.  SSMI_DEFER_APPLY=1 / 0 overrides.)
+        want = os.environ.get("SSMI_DEFER_APPLY", "0" if self.store.dtype_code == F32 else "1") == "1"
+        self.defer_apply_ok = (want and not self.nn_resize and not last2.transpose and
+                               bool(lib().conv2d_bwd_data_bn_bwd_deferred_supported(last2._dref, i)))
+        self.coef1 = torch.empty(3 * i, dtype=torch.float32, device=dev)
+        na = ExpandNextApply()
+        na.y1, na.bn1, na.alpha, na.coef = _ptr(self.y1), C.pointer(self.bn1.params), _ptr(self.bn1.alpha), _ptr(self.coef1)
+        self._next_apply = na
         self._y1_ready = False
         self.keep_y3 = bool(os.environ.get("SSMI_KEEP_Y3"))
         # A regular bottleneck whose own expansion is recomputed has the shapes the chained merge backward of the block in front
@@ -912,18 +937,26 @@ class Bottleneck(Block):
             # (which then has to take the through entry point as well - only it carries the partial buffers)
             wp3 = self.wpart3 if through else None
             wp1 = nb.wpart1 if self._chained else None
-            if self._chained and wp1 is None:
+            na = None
+            if self._chained and dout.apply_pending:
+                na = nb._next_apply
+            # the next block's reduction's weight gradient: forked in FRONT of the launch below where it can be (it then runs
+            # beside it: 7.87 against 8.05 ms per float32 ENet step); with a pending apply pass that launch is what writes its dy1
+            if self._chained and wp1 is None and na is None:
                 dout.weight_gradient(cfg)
-            if through or wp1 is not None:
+            if through or wp1 is not None or na is not None:
                 bn2 = self.bn2
                 if wp3 is not None:
                     body = body[:9] + (None,) + body[10:]      # dmain is not stored
                 thru = (_ptr(self.da2), _ptr(bn2.dgamma), _ptr(bn2.dbeta), _ptr(bn2.dalpha)) if through else (None, None, None, None)
-                lib().expand_merge_bwd_through(*head, *body, *thru, _ptr(wp3), _ptr(wp1), _ptr(ws), wsb, st)
+                lib().expand_merge_bwd_through(*head, *body, *thru, _ptr(wp3), _ptr(wp1), C.byref(na) if na is not None else None,
+                                               _ptr(ws), wsb, st)
             elif self._chained:
                 lib().expand_merge_bwd_chained(head[0], *head[2:], *body, _ptr(ws), wsb, st)
             else:
                 lib().expand_merge_bwd(head[0], head[1], *body, _ptr(ws), wsb, st)
+            if self._chained and wp1 is None and na is not None:
+                dout.weight_gradient(cfg)
             if wp1 is not None:      # behind the launch that left the partial sums
                 cfg.side_job(lambda stream, e=nb._eref, wp=wp1, dw=nb.conv1.dw: lib().expand_weight_reduce(e, _ptr(wp), _ptr(dw), stream),
                              conv=nb.conv1)
@@ -956,12 +989,19 @@ class Bottleneck(Block):
             self.conv3.bwd_data_bn_premerge(pm, self.da2, self.bn2, self.y2, i, self.da2, ws, st)      # da2 -> dy2 (in place)
         else:
             self.conv3.bwd_data_bn(self.dy3, self.da2, self.bn2, self.y2, i, self.da2, self.np_out, ws, st)   # da2 -> dy2 (in place)
-        # conv2
+        # conv2.  A block whose input gradient the block in front will certainly form itself (chained merge backward) leaves the
+        # apply pass of its BN1 backward to that kernel as well (bfloat16 storage by default, see plan())
+        pb = self.prev_block
+        defer_apply = bool(self.mode == 0 and self.defers and self._expanded and self.defer_apply_ok and pb is not None
+                           and pb._expanded and pb.accepts(DeferredInputGradient(self)))
         if self.conv2a is not None:
             cfg.wgrad(self.conv2, self.t, self.da2)
             self.conv2.bwd_data(self.da2, self.dt, st)
             cfg.wgrad(self.conv2a, self.a1, self.dt)
-            self.conv2a.bwd_data_bn(self.dt, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)
+            if defer_apply:
+                self.conv2a.bwd_data_bn_deferred(self.dt, self.da1, self.bn1, self.y1, i, self.coef1, ws, st)
+            else:
+                self.conv2a.bwd_data_bn(self.dt, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)
         elif self.nn_resize:
             cfg.wgrad(self.conv2, self.a1u, self.da2)
             self.conv2.bwd_data(self.da2, self.da1u, st)
@@ -969,10 +1009,13 @@ class Bottleneck(Block):
             self.bn1.act_bwd(self.da1, self.y1, i, self.da1, self.np1, ws, st)     # da1 -> dy1 (in place)
         else:
             cfg.wgrad(self.conv2, self.a1, self.da2)
-            self.conv2.bwd_data_bn(self.da2, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)   # da1 -> dy1
+            if defer_apply:
+                self.conv2.bwd_data_bn_deferred(self.da2, self.da1, self.bn1, self.y1, i, self.coef1, ws, st)
+            else:
+                self.conv2.bwd_data_bn(self.da2, self.da1, self.bn1, self.y1, i, self.da1, self.np1, ws, st)   # da1 -> dy1
         # conv1 + skip branch
         if self.mode == 0 and self.defers and self._expanded:
-            return DeferredInputGradient(self)      # (conv1's weight gradient: by whoever forms the input gradient)
+            return DeferredInputGradient(self, defer_apply)      # (conv1's weight gradient: by whoever forms the input gradient)
         cfg.wgrad(self.conv1, self.x, self.da1)
         if self.mode == 0:
             self.conv1.bwd_data(self.da1, self.dx, st, add=self.dsum)
@@ -1428,6 +1471,8 @@ class ENetGraph(GraphBase):
         # A bottleneck that recomputes its expansion carries its merge forward through the 1x1 reduction the next regular
         # bottleneck starts with (ssmi_expand_merge_fwd_through).  SSMI_NO_FWD_THROUGH=1: the reduction as its own launch.
         for a, b in zip(self.blocks, self.blocks[1:]):
+            if isinstance(b, Bottleneck):
+                b.prev_block = a if isinstance(a, Bottleneck) else None
             if isinstance(a, Bottleneck):
                 a.next_fwd = None
                 if (isinstance(b, Bottleneck) and a.expand is not None and b.mode == 0 and b.cin == a.cout and b.internal == a.expand.cin

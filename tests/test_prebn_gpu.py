@@ -166,11 +166,12 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
     images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=13, block=8)
     res = {}
     for mode in ("stored", "expand", "expand+keep", "expand-unchained", "expand-two-launches", "expand-fused-weight-gradients",
-                 "expand-own-reductions"):
+                 "expand-own-reductions", "expand-own-apply"):
         monkeypatch.delenv("SSMI_NO_EXPAND", raising=False)
         monkeypatch.delenv("SSMI_NO_FWD_THROUGH", raising=False)
         if mode == "expand-own-reductions":
             monkeypatch.setenv("SSMI_NO_FWD_THROUGH", "1")
+        monkeypatch.setenv("SSMI_DEFER_APPLY", "0" if mode == "expand-own-apply" else "1")      # (off by default for float32 storage)
         monkeypatch.delenv("SSMI_KEEP_Y3", raising=False)
         monkeypatch.delenv("SSMI_NO_CHAIN", raising=False)
         monkeypatch.delenv("SSMI_NO_THROUGH", raising=False)
@@ -199,7 +200,7 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
         if mode != "stored":
             assert len(used) >= 15, used
         chained = [b.name for b in g.blocks if getattr(b, "_chained", False)]
-        assert (len(chained) >= 14) == (mode in ("expand", "expand+keep", "expand-two-launches", "expand-fused-weight-gradients", "expand-own-reductions")), (mode, chained)
+        assert (len(chained) >= 14) == (mode in ("expand", "expand+keep", "expand-two-launches", "expand-fused-weight-gradients", "expand-own-reductions", "expand-own-apply")), (mode, chained)
         res[mode] = dict(loss=out[0], grad=g.store.grad.clone(), outs={b.name: b.out.clone() for b in g.blocks if hasattr(b, "bn3")},
                          stats={b.name: (b.bn3.mean.clone(), b.bn3.invstd.clone()) for b in g.blocks if hasattr(b, "bn3")},
                          views={k: (v.data_ptr() - g.store.grad.data_ptr()) // 4 for k, v in g.store.gviews.items()},
@@ -211,7 +212,8 @@ def test_expansion_without_its_output_tensor_follows_the_stored_route(monkeypatc
     # route: the forward pass is the same kernels, and the gradients differ by the summation order inside dout only
     # the same for the expansion's data gradient inside the apply pass against its own launch
     # and for the weight gradients of the 1x1 layers formed inside those passes (opt-in) against their own launches
-    for u in (res["expand-unchained"], res["expand-two-launches"], res["expand-fused-weight-gradients"]):
+    # and for the apply pass of the next block's BN1 backward run by the chained pass on its operand against its own launch
+    for u in (res["expand-unchained"], res["expand-two-launches"], res["expand-fused-weight-gradients"], res["expand-own-apply"]):
         assert b["loss"] == u["loss"] and all(torch.equal(b["outs"][k], u["outs"][k]) for k in b["outs"])
         gb_, gu_ = b["grad"].double(), u["grad"].double()
         assert float((gb_ - gu_).norm() / gu_.norm()) <= 1e-5, float((gb_ - gu_).norm() / gu_.norm())
