@@ -630,15 +630,16 @@ class DeferredInputGradient:
         return b.dx
 
 
-def run_backward(blocks_last_to_first, d, cfg):
+def run_backward(blocks_last_to_first, d, cfg, last=True):
     """Backward pass over blocks (given last block first), weight gradients flushed to the side chain after every block.
-    Returns the gradient of the first block's input (a tensor)."""
+    Returns the gradient of the first block's input: a tensor, or - `last` False: more blocks follow in another call, which takes
+    what this one returns as its `d` - possibly a DeferredInputGradient."""
     for b in blocks_last_to_first:
         if isinstance(d, DeferredInputGradient) and not (isinstance(b, Bottleneck) and b.accepts(d)):
             d = d.materialise(cfg)
         d = b.bwd(d, cfg)
         cfg.flush()
-    return d.materialise(cfg) if isinstance(d, DeferredInputGradient) else d
+    return d.materialise(cfg) if (last and isinstance(d, DeferredInputGradient)) else d
 
 
 class Bottleneck(Block):

@@ -500,7 +500,7 @@ class ExtendedModel(object):
 
         def seg_bwd(j):
             def run(st):
-                d = run_backward(reversed(blocks[bounds[j + 1]:bounds[j]]), carry["d"], g._cfg)
+                d = run_backward(reversed(blocks[bounds[j + 1]:bounds[j]]), carry["d"], g._cfg, last=bounds[j + 1] == 0)
                 if self.grad_sync is not None or j == len(bounds) - 2:
                     g._cfg.join()       # a bucket must be complete before its all-reduce starts
                 carry["d"] = d
