@@ -177,6 +177,15 @@ typedef struct ssmi_premerge {
  * main chain of the backward pass does not wait for (or read back) the stored tensor.  Results are bit-identical to
  * ssmi_merge_bwd followed by ssmi_conv2d_bwd_data_bn_bwd_rot.  float32; ssmi_conv2d_bwd_data_premerge_supported(d) says
  * whether the layer qualifies (1x1, stride 1, forward-form data gradient, at most 32 input and 128 output channels). */
+/* Weight gradients finish with a reduction over per-workgroup partial sums, a 5 us launch per layer.  Between
+ * ssmi_wg_reduce_defer_begin() and ssmi_wg_reduce_defer_flush() the weight-gradient entry points called BY THIS HOST THREAD
+ * (ssmi_conv2d_bwd_weight*, ssmi_conv2d_transpose_bwd_weight, ssmi_expand_weight_reduce) leave that reduction out and remember
+ * it; flush launches all remembered ones as one kernel per 48 layers on `stream` (bit-identical results) and, with end != 0,
+ * stops the deferral.  Until the flush the gradients are not written and every deferred layer's workspace must stay untouched:
+ * give each layer its own.  Layers with 16384 or more gradient elements are reduced at once as before. */
+ssmi_status ssmi_wg_reduce_defer_begin(void);
+ssmi_status ssmi_wg_reduce_defer_flush(int32_t end, void* stream);
+
 /* ssmi_conv2d_bwd_data_bn_bwd_rot stopped after the reduction: da = the plain data gradient (behind the BatchNormalization +
  * activation), dgamma / dbeta / dalpha written, coef = k1 | m1 | m2 (3 * cin floats) for a consumer that runs the apply pass
  *   dx_bn = k1 * (da * act'(z) - m1 - xhat * m2)

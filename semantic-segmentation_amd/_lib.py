@@ -76,6 +76,8 @@ _PROTOS = {
     "ssmi_conv2d_bwd_data_bn_bwd_workspace_bytes": (_sz, [_PD]),
     "ssmi_conv2d_bwd_data_bn_bwd": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _i64,
                                            _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_wg_reduce_defer_begin": (_i32, []),
+    "ssmi_wg_reduce_defer_flush": (_i32, [_i32, _vp]),
     "ssmi_conv2d_bwd_data_bn_bwd_deferred_supported": (_i32, [_PD, _i32]),
     "ssmi_conv2d_bwd_data_bn_bwd_rot_deferred": (_i32, [_PD, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp, _vp,
                                                         _vp, _vp, _sz, _vp]),

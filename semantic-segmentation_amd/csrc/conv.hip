@@ -9,6 +9,8 @@
 // MFMA operand map (32x32x2, wave64): lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31];
 // accumulator register i of lane l is C[row = (i&3) + 8*(i>>2) + 4*(l>>5)][col = l&31].
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 #include <algorithm>
 #include <type_traits>
@@ -2053,12 +2055,10 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_lds_bf16(Geo g, Sizes sz,
 
 // Strip reduction: 16 outputs x 16 strip-slices per workgroup; every thread adds its strips (slice, slice+16, ...) with
 // four independent accumulators, the 16 slices are then combined through LDS in a fixed order (deterministic).
-__global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __restrict__ part, int nstrips, int K,
-                                                              int K_aug, int cout, float* __restrict__ dw,
-                                                              float* __restrict__ dbias) {
-  __shared__ float sm[256];
+__device__ __forceinline__ void wg_reduce_body(const float* __restrict__ part, int nstrips, int K, int K_aug, int cout,
+                                               float* __restrict__ dw, float* __restrict__ dbias, int blk, float* sm) {
   const int E = K_aug * cout;
-  const int e = blockIdx.x * 16 + (threadIdx.x & 15);
+  const int e = blk * 16 + (threadIdx.x & 15);
   const int slice = threadIdx.x >> 4;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   {
@@ -2083,6 +2083,36 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __res
     if (e < K * cout) dw[e] = t;
     else if (dbias) dbias[e - K * cout] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void conv_bwd_weight_reduce(const float* __restrict__ part, int nstrips, int K,
+                                                              int K_aug, int cout, float* __restrict__ dw,
+                                                              float* __restrict__ dbias) {
+  __shared__ float sm[256];
+  wg_reduce_body(part, nstrips, K, K_aug, cout, dw, dbias, (int)blockIdx.x, sm);
+}
+
+// The strip reductions of many layers in one launch (their partial sums have been left in place: ssmi_wg_reduce_defer_*): the
+// table travels in the kernel arguments, a workgroup finds its layer by its index and runs that layer's reduction unchanged
+// (the same additions in the same order as conv_bwd_weight_reduce: results are bit-identical).
+static constexpr int kWgBatchMax = 48;
+struct WgReduceEntry {
+  const float* part;
+  float* dw;
+  float* dbias;
+  int nstrips, K, K_aug, cout;
+};
+struct WgReduceBatch {
+  WgReduceEntry e[kWgBatchMax];
+  int first_wg[kWgBatchMax + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void conv_bwd_weight_reduce_batch(WgReduceBatch b) {
+  __shared__ float sm[256];
+  int i = 0;
+  while (i + 1 < b.n && (int)blockIdx.x >= b.first_wg[i + 1]) ++i;      // uniform
+  const WgReduceEntry& q = b.e[i];
+  wg_reduce_body(q.part, q.nstrips, q.K, q.K_aug, q.cout, q.dw, q.dbias, (int)blockIdx.x - b.first_wg[i], sm);
 }
 
 // The same reduction for long partial rows (the wide layers: hundreds of thousands of elements per row, tens to a few
@@ -2118,10 +2148,17 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_reduce_wide(const float* 
 }
 
 // Picks the reduction kernel by the shape of the partial-sum matrix.
+// reductions recorded instead of launched (ssmi_wg_reduce_defer_begin .. _flush), per host thread
+static thread_local std::vector<WgReduceEntry>* g_wg_defer = nullptr;
+
 void launch_wg_reduce(const float* part, int nstrips, int K, int K_aug, int cout, float* dw, float* dbias, hipStream_t st) {
   const int E = K_aug * cout;
   static const bool ablate = getenv("SSMI_ABLATE_WG_REDUCE") != nullptr;     // timing experiment only: results are meaningless
   if (ablate) return;
+  if (g_wg_defer && E < 16384) {      // (long rows take the wide kernel at once: their launch is not what they cost)
+    g_wg_defer->push_back(WgReduceEntry{part, dw, dbias, nstrips, K, K_aug, cout});
+    return;
+  }
   static const bool no_wide = getenv("SSMI_NO_WIDE_REDUCE") != nullptr;      // measurement switch
   const bool aligned = ((reinterpret_cast<uintptr_t>(part) | reinterpret_cast<uintptr_t>(dw) | reinterpret_cast<uintptr_t>(dbias)) & 15) == 0;
   if (!no_wide && E >= 16384 && cout % 4 == 0 && aligned)
@@ -3801,6 +3838,36 @@ ssmi_status ssmi_conv2d_bwd_data_bn_bwd_rot(const ssmi_conv_desc* d, const void*
                                           static_cast<const T*>(bn_x), ld_x, mean, invstd, gamma, beta, act, alpha, slope, drop,
                                           hw, static_cast<T*>(dx_bn), dgamma, dbeta, dalpha, ws, ws_bytes, stream);
   });
+}
+
+ssmi_status ssmi_wg_reduce_defer_begin(void) {
+  if (!g_wg_defer) g_wg_defer = new std::vector<WgReduceEntry>();
+  return SSMI_OK;
+}
+
+ssmi_status ssmi_wg_reduce_defer_flush(int32_t end, void* stream) {
+  if (!g_wg_defer) return SSMI_OK;
+  hipStream_t st = as_stream(stream);
+  const std::vector<WgReduceEntry>& v = *g_wg_defer;
+  for (size_t i0 = 0; i0 < v.size(); i0 += kWgBatchMax) {
+    WgReduceBatch b{};
+    b.n = (int)std::min<size_t>(kWgBatchMax, v.size() - i0);
+    int wgs = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.e[i] = v[i0 + i];
+      b.first_wg[i] = wgs;
+      wgs += (b.e[i].K_aug * b.e[i].cout + 15) / 16;
+    }
+    b.first_wg[b.n] = wgs;
+    hipLaunchKernelGGL(conv_bwd_weight_reduce_batch, dim3((unsigned)wgs), dim3(256), 0, st, b);
+    SSMI_LAUNCH_CHECK();
+  }
+  g_wg_defer->clear();
+  if (end) {
+    delete g_wg_defer;
+    g_wg_defer = nullptr;
+  }
+  return SSMI_OK;
 }
 
 int32_t ssmi_conv2d_bwd_data_bn_bwd_deferred_supported(const ssmi_conv_desc* d, int32_t ld_x) {

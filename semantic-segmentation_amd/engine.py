@@ -161,6 +161,7 @@ class Conv:
         self.store = store
         self.desc = None
         self.ws_bytes = 0
+        self._ws_view = None      # this layer's own weight-gradient workspace when the strip reductions are grouped (GraphBase.plan)
         self.pack_usage = 0       # bf16 storage: bit 0 / 1 = forward / data gradient can run from a bfloat16 kernel pack
         self.uses_rot = False     # the data gradient can use a pre-rotated kernel matrix (decided by the library in plan())
         self.prebn_ok = False
@@ -395,6 +396,7 @@ _ABLATE_WGRAD = os.environ.get("SSMI_ABLATE_WGRAD") is not None
 # timing experiments only (results meaningless): skip the weight gradients of one class of layers - "head" (the logits layer),
 # "1x1" (every 1x1 convolution), "spatial" (everything else)
 _ABLATE_WGRAD_KIND = os.environ.get("SSMI_ABLATE_WGRAD_KIND", "")
+_REDUCE_PER_GROUP = os.environ.get("SSMI_GROUPED_REDUCE", "") == "block"      # grouped strip reductions (opt-in): one launch per block instead of one per join
 _WGRAD_LAG = int(os.environ.get("SSMI_WGRAD_LAG", "1"))      # blocks between a fork point and the launches behind it (0: at once)
 _WGRAD_FORK_PER_CONV = os.environ.get("SSMI_WGRAD_FORK", "conv") == "conv"      # one fork point per layer instead of one per block
 
@@ -409,7 +411,7 @@ class RunCfg:
     Under graph capture this becomes a parallel branch of the HIP graph, which fills the machine while the latency-bound
     main chain (small BN / merge kernels) is running.  Without a side stream wgrad() launches in place."""
     __slots__ = ("training", "update_moving", "unbiased_moving", "use_dropout", "st", "ws", "main", "side", "ws2",
-                 "_forked", "_pending", "_sides", "_turn", "_deferred")
+                 "_forked", "_pending", "_sides", "_turn", "_deferred", "defer_reduce", "_reduce_open")
 
     def __init__(self, training, update_moving, unbiased_moving, use_dropout, st, ws, main=None, side=None, ws2=None):
         self.training, self.update_moving, self.unbiased_moving = training, update_moving, unbiased_moving
@@ -424,6 +426,10 @@ class RunCfg:
         self._pending = []
         self._deferred = []
         self._turn = 0
+        # the strip reductions of the weight gradients collected and launched as one kernel at join() (every layer then has its
+        # own workspace: conv._ws_view); set by the graph
+        self.defer_reduce = False
+        self._reduce_open = False
 
     def wgrad(self, conv, x, dy, pre=None, before=None):
         """`pre`: the BatchNorm (+PReLU) whose output is this layer's input when `x` is that BatchNorm's RAW input.
@@ -497,6 +503,9 @@ class RunCfg:
             self._turn += 1
         if not _WGRAD_FORK_PER_CONV:
             side.wait_event(ev)
+        if self.defer_reduce and not self._reduce_open:
+            lib().wg_reduce_defer_begin()
+            self._reduce_open = True
         for conv, x, dy, pre, before, own in items:
             if own is not None:
                 side.wait_event(own)
@@ -504,15 +513,21 @@ class RunCfg:
                 before(side.cuda_stream)
             if conv is None:      # side_job
                 continue
+            wsc = conv._ws_view if (self.defer_reduce and conv._ws_view is not None) else ws2
             if pre is not None:
-                conv.bwd_weight_prebn(x, pre, dy, ws2, side.cuda_stream)
+                conv.bwd_weight_prebn(x, pre, dy, wsc, side.cuda_stream)
             else:
-                conv.bwd_weight(x, dy, ws2, side.cuda_stream)
+                conv.bwd_weight(x, dy, wsc, side.cuda_stream)
+        if self._reduce_open and _REDUCE_PER_GROUP:
+            lib().wg_reduce_defer_flush(0, side.cuda_stream)
         self._forked = True
 
     def join(self):
         self.flush()
         self._launch_deferred(0)
+        if self._reduce_open:
+            lib().wg_reduce_defer_flush(1, self.side.cuda_stream)
+            self._reduce_open = False
         if self.side is not None and self._forked:
             for side in ([sd for sd, _ in self._sides] if self._sides else [self.side]):
                 ev = torch.cuda.Event()
@@ -1343,6 +1358,26 @@ class GraphBase:
         self.ws = torch.empty((need + 3) // 4 + 64, dtype=torch.float32, device=dev)
         self.ws2 = torch.empty((need2 + 3) // 4 + 64, dtype=torch.float32, device=dev) if self.overlap_weight_gradients \
             else self.ws
+        # SSMI_GROUPED_REDUCE=join|block: one strip reduction per join (or per block) instead of one per layer
+        # (ssmi_wg_reduce_defer_*): every layer's partial sums must then survive until that launch, so each layer gets its own
+        # workspace out of one arena - where that arena stays modest (the ENets: 0.7 GB; the wide models' layers reduce long
+        # rows, whose launch is not what they cost).  Off by default: bit-identical, 89 -> 2 (29) launches, and SLOWER - ENet
+        # 512x512 batch 16: 7.94 (7.92) against 7.87 ms float32, 5.72 (5.67) against 5.67 bfloat16: the per-layer launches hide
+        # beside the main chain, the grouped one is a tail behind the last weight gradient.
+        self.defer_reduce = False
+        convs = [cv for b in self.blocks for cv in b.convs()]
+        for cv in convs:
+            cv._ws_view = None
+        total = sum((cv.ws_bytes + 255) // 256 * 256 + 256 for cv in convs)
+        if (self.overlap_weight_gradients and dev.type == "cuda" and total <= (2 << 30)
+                and os.environ.get("SSMI_GROUPED_REDUCE", "") in ("join", "block") and int(os.environ.get("SSMI_WGRAD_STREAMS", "1")) == 1):
+            self.ws2_arena = torch.empty(total // 4, dtype=torch.float32, device=dev)
+            off = 0
+            for cv in convs:
+                nb_ = (cv.ws_bytes + 255) // 256 * 256 + 256
+                cv._ws_view = self.ws2_arena[off // 4:(off + nb_) // 4]
+                off += nb_
+            self.defer_reduce = True
         if self.side_stream is None and dev.type == "cuda" and self.overlap_weight_gradients:
             self.side_stream = torch.cuda.Stream(device=dev)
         # ONE weight-gradient stream.  Under graph replay the HIP runtime does not keep captured streams apart: it walks the
@@ -1385,6 +1420,7 @@ class GraphBase:
         cfg = RunCfg(training, update_moving and training, unbiased_moving,
                      training if use_dropout is None else use_dropout, st, self.ws, main,
                      self.side_streams if multi else side, self.side_wss if multi else self.ws2)
+        cfg.defer_reduce = bool(getattr(self, "defer_reduce", False) and side is not None and not multi)
         sto = self.store
         sto.infer_stats_batched = True
         if not training and sto.n_state:

@@ -205,7 +205,8 @@ def test_thirty_step_loss_trajectory_matches_the_oracle_and_falls():
 def test_weight_gradient_schedule_does_not_change_results(monkeypatch):
     """Where the weight gradients are forked from the main stream and when their launches are created (engine.RunCfg:
     per-layer fork points, launches issued one block later) is scheduling only: the step with one fork per block and
-    immediate launches, and the step with everything on the main stream, give the same bits; nothing stays queued."""
+    immediate launches, the step with everything on the main stream, and the step with one strip reduction per layer instead of
+    one grouped launch per join, give the same bits; nothing stays queued."""
     import numpy as np
     import torch
     from conftest import pkg
@@ -217,9 +218,15 @@ def test_weight_gradient_schedule_does_not_change_results(monkeypatch):
     w0 = E.init_weights(name, NC, seed=21, perturb=True)
     images, labels, pw = E.synthetic_batch(B, H, W, NC, seed=22, block=8)
     res = []
-    for lag, per_conv, overlap in ((1, True, True), (0, False, True), (2, True, True), (1, True, False)):
+    for lag, per_conv, overlap, grouped in ((1, True, True, False), (0, False, True, False), (2, True, True, False), (1, True, False, False),
+                                            (1, True, True, True)):
         monkeypatch.setattr(eng, "_WGRAD_LAG", lag)
         monkeypatch.setattr(eng, "_WGRAD_FORK_PER_CONV", per_conv)
+        # grouped: the strip reductions of all layers as one launch per join (ssmi_wg_reduce_defer_*) instead of one per layer
+        # (opt-in: measured slower than the per-layer launches)
+        monkeypatch.delenv("SSMI_GROUPED_REDUCE", raising=False)
+        if grouped:
+            monkeypatch.setenv("SSMI_GROUPED_REDUCE", "join")
         m = models.get_model(name, (None, None, 3), NC, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY).model
         m.graph.overlap_weight_gradients = overlap
         m.set_weights([w0[k] for k in m.weight_names()])
@@ -230,6 +237,7 @@ def test_weight_gradient_schedule_does_not_change_results(monkeypatch):
         cfg = m.graph._cfg
         assert not cfg._pending and not cfg._deferred, "weight gradients left unlaunched"
         assert (cfg.side is not None) == overlap
+        assert cfg.defer_reduce == (overlap and grouped) and not cfg._reduce_open
         res.append((outs, [w.copy() for w in m.get_weights()]))
     for outs, ws in res[1:]:
         for a, b in zip(res[0][0], outs):
