@@ -689,6 +689,10 @@ ssmi_status ssmi_comm_broadcast_f32(ssmi_comm* comm, float* buf, int64_t count, 
  *                          of the BatchNormalization behind it (save_mean1 / save_invstd1, moving averages when given) - the
  *                          output tile is multiplied where it was formed; replaces the next block's
  *                          ssmi_conv2d_fwd_bn_stats, whose read of `out` it saves
+ *   ssmi_expand_merge_fwd_through_infer  the inference-phase form (every BatchNormalization with fixed statistics, given as
+ *                          mean / invstd like the others): a1_next [n,h,w,cin] = PReLU1'(BN1'(out * w_next)), the ACTIVATED input of
+ *                          the next block's second convolution; replaces ssmi_conv2d_fwd_bn_add_act_infer of this block + the next
+ *                          block's ssmi_conv2d_fwd_bn_act_infer.  (ssmi_expand_merge_fwd itself serves inference as it is.)
  *   ssmi_expand_merge_bwd  dsum = gradient of the pre-activation sum (= gradient of the skip branch), dmain = gradient of
  *                          y3, dgamma3 / dbeta3 / dalpha overwritten - as ssmi_merge_bwd
  *   ssmi_expand_merge_bwd_chained  the same with dout FORMED per tile instead of read: the block that follows a regular
@@ -741,6 +745,10 @@ ssmi_status ssmi_expand_merge_fwd_through(const ssmi_expand_desc* d, const void*
                                           const float* alpha, void* out, void* y3_out, const float* w_next, void* y1_next, float eps,
                                           float momentum, int32_t unbiased_moving, float* moving_mean1, float* moving_var1,
                                           float* save_mean1, float* save_invstd1, void* ws, size_t ws_bytes, void* stream);
+ssmi_status ssmi_expand_merge_fwd_through_infer(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                                const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
+                                                int32_t c_skip, const float* alpha, void* out, const float* w_next,
+                                                const ssmi_bn_params* bn1_next, const float* alpha1_next, void* a1_next, void* stream);
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,
                                   const float* pre_alpha, const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
                                   int32_t c_skip, const float* alpha, void* dmain, void* dsum, float* dgamma3, float* dbeta3, float* dalpha, void* ws,

@@ -125,6 +125,7 @@ _PROTOS = {
     "ssmi_expand_merge_fwd": (_i32, [_PE, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "ssmi_expand_merge_fwd_through": (_i32, [_PE, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _i32, _vp, _vp,
                                              _vp, _vp, _vp, _sz, _vp]),
+    "ssmi_expand_merge_fwd_through_infer": (_i32, [_PE, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _PB, _vp, _vp, _vp]),
     "ssmi_expand_merge_bwd": (_i32, [_PE, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "ssmi_expand_merge_bwd_chained": (_i32, [_PE, _vp, _vp, _vp, _vp, _PB, _vp, _vp, _PB, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                              _sz, _vp]),

@@ -15,6 +15,8 @@
 //   mode Ft  mode F carried THROUGH the next block's 1x1 reduction (src/models.py:1090-1100): the output tile goes back into LDS
 //            and is multiplied with that layer's kernel (same split as B2t); y1' = out * W1' is stored with the column sums of y1'
 //            and y1'^2 (BN1' statistics) - the next block starts with its BatchNormalization apply instead of a convolution
+//            (NA, inference phase: the BatchNormalization has fixed statistics, so BN1' + PReLU1' are applied right there and the
+//            ACTIVATED tensor is stored; no sums)
 //   WG       (B2t and B1c) the weight gradient of a 1x1 layer formed where its operands already sit in LDS, accumulated in
 //            registers over the workgroup's tiles and written as one partial matrix per workgroup (per pixel-block wave pair
 //            for 64 channels), summed by ssmi_expand_weight_reduce:  B2t: dW3 = a2^T * dmain (dmain is then not stored at
@@ -90,7 +92,7 @@ struct ExpandLds {
 
 template <typename T, int C4, int C, int MODE, bool WG = false, bool NA = false>
 __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
-  static_assert(!NA || MODE == 4, "the next block's apply pass belongs to the B1c mode");
+  static_assert(!NA || MODE == 4 || MODE == 6, "the next block's BN1: backward apply pass in B1c, inference-phase forward in Ft");
   using L = ExpandLds<T, C4, C, MODE, WG>;
   static_assert(!WG || MODE == 4 || MODE == 5, "the fused weight gradients belong to the B1c and B2t modes");
   constexpr bool kBf = sizeof(T) == 2;      // bfloat16 storage: operands and y3 take the roundings the stored route's tensors have
@@ -268,16 +270,18 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   n_m = n_is = n_g = n_b = n_al = n_k1 = n_m1 = n_m2 = f32x4{0.f, 0.f, 0.f, 0.f};
   bool n_act = false;
   if constexpr (NA) {
-    {
+    {      // (Ft, inference phase: coef_next is unused and may be null)
       n_m = *reinterpret_cast<const f32x4*>(a.bn1_next[0] + yc);
       n_is = *reinterpret_cast<const f32x4*>(a.bn1_next[1] + yc);
       n_g = *reinterpret_cast<const f32x4*>(a.bn1_next[2] + yc);
       n_b = *reinterpret_cast<const f32x4*>(a.bn1_next[3] + yc);
       n_act = a.bn1_next[4] != nullptr;
       if (n_act) n_al = *reinterpret_cast<const f32x4*>(a.bn1_next[4] + yc);
-      n_k1 = *reinterpret_cast<const f32x4*>(a.coef_next + yc);
-      n_m1 = *reinterpret_cast<const f32x4*>(a.coef_next + C4 + yc);
-      n_m2 = *reinterpret_cast<const f32x4*>(a.coef_next + 2 * C4 + yc);
+      if constexpr (kChain) {
+        n_k1 = *reinterpret_cast<const f32x4*>(a.coef_next + yc);
+        n_m1 = *reinterpret_cast<const f32x4*>(a.coef_next + C4 + yc);
+        n_m2 = *reinterpret_cast<const f32x4*>(a.coef_next + 2 * C4 + yc);
+      }
     }
   }
   const bool has_skip = c < a.c_skip;      // channel-padded skip branch (downsampling blocks): zeros beyond its channels
@@ -562,6 +566,10 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int k2 = 1; k2 < KS; ++k2) d += Pn[(k2 * TP + px) * WTS + yc + e];
         da[e] = d;
+        if constexpr (kFt && NA) {      // inference phase: BN1' (fixed statistics) + PReLU1' applied here, the activated tensor is stored
+          da[e] = pre_bn_act(d, n_m[e], n_is[e], n_g[e], n_b[e], n_al[e], n_act);
+          continue;
+        }
         if constexpr (kFt) {      // BN1' statistics of the next block, from the unrounded values as the convolution kernels take them
           const float yy = live2 ? d : 0.f;
           v2[0][e] += yy;
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
       }
     }
   }
-  if constexpr (kThru || kFt) {      // one row of BN2-backward sums (B2t) / BN1' statistics (Ft) per workgroup, pixels added in a fixed order
+  if constexpr (kThru || (kFt && !NA)) {      // one row of BN2-backward sums (B2t) / BN1' statistics (Ft) per workgroup, pixels added in a fixed order
     constexpr int N2 = kThru ? 3 : 2;
     __syncthreads();
     float* red = St;          // [N2][TP][C4]
@@ -837,6 +845,28 @@ ssmi_status ssmi_expand_merge_fwd_through(const ssmi_expand_desc* d, const void*
   if (s) return s;
   return launch_bn_stats_final(a.part2, rows, d->cin, a.npix, eps, momentum, unbiased_moving, moving_mean1, moving_var1, save_mean1,
                                save_invstd1, as_stream(stream));
+}
+
+ssmi_status ssmi_expand_merge_fwd_through_infer(const ssmi_expand_desc* d, const void* x_raw, const ssmi_bn_params* pre, const float* pre_alpha,
+                                                const float* w, const ssmi_bn_params* bn3, const float* drop, const void* skip,
+                                                int32_t c_skip, const float* alpha, void* out, const float* w_next,
+                                                const ssmi_bn_params* bn1_next, const float* alpha1_next, void* a1_next, void* stream) {
+  SSMI_REQUIRE(expand_shape_ok(d), SSMI_E_UNSUPPORTED, "expand_merge_fwd_through_infer: 16 -> 64 or 32 -> 128 channel expansions only");
+  SSMI_REQUIRE(x_raw && pre && pre->mean && pre->invstd && pre->gamma && pre->beta && w && bn3 && bn3->mean && bn3->invstd && bn3->gamma &&
+               bn3->beta && skip && alpha && out && w_next && a1_next && bn1_next && bn1_next->mean && bn1_next->invstd && bn1_next->gamma &&
+               bn1_next->beta, SSMI_E_INVALID_ARG, "expand_merge_fwd_through_infer: NULL argument");
+  SSMI_REQUIRE(c_skip > 0 && c_skip <= d->cout && c_skip % 4 == 0, SSMI_E_SHAPE,
+               "expand_merge_fwd_through_infer: skip channels must be a multiple of 4 within the output's");
+  SSMI_REQUIRE(aligned16({x_raw, w, pre->mean, pre->invstd, pre->gamma, pre->beta, pre_alpha, bn3->mean, bn3->invstd, bn3->gamma, bn3->beta,
+                          drop, skip, alpha, out, w_next, a1_next, bn1_next->mean, bn1_next->invstd, bn1_next->gamma, bn1_next->beta,
+                          alpha1_next}), SSMI_E_INVALID_ARG, "expand_merge_fwd_through_infer: pointers must be 16-byte aligned");
+  ExpandArgs a = expand_args(d, x_raw, pre, pre_alpha, w);
+  a.mean3 = bn3->mean; a.invstd3 = bn3->invstd; a.gamma3 = bn3->gamma; a.beta3 = bn3->beta; a.alpha3 = alpha;
+  a.drop = drop; a.skip = skip; a.c_skip = c_skip; a.out = out;
+  a.w_next = w_next; a.da2 = a1_next;
+  a.bn1_next[0] = bn1_next->mean; a.bn1_next[1] = bn1_next->invstd; a.bn1_next[2] = bn1_next->gamma; a.bn1_next[3] = bn1_next->beta;
+  a.bn1_next[4] = alpha1_next;
+  return launch_expand<6, false, true>(d, a, nullptr, as_stream(stream));
 }
 
 ssmi_status ssmi_expand_merge_bwd(const ssmi_expand_desc* d, const void* dout, const void* x_raw, const ssmi_bn_params* pre,

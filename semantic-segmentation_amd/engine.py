@@ -800,6 +800,8 @@ class Bottleneck(Block):
                 self.expand = ed
                 self._eref = C.byref(ed)
         self._expanded = False
+        self._a1_ready = False
+        self.infer_expand = not os.environ.get("SSMI_NO_INFER_EXPAND")
         self.prev_block = None
         last2 = self.conv2a if self.conv2a is not None else self.conv2      # the layer whose data gradient meets BN1
         # (on for bfloat16 storage only: 5.67 against 5.72 ms per ENet step; float32 7.94 against 7.87 - the chained kernel gets
@@ -859,7 +861,9 @@ class Bottleneck(Block):
         # inference phase: BN (fixed statistics) + PReLU ride in the convolution's epilogue, a1 / a2 are written directly
         fuse1 = not tr and not self.conv1.transpose
         fuse2 = not tr and not self.conv2.transpose
-        if fuse1:
+        if not tr and self._a1_ready:      # inference phase: the block in front has left the activated a1 (merge forward carried through)
+            self._a1_ready = False
+        elif fuse1:
             self.conv1.fwd_bn_act_infer(x, self.a1, self.bn1, st)
         else:
             if tr and self._y1_ready:      # the block in front has left y1 and BN1's statistics (merge forward carried through)
@@ -874,6 +878,30 @@ class Bottleneck(Block):
         elif self.nn_resize:
             L.upsample_nn2x_fwd(_ptr(self.a1), self.n, self.h1, self.w1, i, _ptr(self.a1u), i, st)
             src2 = self.a1u
+        # inference phase, expansion recomputed inside the merge (and carried through the next block's reduction): conv2 stores
+        # its RAW output, its BN + PReLU are applied on load like in the training phase.  SSMI_NO_INFER_EXPAND=1: the route below.
+        infer_expand = (not tr and self.expand is not None and self.infer_expand and not self.conv2.transpose
+                        and not self.keep_y3)
+        if infer_expand:
+            self.conv2.fwd(src2, self.y2, st)
+            drop = self.drop_mask if (cfg.use_dropout and self.drop_mask is not None) else None
+            self._drop_used = drop
+            self._expanded = False
+            bn2, bn3, L0 = self.bn2, self.bn3, lib()
+            skip, c_skip = x, self.cout
+            if self.mode == 1:
+                L.maxpool_argmax_fwd(_ptr(x), self.n, self.hin, self.win, self.cin, _ptr(self.pooled), self.cin, _ptr(self.idx), None, st)
+                skip, c_skip = self.pooled, self.cin
+            nb = getattr(self, "next_fwd", None)
+            if nb is not None:
+                L0.expand_merge_fwd_through_infer(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), bn3._pref,
+                                                  _ptr(drop), _ptr(skip), c_skip, _ptr(self.alpha3), _ptr(self.out), _ptr(nb.conv1.w),
+                                                  nb.bn1._pref, _ptr(nb.bn1.alpha), _ptr(nb.a1), st)
+                nb._a1_ready = True
+            else:
+                L0.expand_merge_fwd(self._eref, _ptr(self.y2), bn2._pref, _ptr(bn2.alpha), _ptr(self.conv3.w), bn3._pref, _ptr(drop),
+                                    _ptr(skip), c_skip, _ptr(self.alpha3), _ptr(self.out), None, st)
+            return self.out
         if fuse2:
             self.conv2.fwd_bn_act_infer(src2, self.a2, self.bn2, st)
         else:

@@ -159,6 +159,21 @@ def test_expansion_entry_points_on_ragged_blocks(c4, c, n, h, w, dtype):
     _close(y1n, y1r, tol, "y1 of the next block")
     _close(m1, y1r.reshape(-1, c4).mean(0), tol, "BN1' mean")
     _close(is1, 1 / torch.sqrt(y1r.reshape(-1, c4).var(0, unbiased=False) + EPS), tol, "BN1' invstd")
+    # ---- inference-phase form: BN1' (fixed statistics) + PReLU1' applied to the carried-through product ----------------
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    g1 = (torch.rand(c4, generator=gen) + 0.5).to(DEV)
+    b1 = (torch.rand(c4, generator=gen) - 0.5).to(DEV)
+    al1 = (torch.rand(c4, generator=gen) * 0.6 - 0.2).to(DEV)
+    bn1 = B._bn(m1, is1, g1, b1)
+    out3 = torch.full_like(out, 7.0)
+    a1n = torch.full((n, h, w, c4), 7.0, dtype=B.adt, device=DEV)
+    L.expand_merge_fwd_through_infer(d, B.y2.data_ptr(), C.byref(B.bn2), B.a2.data_ptr(), B.w3.data_ptr(), C.byref(bn3), B.drop.data_ptr(),
+                                     B.skip.data_ptr(), c, B.a3.data_ptr(), out3.data_ptr(), B.w1n.data_ptr(), C.byref(bn1),
+                                     al1.data_ptr(), a1n.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(out3, out)
+    z1 = g1.double() * (y1r - m1.double()) * is1.double() + b1.double()
+    _close(a1n, _prelu(z1, al1.double()), tol, "activated input of the next block's second convolution")
     # ---- merge backward: plain, chained, carried through --------------------------------------------------------------
     mask3 = out.double() > 0
     for form in ("plain", "chained", "through", "chained+through"):
