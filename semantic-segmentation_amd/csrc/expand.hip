@@ -1,36 +1,39 @@
-// The 1x1 expansion of a regular ENet bottleneck (src/models.py:1142-1172: Conv2D 1x1 -> BatchNormalization ->
-// SpatialDropout2D -> Add with the block input -> PReLU) WITHOUT its output tensor.  The expansion maps 16 or 32 channels to
-// 64 or 128: recomputing it from its 4x smaller input is nearly free, while its output y3 is the widest tensor of the block and
-// is written once and read three times (merge forward, both merge-backward passes).  Every kernel here recomputes
+// The 1x1 expansion of an ENet bottleneck (src/models.py:1142-1172: Conv2D 1x1 -> BatchNormalization -> SpatialDropout2D ->
+// Add with the skip branch -> PReLU) WITHOUT its output tensor.  The expansion maps 16 or 32 channels to 64 or 128:
+// recomputing it from its 4x smaller input is nearly free, while its output y3 is the widest tensor of the block and would be
+// written once and read three times (merge forward, both merge-backward passes).  Every mode of the kernel recomputes
 //     y3 = PReLU2(BN2(y2_raw)) * W3                 (normalise on load, as ssmi_conv2d_fwd_bn_stats_prebn)
-// on v_mfma_f32_32x32x2_f32 and consumes it in place:
-//   mode S   column sums of y3 and y3^2 (training-phase statistics of BN3); nothing is stored
-//   mode F   out = PReLU3(drop * BN3(y3) + skip)                                      (ssmi_merge_fwd, identity skip)
-//   mode B1  dsum = dout * PReLU3'(s), column sums of dz, dz * xhat3, dout * min(s, 0) (ssmi_merge_bwd, reducing pass)
-//   mode B2  dmain = k1 * (dsum * drop - m1 - xhat3 * m2)                              (ssmi_merge_bwd, apply pass)
-//   mode B2t mode B2 carried THROUGH the expansion's own data gradient: the dmain tile goes back into LDS and is multiplied
-//            with W3^T (split over the waves along its 64 / 128 channels), da2 = dmain * W3^T is stored together with the column
-//            sums BN2's backward needs (sum dz, sum dz * xhat2, sum da2 * min(z2, 0): ssmi_conv2d_bwd_data_bn_bwd's) - dmain
-//            is still stored (the expansion's weight gradient reads it) but not read again on the main chain
-//   mode Ft  mode F carried THROUGH the next block's 1x1 reduction (src/models.py:1090-1100): the output tile goes back into LDS
-//            and is multiplied with that layer's kernel (same split as B2t); y1' = out * W1' is stored with the column sums of y1'
-//            and y1'^2 (BN1' statistics) - the next block starts with its BatchNormalization apply instead of a convolution
-//            (NA, inference phase: the BatchNormalization has fixed statistics, so BN1' + PReLU1' are applied right there and the
-//            ACTIVATED tensor is stored; no sums)
-//   WG       (B2t and B1c) the weight gradient of a 1x1 layer formed where its operands already sit in LDS, accumulated in
-//            registers over the workgroup's tiles and written as one partial matrix per workgroup (per pixel-block wave pair
-//            for 64 channels), summed by ssmi_expand_weight_reduce:  B2t: dW3 = a2^T * dmain (dmain is then not stored at
-//            all);  B1c: dW1' = out^T * dy1', the NEXT block's reduction - out = PReLU3(s) is what this pass computes anyway
-//   mode B1c mode B1 whose dout is not read but formed in place: dout = dy1' * W1'^T + dsum', the data gradient of the NEXT
-//            block's 1x1 reduction (src/models.py:1090-1096) plus that block's skip gradient - the same (C/4 -> C) product
-//            shape as the expansion, so the tile loop runs two products and dout is neither written nor read
-// with the arithmetic of the merge kernels per element.  A 256-thread workgroup walks 64-pixel (64 channels) or 32-pixel (128 channels) tiles: the raw input tile is
-// normalised on its way into LDS, four waves multiply (pixel blocks x channel groups, kernel matrix resident in LDS), the
-// accumulators go through LDS, and the elementwise phase runs in the merge kernels' layout - a thread owns four consecutive
-// channels of a pixel, 16-byte accesses - with every global operand of the tile requested before the multiply phase.
-// Both storage types (bfloat16: the operand, the kernel and y3 take the roundings the stored route's tensors and packs have, so
-// the values equal that route's up to summation order; its products run on v_mfma_f32_32x32x16_bf16 - the operand tiles sit in
-// LDS as bfloat16 rows, the kernel matrices stay in registers as matrix-instruction operands for the whole launch); (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
+// per tile and consumes it in place, with the arithmetic of the merge kernels per element:
+//   S   (0) column sums of y3 and y3^2 (training-phase statistics of BN3); nothing is stored
+//   F   (1) out = PReLU3(drop * BN3(y3) + skip)                                      (ssmi_merge_fwd; skip: the block input,
+//           or - downsampling block - its max-pooled input as a channel-padded operand)
+//   Ft  (6) F carried THROUGH the next block's 1x1 reduction (src/models.py:1090-1100): the output tile goes back into LDS and
+//           is multiplied with that layer's kernel (the waves split the 64 / 128 channels, partial products through LDS);
+//           y1' = out * W1' is stored with the column sums of y1' and y1'^2 (BN1' statistics) - the next block starts with its
+//           BatchNormalization apply instead of a convolution.  NA (inference phase: fixed statistics): BN1' + PReLU1' are
+//           applied right there and the ACTIVATED tensor is stored; no sums
+//   B1  (2) dsum = dout * PReLU3'(s), column sums of dz, dz * xhat3, dout * min(s, 0) (ssmi_merge_bwd, reducing pass)
+//   B1c (4) B1 whose dout is not read but formed per tile: dout = dy1' * W1'^T + dsum', the data gradient of the NEXT block's
+//           1x1 reduction plus that block's skip gradient - the same (C/4 -> C) product shape as the expansion, so the tile
+//           loop runs two products and dout is neither written nor read.  NA: dy1' is still the gradient BEHIND that block's
+//           BN1 + PReLU1; the apply pass of their backward runs on the operand as it is staged (and writes dy1' back)
+//   B2  (3) dmain = k1 * (dsum * drop - m1 - xhat3 * m2)                              (ssmi_merge_bwd, apply pass)
+//   B2t (5) B2 carried THROUGH the expansion's own data gradient: the dmain tile goes back into LDS and is multiplied with
+//           W3^T (same split as Ft); da2 = dmain * W3^T is stored with the column sums BN2's backward needs (sum dz,
+//           sum dz * xhat2, sum da2 * min(z2, 0): ssmi_conv2d_bwd_data_bn_bwd's); dmain is still stored for the expansion's
+//           weight gradient but not read again on the main chain
+//   WG  (B1c, B2t) the weight gradient of a 1x1 layer formed where its operands already sit in LDS, accumulated in registers
+//           over the workgroup's tiles and written as one partial matrix per workgroup (per 32-pixel block of a 64-pixel tile),
+//           summed by ssmi_expand_weight_reduce:  B2t: dW3 = a2^T * dmain (dmain is then not stored at all);  B1c: dW1' =
+//           out^T * dy1', the NEXT block's reduction (out = PReLU3(s) is what this pass computes anyway)
+// A 256-thread workgroup walks 64-pixel (64 channels) or 32-pixel (128 channels) tiles: the raw input tile is normalised on its
+// way into LDS, four waves multiply (pixel blocks x channel groups), the accumulators go through LDS, and the elementwise
+// phase runs in the merge kernels' layout - a thread owns four consecutive channels of a pixel, 16-byte accesses.  The wide
+// operands of a tile are requested before its multiply phase, the narrow ones one tile ahead.
+// float32 storage: v_mfma_f32_32x32x2_f32, kernel matrices resident in LDS.  bfloat16 storage: the operand, the kernel and y3
+// take the roundings the stored route's tensors and packs have (values equal that route's up to summation order); products on
+// v_mfma_f32_32x32x16_bf16, operand tiles in LDS as bfloat16 rows, kernel matrices in registers as matrix-instruction operands
+// for the whole launch.  (16 -> 64) and (32 -> 128) channels, the two shapes the ENets have.
 #include "common.h"
 
 namespace ssmi {
