@@ -249,6 +249,12 @@ def test_enet_naive_train_step_parity():
     _run_case("enet-naive-upsampling", 2, 64, 64, seed=3, steps=2)
 
 
+def test_enet_naive_train_step_parity_ragged_tiles():
+    """Pixel counts that end in a partial 32- / 64-pixel tile of the expansion kernels at every stage (180 and 720 pixels), so
+    the chained / carried-through passes run their masked last tiles inside a whole step."""
+    _run_case("enet-naive-upsampling", 3, 48, 80, seed=11, steps=1)
+
+
 def test_enet_max_unpooling_train_step_parity():
     _run_case("enet-max-unpooling", 3, 64, 96, seed=5, steps=1)
 
