@@ -539,16 +539,19 @@ class ExtendedModel(object):
 
     def _cut_indices(self) -> List[int]:
         """Block indices (descending) in front of which the backward pass is cut so that the gradients behind the cut can be
-        all-reduced while the rest of the backward pass runs.  ENets (1.46 MB of gradients): one cut in front of en_bn_2.0 -
-        the late blocks hold ~95 % of the parameters, the early blocks the high-resolution (slow) backward work that hides
-        the first bucket's all-reduce.  Wide models: a cut whenever ~BUCKET_BYTES of gradients have become final, in the
+        all-reduced while the rest of the backward pass runs.  ENets (1.46 MB of gradients): none by default, one bucket;
+        with SSMI_DP_CUTS=1 one cut in front of en_bn_2.0 - the late blocks hold ~95 % of the parameters, the early blocks the
+        high-resolution (slow) backward work that hides the first bucket's all-reduce.  Wide models: a cut whenever ~BUCKET_BYTES of gradients have become final, in the
         order the backward pass produces them (last layers first)."""
         blocks = self.graph.blocks
         offs = self._block_offsets()
         if offs is None:
             return []
+        # (the ENet cut is opt-in, SSMI_DP_CUTS=1: with 1.46 MB of gradients the second graph boundary and the join of the
+        # weight-gradient chain at the cut cost more - one-rank RCCL step 8.07 ms against 7.93 with ONE bucket behind the whole
+        # backward pass, plain step 7.88 - than an all-reduce of that size can hide)
         for i, b in enumerate(blocks):
-            if b.name == "en_bn_2.0" and offs[i] is not None:
+            if b.name == "en_bn_2.0" and offs[i] is not None and os.environ.get("SSMI_DP_CUTS") == "1":
                 return [i]
         cuts, hi = [], self.graph.store.theta.numel()
         for i in range(len(blocks) - 1, 0, -1):

@@ -130,7 +130,8 @@ def test_two_gloo_ranks_share_the_gpu_and_finish_the_data_parallel_step():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SSMI_DIST_BACKEND="gloo", SSMI_BENCH_WATCHDOG="100")
+    # (SSMI_DP_CUTS=1: the two-segment ENet step - the default is one bucket - so that the cut, its join and the second graph run)
+    env = dict(os.environ, SSMI_DIST_BACKEND="gloo", SSMI_BENCH_WATCHDOG="100", SSMI_DP_CUTS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -165,11 +165,15 @@ def test_keras_default_initialisers():
     assert np.abs(w["initial_block_conv2d/kernel"]).max() <= lim
 
 
-def test_bucket_ranges_cover_the_arena_in_backward_order():
+def test_bucket_ranges_cover_the_arena_in_backward_order(monkeypatch):
     models = pkg("models")
     losses = pkg("losses")
     m = models.get_model("enet-naive-upsampling", (None, None, 3), 24,
                          losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY, device="cpu").model
+    # the ENets' 1.46 MB of gradients travel as one bucket by default; SSMI_DP_CUTS=1 cuts the backward pass once
+    monkeypatch.delenv("SSMI_DP_CUTS", raising=False)
+    assert m._cut_indices() == [] and m.bucket_ranges() == [(0, m.graph.store.theta.numel())]
+    monkeypatch.setenv("SSMI_DP_CUTS", "1")
     (lo1, hi1), (lo2, hi2) = m.bucket_ranges()
     n = m.graph.store.theta.numel()
     assert lo2 == 0 and hi2 == lo1 and hi1 == n and 0 < lo1 < n
@@ -179,10 +183,11 @@ def test_bucket_ranges_cover_the_arena_in_backward_order():
 
 
 @pytest.mark.parametrize("name", ["segnet", "unet", "enet-max-unpooling"])
-def test_bucket_ranges_of_every_model_tile_the_arena(name):
+def test_bucket_ranges_of_every_model_tile_the_arena(name, monkeypatch):
     """Buckets are contiguous, ordered from the end of the arena (the gradients the backward pass finishes first) to its
     start, and ~25 MB each for the wide models; every cut is the first parameter of a block."""
     models, losses = pkg("models"), pkg("losses")
+    monkeypatch.setenv("SSMI_DP_CUTS", "1")
     m = models.get_model(name, (None, None, 3), 24, losses.ModelLambdaLossType.SEGMENTATION_CATEGORICAL_CROSS_ENTROPY,
                          device="cpu").model
     rs = m.bucket_ranges()
