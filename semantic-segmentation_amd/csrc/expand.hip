@@ -83,14 +83,17 @@ template <typename T, int C4, int C, int MODE, bool WG>
 struct ExpandLds {
   static constexpr bool kBf = sizeof(T) == 2;
   static constexpr int TP = C == 128 ? 32 : 64;
-  static constexpr int W = kBf ? 0 : C4 * C;                    // a kernel matrix (bfloat16: register operands instead)
+  static constexpr int W = 0;                                   // (kernel matrices: register operands of the matrix instructions)
   static constexpr int A = (TP * (C4 + 1) + 3) & ~3;            // a narrow operand tile
   static constexpr int S = TP * (C + 4);                        // a staged accumulator tile
   static constexpr int D = (TP * (C * 2 + 16) + 3) / 4;         // a bfloat16 wide tile
   static constexpr int Wl = 0, Al = W, St = Al + A, X = St + S; // X: start of the mode's own regions
   static constexpr int Wn = X, An = Wn + W, Sn = An + A, Ot = Sn + S;                 // B1c
-  static constexpr int Wt = X, WtN = kBf ? D : C * 36, Pn = Wt + WtN;                 // B2t
-  static constexpr int total = MODE == 4 ? Ot + (WG && kBf ? D : 0) : (MODE == 5 || MODE == 6 ? Pn + 4 * 32 * 33 : X);
+  // B2t / Ft: the partial products Pn [waves along channels][TP][33] reuse the staged tile St, which is dead by then (TP * 33 *
+  // (4 / (TP / 32)) <= TP * (C + 4) for both shapes)
+  static constexpr int Wt = X, WtN = kBf ? D : 0, Pn = St;      // Wt: the bfloat16 dmain / output tile
+  static constexpr int total = MODE == 4 ? Ot + (WG && kBf ? D : 0) : (MODE == 5 || MODE == 6 ? Wt + WtN : X);
+  static_assert(4 * 32 * 33 <= S, "partial products fit the staged tile");
 };
 
 template <typename T, int C4, int C, int MODE, bool WG = false, bool NA = false>
@@ -117,15 +120,12 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
   constexpr bool kSums = MODE == 0 || kB1;
   static_assert(NY >= 1 && 256 % P4 == 0 && 256 % G == 0, "shape");
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* const Wl = sm + L::Wl;               // [C4][C] (float32 storage only)
   float* const Al = sm + L::Al;               // [TP][AS]
   float* const St = sm + L::St;               // [TP][SS], later the reduction scratch
-  float* const Wn = sm + L::Wn;               // B1c: [C4][C], the next block's reduction kernel transposed (float32 storage only)
   float* const An = sm + L::An;               // B1c: [TP][AS]
   float* const Sn = sm + L::Sn;               // B1c: [TP][SS]
-  float* const Wt = sm + L::Wt;               // B2t: W3^T [C][WTS] (float32 storage) / the bfloat16 dmain tile [TP][2 C + 16 bytes]
+  float* const Wt = sm + L::Wt;               // B2t / Ft, bfloat16: the dmain / output tile [TP][2 C + 16 bytes]
   float* const Pn = sm + L::Pn;               // B2t: [KS][TP][WTS]
-  static_assert(C * 36 >= C * WTS, "B2t regions");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const int pw = wave % PWN, cw = wave / PWN;
@@ -198,28 +198,26 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         wtf[s2] = pack_bf16x8(lo, hi);
       }
     }
-  } else {
-    for (int e = tid * 4; e < C4 * C; e += 1024) *reinterpret_cast<f32x4*>(Wl + e) = *reinterpret_cast<const f32x4*>(a.w + e);
   }
-  if constexpr (kThru && !kBf) {
-    __syncthreads();
-    for (int e = tid; e < C * 32; e += 256) {
-      const int cc = e >> 5, n = e & 31;
-      Wt[cc * WTS + n] = n < C4 ? Wl[n * C + cc] : 0.f;
-    }
-  }
-  if constexpr (kFt && !kBf) {
-    for (int e = tid; e < C * 32; e += 256) {
-      const int cc = e >> 5, n = e & 31;
-      Wt[cc * WTS + n] = n < C4 ? a.w_next[cc * C4 + n] : 0.f;
-    }
-  }
-  if constexpr (kChain && !kBf) {
-    for (int e = tid * 4; e < C4 * C; e += 1024) {      // w_next[c][k..k+3] -> Wn[k..k+3][c]
-      const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w_next + e);
-      const int cc = e / C4, k0 = e % C4;
+  // float32: the same, one word per lane and matrix instruction (lane (r, hh) holds row 2 s + hh of column r)
+  constexpr int Q1 = C4 / 2, Q3 = KW / 2;
+  float wq[!kBf ? NT : 1][!kBf ? Q1 : 1], wnq[!kBf && kChain ? NT : 1][!kBf && kChain ? Q1 : 1], wtq[!kBf && (kThru || kFt) ? Q3 : 1];
+  if constexpr (!kBf) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) Wn[(k0 + j) * C + cc] = wv[j];
+    for (int u = 0; u < NT; ++u) {
+      const int col = cw * (C / CWN) + u * 32 + r;
+#pragma unroll
+      for (int s2 = 0; s2 < Q1; ++s2) {
+        wq[u][s2] = a.w[(2 * s2 + hh) * C + col];
+        if constexpr (kChain) wnq[u][s2] = a.w_next[col * C4 + 2 * s2 + hh];      // the next block's reduction kernel, transposed
+      }
+    }
+    if constexpr (kThru || kFt) {      // B2t: W3^T, Ft: the next block's reduction kernel; this wave's share of the C rows, column r
+#pragma unroll
+      for (int s2 = 0; s2 < Q3; ++s2) {
+        const int cc = cw * KW + 2 * s2 + hh;
+        wtq[s2] = r < C4 ? (kThru ? a.w[r * C + cc] : a.w_next[cc * C4 + r]) : 0.f;
+      }
     }
   }
 
@@ -391,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
         const int k = 2 * s + hh;
         const float av = Al[(pw * 32 + r) * AS + k];
 #pragma unroll
-        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wl[k * C + cw * (C / CWN) + u * 32 + r], acc[u], 0, 0, 0);
+        for (int u = 0; u < NT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wq[u][s], acc[u], 0, 0, 0);
       }
     }
     if constexpr (kChain) {      // the data gradient of the next block's reduction, staged beside y3
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           const int k = 2 * s + hh;
           const float av = An[(pw * 32 + r) * AS + k];
 #pragma unroll
-          for (int u = 0; u < NT; ++u) accn[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, Wn[k * C + cw * (C / CWN) + u * 32 + r], accn[u], 0, 0, 0);
+          for (int u = 0; u < NT; ++u) accn[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wnq[u][s], accn[u], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -552,9 +550,10 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
 #pragma unroll
         for (int s = 0; s < KW / 2; ++s) {
           const int k = cw * KW + 2 * s + hh;
-          acd = __builtin_amdgcn_mfma_f32_32x32x2f32(St[(pw * 32 + r) * SS + k], Wt[k * WTS + r], acd, 0, 0, 0);
+          acd = __builtin_amdgcn_mfma_f32_32x32x2f32(St[(pw * 32 + r) * SS + k], wtq[s], acd, 0, 0, 0);
         }
       }
+      if constexpr (!kBf) __syncthreads();      // Pn lies over St, which the float32 product above was still reading
 #pragma unroll
       for (int i = 0; i < 16; ++i) Pn[(cw * TP + pw * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh) * WTS + r] = acd[i];
       __syncthreads();
@@ -680,6 +679,10 @@ static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a,
   if (rows) *rows = grid;
   return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {
     using T = decltype(tag);
+    if constexpr (sizeof(T) == 4 && WG && NA) {      // (float32: the three products' operands + both parameter sets exceed 256 registers)
+      set_error("expand_merge_bwd_through: wpart1_next together with next_apply is available for bfloat16 storage only");
+      return SSMI_E_UNSUPPORTED;
+    } else
     if (d->cin == 16) {
       constexpr size_t lds = (size_t)ExpandLds<T, 16, 64, MODE, WG>::total * 4;
       hipLaunchKernelGGL((expand_kernel<T, 16, 64, MODE, WG, NA>), dim3(grid), dim3(256), lds, st, a);

@@ -807,6 +807,8 @@ class Bottleneck(Block):
         # (on for bfloat16 storage only: 5.67 against 5.72 ms per ENet step; float32 7.94 against 7.87 - the chained kernel gets
         # heavier and the reduction's weight gradient can no longer start beside it.  SSMI_DEFER_APPLY=1 / 0 overrides.)
         want = os.environ.get("SSMI_DEFER_APPLY", "0" if self.store.dtype_code == F32 else "1") == "1"
+        if self.store.dtype_code == F32 and os.environ.get("SSMI_FUSED_WGRAD", "0") == "1":
+            want = False      # (float32: the chained kernel has no registers for the fused weight gradient AND the apply pass)
         self.defer_apply_ok = (want and not self.nn_resize and not last2.transpose and
                                bool(lib().conv2d_bwd_data_bn_bwd_deferred_supported(last2._dref, i)))
         self.coef1 = torch.empty(3 * i, dtype=torch.float32, device=dev)
