@@ -675,6 +675,9 @@ static int expand_weight_rows(const ssmi_expand_desc* d) { return expand_grid(d)
 
 template <int MODE, bool WG = false, bool NA = false>
 static ssmi_status launch_expand(const ssmi_expand_desc* d, const ExpandArgs& a, int* rows, hipStream_t st) {
+  // (the B1c mode alone at 256 / 384 workgroups instead of 512: 7.71 / 7.72 against 7.70 ms per float32 ENet step - at 210
+  // registers its two waves per SIMD leave the weight-gradient chain no room while it runs, and what half the waves lose the
+  // chain gains; three waves per SIMD would need 168 registers, which this mode does not reach without spilling)
   const int grid = expand_grid(d);
   if (rows) *rows = grid;
   return dispatch_dtype(d->dtype, [&](auto tag) -> ssmi_status {
