@@ -214,8 +214,9 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
     }
     if constexpr (kThru || kFt) {      // B2t: W3^T, Ft: the next block's reduction kernel; this wave's share of the C rows, column r
 #pragma unroll
+      // (the reduction index runs in the order the operand tile is read below: 16 bytes = four consecutive channels per lane)
       for (int s2 = 0; s2 < Q3; ++s2) {
-        const int cc = cw * KW + 2 * s2 + hh;
+        const int cc = cw * KW + 8 * (s2 >> 2) + 4 * hh + (s2 & 3);
         wtq[s2] = r < C4 ? (kThru ? a.w[r * C + cc] : a.w_next[cc * C4 + r]) : 0.f;
       }
     }
@@ -547,10 +548,14 @@ __global__ __launch_bounds__(256, 2) void expand_kernel(ExpandArgs a) {
           acd = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(Dtb + (pw * 32 + r) * DBS + (cw * KW + 16 * s2 + 8 * hh) * 2),
                                                         wtf[s2], acd, 0, 0, 0);
       } else {
+        // one 16-byte read feeds four matrix instructions (a column read of 4 bytes per lane hits every bank twice: the
+        // rows are a multiple of 16 bytes apart); lane half hh takes channels 4 hh .. 4 hh + 3 of each group of eight
+        static_assert(KW % 8 == 0, "shape");
 #pragma unroll
-        for (int s = 0; s < KW / 2; ++s) {
-          const int k = cw * KW + 2 * s + hh;
-          acd = __builtin_amdgcn_mfma_f32_32x32x2f32(St[(pw * 32 + r) * SS + k], wtq[s], acd, 0, 0, 0);
+        for (int g8 = 0; g8 < KW / 8; ++g8) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(St + (pw * 32 + r) * SS + cw * KW + 8 * g8 + 4 * hh);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acd = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[j], wtq[4 * g8 + j], acd, 0, 0, 0);
         }
       }
       if constexpr (!kBf) __syncthreads();      // Pn lies over St, which the float32 product above was still reading
