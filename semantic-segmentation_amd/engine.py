@@ -1493,6 +1493,8 @@ class ENetGraph(GraphBase):
     """Blocks + arenas + activation plan of `enet-naive-upsampling` / `enet-max-unpooling` /
     `enet-naive-upsampling-enhanced`."""
 
+    multiple = 8    # three 2x reductions (initial block, bottlenecks 1.0 and 2.0)
+
     def __init__(self, variant: str, num_classes: int, device="cuda", encoder_only: bool = False, act_dtype=torch.float32):
         assert variant in ("naive", "unpool", "enhanced")
         self.variant, self.num_classes, self.encoder_only = variant, num_classes, encoder_only

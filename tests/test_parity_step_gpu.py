@@ -255,6 +255,13 @@ def test_enet_naive_train_step_parity_ragged_tiles():
     _run_case("enet-naive-upsampling", 3, 48, 80, seed=11, steps=1)
 
 
+@pytest.mark.parametrize("model", ["enet-naive-upsampling", "enet-max-unpooling"])
+def test_enet_train_step_parity_odd_stage_sizes(model):
+    """40 x 72 is a multiple of 8 and not of 16: stages 2 / 3 work on 5 x 9 pixels per image (odd in both directions, 45 pixels),
+    the smallest granularity three 2x reductions allow."""
+    _run_case(model, 2, 40, 72, seed=13, steps=1)
+
+
 def test_enet_max_unpooling_train_step_parity():
     _run_case("enet-max-unpooling", 3, 64, 96, seed=5, steps=1)
 
