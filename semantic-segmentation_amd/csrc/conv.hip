@@ -802,6 +802,7 @@ struct GemmArgs {
   int pmin_y, pmin_x;            // smallest tap offset (patch origin relative to the tile origin)
   int PH, PW, CP;                // patch rows, columns, words per pixel (C_r + 4 pad)
   int patch_off;                 // word offset of the patch inside the dynamic LDS block
+  const void* wpack;             // conv_regw<bf16, ..., true>: the layer's bfloat16 kernel pack [tap][cout][cin]
 };
 static constexpr int kMaxTaps = 32;
 
@@ -1245,6 +1246,18 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   }
 }
 
+// conv_regw's pixel operand of one 16-channel block: float32 values, or (BF) the four bfloat16 as loaded
+template <typename T, bool BF> struct RegwOperand {
+  typedef f32x4 type;
+  f32x4 v;
+  static __device__ __forceinline__ f32x4 ld(__amdgpu_buffer_rsrc_t r, unsigned off4) { return Act<T>::ld4(r, off4); }
+};
+template <> struct RegwOperand<bf16, true> {
+  typedef u32x2 type;
+  u32x2 v;
+  static __device__ __forceinline__ u32x2 ld(__amdgpu_buffer_rsrc_t r, unsigned off4) { return Act<bf16>::ld4r(r, off4); }
+};
+
 // ---------------------------------------------------------------------------------------------------
 // Register-weight implicit GEMM for narrow outputs (<= 16 output channels, stride 1, short reductions: K = NTAP * CR <=
 // 144): the same GEMM as conv_gemm_lds with 16 x 16 x 4 MFMA tiles, but the wave's share of the kernel matrix -
@@ -1256,7 +1269,11 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 //   forward (mode 0): in = x, CR = cin;  data gradient (mode 1, stride 1): in = dy, CR = cout, flipped taps.
 // Epilogue as conv_gemm_lds: bias, addend, fused BatchNormalization statistics (part) or BN backward sums (bb).
 // ---------------------------------------------------------------------------------------------------
-template <typename T, int NTAP, int CR, int MT>
+// BF (bfloat16 tensors, forward form, the layer's kernel pack [tap][cout][cin] in a.wpack): one v_mfma_f32_16x16x16_bf16 per
+// tap and 16-channel block - lane (c, kq) feeds the four channels 4 * kq .. 4 * kq + 3 of its pixel exactly as its 8-byte load
+// delivered them, and the same four channels of output channel c's pack row (one 8-byte load per block, once per wave).
+// Half the operand registers of the float32 route, a quarter of its matrix cycles, no widening.
+template <typename T, int NTAP, int CR, int MT, bool BF = false>
 __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, const T* __restrict__ in,
                                                  const float* __restrict__ w, const float* __restrict__ bias,
                                                  const T* __restrict__ add, T* __restrict__ out,
@@ -1274,9 +1291,10 @@ __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, co
   // tap offsets (uniform) and the lane's kernel words: B[(t * CB + cb) * 4 + j] = Wl[t][cb * 16 + 4 * kq + j][c]
   int tdy[NTAP], tdx[NTAP];
   unsigned toff[NTAP];
-  float B[NB * 4];
+  float B[BF ? 1 : NB * 4];
+  u32x2 Bp[BF ? NB : 1];
   {
-    const __amdgpu_buffer_rsrc_t rwt = make_rsrc(w, sz.w_bytes);
+    const __amdgpu_buffer_rsrc_t rwt = BF ? make_rsrc(a.wpack, (unsigned)(NTAP * CR * a.C_o) * 2u) : make_rsrc(w, sz.w_bytes);
     const unsigned cmask = cv ? 0u : kOOB;         // kernel matrices are far below 2 GiB: OR-ing the marker in is exact
 #pragma unroll
     for (int t = 0; t < NTAP; ++t) {
@@ -1287,7 +1305,10 @@ __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, co
 #pragma unroll
       for (int cb = 0; cb < CB; ++cb) {
         const int r0 = cb * 16 + 4 * kq;
-        if (bwd) {
+        if constexpr (BF) {
+          // pack[t][co = c][ci = r0 .. r0 + 3]: four bfloat16, one 8-byte load
+          Bp[t * CB + cb] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rwt, ((unsigned)((t * a.C_o + c) * CR + r0) * 2u) | cmask, 0, 0));
+        } else if (bwd) {
           // data gradient: w[t][ci = c][co = r0 .. r0 + 3] is one 16-byte load (cout = CR is a multiple of 16)
           const f32x4 v = bload4(rwt, ((unsigned)((t * g.cin + c) * g.cout + r0) * 4u) | cmask);
 #pragma unroll
@@ -1310,7 +1331,7 @@ __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, co
   const int64_t ngroups = (M + MT * 16 - 1) / (MT * 16);
   float st1 = 0.f, st2 = 0.f, st3 = 0.f;
 
-  f32x4 An[MT][NB];                 // operands of the group fetched ahead
+  typename RegwOperand<T, BF>::type An[MT][NB];      // operands of the group fetched ahead
   auto fetch = [&](int64_t grp) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -1328,7 +1349,7 @@ __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, co
         bool ok = pv;
         if (NTAP > 1) ok = ok & ((unsigned)(qy + tdy[t]) < (unsigned)a.in_h) & ((unsigned)(qx + tdx[t]) < (unsigned)a.in_w);
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) An[m][t * CB + cb] = Act<T>::ld4(rin, ok ? pbase + toff[t] + (unsigned)(cb * 64) : kOOB);
+        for (int cb = 0; cb < CB; ++cb) An[m][t * CB + cb] = RegwOperand<T, BF>::ld(rin, ok ? pbase + toff[t] + (unsigned)(cb * 64) : kOOB);
       }
     }
   };
@@ -1337,22 +1358,31 @@ __global__ __launch_bounds__(256) void conv_regw(Geo g, Sizes sz, GemmArgs a, co
   const int64_t gstep = (int64_t)gridDim.x * 4;
   fetch(grp);
   for (; grp < ngroups; grp += gstep) {
-    f32x4 A[MT][NB];
+    RegwOperand<T, BF> A[MT][NB];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) A[m][b] = An[m][b];
+      for (int b = 0; b < NB; ++b) A[m][b].v = An[m][b];
     fetch(grp + gstep);             // past the end every lane reads zeros
     typedef float accv __attribute__((ext_vector_type(4)));
     accv acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) acc[m] = accv{0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+      typedef short s16x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int m = 0; m < MT; ++m)
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, A[m][b].v), __builtin_bit_cast(s16x4, Bp[b]), acc[m], 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][b][j], B[b * 4 + j], acc[m], 0, 0, 0);
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m][b].v[j], B[b * 4 + j], acc[m], 0, 0, 0);
+    }
 
     // ---- epilogue: accumulator element i of tile m is output pixel tile0 + m * 16 + 4 * kq + i, column c ----
     const unsigned tile0 = (unsigned)(grp * (MT * 16));
@@ -2296,13 +2326,23 @@ __global__ __launch_bounds__(256) void conv_pack_bf16_batch_kernel(const RotEntr
 // Which passes of a bfloat16 layer run on the bfloat16 matrix instructions when the packs are there.  Forward: input
 // channels in whole 16-blocks (16-byte operand loads) and more than 16 output channels (narrower outputs stay on the
 // 16-wide register / LDS kernels).  Data gradient: stride 1, same-size output, the mirror conditions.
+// Narrow outputs (<= 16 channels) whose reduction conv_regw keeps in registers: 1x1 over 16 / 64 / 128 channels, 3x3 over 16
+// (forward geometry; SSMI_NO_BF16_REGW=1 keeps them on the float32 matrix instructions).
+static bool regw_pack_ok(int kh, int kw, int stride, int c_r, int c_o, int in_ld) {
+  static const bool off = getenv("SSMI_NO_BF16_REGW") != nullptr;
+  const int ntaps = kh * kw;
+  return !off && c_o <= 16 && stride == 1 && in_ld % 8 == 0 &&
+         ((ntaps == 1 && (c_r == 16 || c_r == 64 || c_r == 128)) || (kh == 3 && kw == 3 && c_r == 16));
+}
 static bool fwd_pack_ok(const Geo& g) {
   static const bool off = getenv("SSMI_NO_BF16_MFMA") != nullptr;
-  return !off && g.cin % 16 == 0 && g.x_ld % 8 == 0 && g.cout > 16;      // cin % 16 == 0 implies the VEC instantiation
+  // cin % 16 == 0 implies the VEC instantiation
+  return !off && g.cin % 16 == 0 && g.x_ld % 8 == 0 && (g.cout > 16 || regw_pack_ok(g.kh, g.kw, g.stride, g.cin, g.cout, g.x_ld));
 }
 static bool dgrad_pack_ok(const Geo& g) {
   static const bool off = getenv("SSMI_NO_BF16_MFMA") != nullptr;
-  return !off && g.stride == 1 && g.ho == g.h && g.wo == g.w && g.cout % 16 == 0 && g.y_ld % 8 == 0 && g.cin > 16;
+  return !off && g.stride == 1 && g.ho == g.h && g.wo == g.w && g.cout % 16 == 0 && g.y_ld % 8 == 0 &&
+         (g.cin > 16 || regw_pack_ok(g.kh, g.kw, g.stride, g.cout, g.cin, g.y_ld));
 }
 
 static ssmi_status check_desc(const ssmi_conv_desc* d) {
@@ -2365,9 +2405,10 @@ static int conv_kernel_override() {
 template <typename T>
 static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in, const float* w, const float* bias,
                             const T* add, T* out, hipStream_t st, ssmi_status* status, float* part = nullptr,
-                            int* part_rows = nullptr, BnBwdArgs bb = BnBwdArgs{}) {
+                            int* part_rows = nullptr, BnBwdArgs bb = BnBwdArgs{}, const void* wpack = nullptr) {
   GemmArgs a;
   a.mode = mode;
+  a.wpack = wpack;
   a.C_r = mode == 0 ? g.cin : g.cout;
   a.C_o = mode == 0 ? g.cout : g.cin;
   a.in_h = mode == 0 ? g.h : g.ho;
@@ -2399,7 +2440,7 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
   static const bool no_regw = getenv("SSMI_NO_REGW") != nullptr;
   if (!no_regw && force == 0 && m16 && vec && s == 1 &&
       ((ntaps == 1 && (a.C_r == 16 || a.C_r == 64 || a.C_r == 128)) || (ntaps == 9 && g.kh == 3 && a.C_r == 16)) &&
-      (mode == 0 || (g.ho == g.h && g.wo == g.w)) && !(mode == 0 && bb.mean != nullptr)) {
+      (mode == 0 || (g.ho == g.h && g.wo == g.w)) && !(mode == 0 && bb.mean != nullptr && bb.x == nullptr)) {
     const int64_t M = (int64_t)g.n * qh * qw;
     // Measured on MI355X (batch 16, 128x128): 3x3 16->16 forward 28.3 -> 23.3 us and data gradient 28.4 -> 22.9 us with two
     // tiles per wave and 512 workgroups (four groups per wave, no remainder); 1x1 64->16 19.0 -> 16.7 us and the data
@@ -2413,8 +2454,19 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
     int64_t bx = ceil_div64(ngroups, 4);
     if (bx > regw_wgs) bx = regw_wgs;
     if (part_rows) *part_rows = (int)bx;
-    set_last_kernel("conv_regw<%d, %d, %d>", ntaps, a.C_r, mt_);
-#define LR(NTAP_, CR_, MT_) hipLaunchKernelGGL((conv_regw<T, NTAP_, CR_, MT_>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb)
+    bool bf = false;
+    if constexpr (sizeof(T) == 2) bf = wpack != nullptr && mode == 0 && (a.in_ld % 4) == 0;
+    set_last_kernel(bf ? "conv_regw<%d, %d, %d> bf16 mfma" : "conv_regw<%d, %d, %d>", ntaps, a.C_r, mt_);
+#define LR(NTAP_, CR_, MT_)                                                                                                          \
+    do {                                                                                                                             \
+      if constexpr (sizeof(T) == 2) {                                                                                                \
+        if (bf) {                                                                                                                    \
+          hipLaunchKernelGGL((conv_regw<T, NTAP_, CR_, MT_, true>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb); \
+          break;                                                                                                                     \
+        }                                                                                                                            \
+      }                                                                                                                              \
+      hipLaunchKernelGGL((conv_regw<T, NTAP_, CR_, MT_>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb); \
+    } while (0)
     if (ntaps == 1 && a.C_r == 64) { if (mt_ == 1) LR(1, 64, 1); else if (mt_ == 2) LR(1, 64, 2); else LR(1, 64, 4); }
     else if (ntaps == 1 && a.C_r == 16) { if (mt_ == 1) LR(1, 16, 1); else LR(1, 16, 2); }
     else if (ntaps == 1) { if (mt_ == 1) LR(1, 128, 1); else LR(1, 128, 2); }
@@ -2429,6 +2481,8 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
     }
     return true;
   }
+
+  if (wpack) return false;      // the caller's `w` need not be this geometry's kernel: only the pack is
 
   // Tile variant (opt-in, SSMI_CONV_KERNEL=tile): multi-tap stride-1 convolutions into <= 32 channels read every input
   // pixel once per tap; staging the 8 x 32 tile's halo patch in LDS makes that one pass over global memory and removes
@@ -2542,6 +2596,14 @@ static ssmi_status launch_fwd(const Geo& g, const T* x, const float* w, const fl
   }
   const bool pre = bn.pre[0] != nullptr;
   if (pre) direct_only = true;
+  if constexpr (sizeof(T) == 2) {
+    if (bn.wpack && g.cout <= 16) {      // narrow output: the register-weight kernel on the bfloat16 matrix instructions
+      if (!pre && bn.pm_main == nullptr && !(bn.mean != nullptr && bn.x == nullptr) &&
+          launch_gemm_lds<T>(g, sz, 0, x, w, bias, static_cast<const T*>(bn.add), y, st, &e, part, part_rows, bn, bn.wpack))
+        return e;
+      // else (an override or an epilogue that kernel does not have): the direct kernel below, from the same pack
+    }
+  }
   if constexpr (sizeof(T) == 2) {
     if (bn.wpack && !pre && bn.pm_main == nullptr &&
         conv_tiled_bf16_ok(g.h, g.w, g.cin, g.cout, g.kh, g.kw, g.stride, g.dil, g.pad_t, g.pad_l, g.ho, g.wo, g.x_ld, g.y_ld)) {

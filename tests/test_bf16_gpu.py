@@ -283,6 +283,10 @@ PACKED_CASES = [  # kh, kw, cin, cout, stride, dil, padding, N, H, W
     # wide layers: the kernel rows of a workgroup's 128 output channels staged through LDS (ragged pixel and channel tails)
     (3, 3, 64, 128, 1, 1, "same", 1, 12, 12), (3, 3, 128, 128, 1, 1, "same", 2, 9, 11), (3, 3, 64, 160, 1, 2, "same", 1, 10, 13),
     (1, 1, 256, 256, 1, 1, "valid", 1, 7, 9),
+    # narrow outputs: the register-weight kernel on v_mfma_f32_16x16x16_bf16 (forward of the first four, data gradient of all
+    # but the fourth; ragged pixel groups)
+    (3, 3, 16, 16, 1, 1, "same", 2, 11, 13), (1, 1, 64, 16, 1, 1, "valid", 2, 9, 7), (1, 1, 128, 16, 1, 1, "valid", 1, 10, 10),
+    (1, 1, 64, 4, 1, 1, "valid", 1, 12, 9), (1, 1, 16, 64, 1, 1, "valid", 3, 5, 7), (1, 1, 16, 16, 1, 1, "valid", 1, 6, 11),
 ]
 
 
