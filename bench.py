@@ -374,8 +374,9 @@ def measure_roofline(model, stream, model_name, steps=3):
             # trace names: storage type first, then the record's arguments, then (newer builds) the normalise-on-load flag;
             # kernels that exist for one storage type only carry no type and are recorded under the trace's own name
             for k, v in raw.items():
-                m = re.match(r"^(\w+)<(float|__bf16|bf16), (.*?)(, false|, 0)?>$", k)
-                if k == base or (m and (m.group(2) != "float") == want_bf16 and "{}<{}>".format(m.group(1), m.group(3)) == base):
+                m = re.match(r"^(\w+)<(float|__bf16|bf16), (.*?)(, false|, true|, 0)?>$", k)
+                if k == base or (m and (m.group(2) != "float") == want_bf16 and
+                                 base in ("{}<{}>".format(m.group(1), m.group(3)), "{}<{}{}>".format(m.group(1), m.group(3), m.group(4) or ""))):
                     traffic = v.get("hbm_bytes_per_launch")
                     traffic_source = "profiles/" + fname
     common = {"kernel": "ssmi::" + kernel, "launches_per_step": n // steps, "avg_launch_us": round(ms / n * 1e3, 2),
