@@ -91,7 +91,9 @@ typedef struct ssmi_conv_desc {
    *   w_fwd_pack[tap][co][ci] and w_dgrad_pack[kh*kw-1-tap][ci][co] = bf16(w[tap][ci][co]).
    * With them the forward convolution / the stride-1 data gradient of layers with cin (resp. cout) a multiple of 16 and more
    * than 16 output (resp. input) channels run on the bfloat16 matrix instructions (v_mfma_f32_32x32x16_bf16): products of
-   * bfloat16 activations and bfloat16-ROUNDED weights, float32 accumulation.  The packs must be rewritten whenever w changes. */
+   * bfloat16 activations and bfloat16-ROUNDED weights, float32 accumulation.  So do the stride-1 layers with at most 16 output
+   * (resp. input) channels whose reduction is 1x1 over 16 / 64 / 128 or 3x3 over 16 channels (v_mfma_f32_16x16x16_bf16).
+   * ssmi_conv2d_pack_usage() tells which packs a layer would use.  The packs must be rewritten whenever w changes. */
   const void* w_fwd_pack;
   const void* w_dgrad_pack;
 } ssmi_conv_desc;
