@@ -1246,6 +1246,139 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Four reduction channels per tap (the last decoder stage of the ENets: 3x3 4->4, its stride-2 transposed form, 1x1 4->16 and
+// the data gradient of 1x1 16->4).  Padded to 16-wide matrix tiles these layers ran at a tenth of what their bytes allow
+// (3x3 4->4 at 256x256, batch 16: 54 us for 34 MB); here they are plain vector arithmetic: a thread owns four output channels
+// of one output pixel (OG threads per pixel), gathers one 4-channel operand per tap with a single load and multiplies it by
+// the tap's 4 x 4 block of kernel words, which every lane reads from the same LDS address.
+//   forward (mode 0): any stride / dilation;  data gradient (mode 1): any stride - the taps a pixel's parity excludes are
+//   masked per lane, so the stride-2 transposed convolution is one launch over the whole output.
+// Epilogues as conv_gemm_lds: bias, addend, BatchNormalization statistics rows (part) or BN-backward sums (bb.x), one row
+// per workgroup.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kC4MaxTaps = 9;
+template <typename T, int OG>
+__global__ __launch_bounds__(256) void conv_c4_kernel(Geo g, Sizes sz, GemmArgs a, const T* __restrict__ in,
+                                                      const float* __restrict__ w, const float* __restrict__ bias,
+                                                      const T* __restrict__ add, T* __restrict__ out,
+                                                      float* __restrict__ part, BnBwdArgs bb) {
+  constexpr int CO = 4 * OG;
+  __shared__ __attribute__((aligned(16))) float wl[kC4MaxTaps * 4 * CO];      // [tap][reduction channel][output channel]
+  __shared__ float red[4 * 3 * CO];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool bwd = a.mode == 1;
+  const int ntaps = g.kh * g.kw;
+  for (int e = tid; e < ntaps * 4 * CO; e += 256) {
+    const int t = e / (4 * CO), rem = e - t * (4 * CO), r = rem / CO, o = rem - r * CO;
+    wl[e] = bwd ? w[(t * g.cin + o) * g.cout + r] : w[(t * g.cin + r) * g.cout + o];
+  }
+  __syncthreads();
+  const int oh = bwd ? g.h : g.ho, ow = bwd ? g.w : g.wo;      // output grid
+  const unsigned total = (unsigned)((int64_t)g.n * oh * ow) * (unsigned)OG;
+  const __amdgpu_buffer_rsrc_t rin = Act<T>::rsrc(in, bwd ? sz.y_bytes : sz.x_bytes);
+  const int og = tid & (OG - 1);            // constant per thread: the loop stride is a multiple of OG
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias) bv = f32x4{bias[4 * og], bias[4 * og + 1], bias[4 * og + 2], bias[4 * og + 3]};
+  f32x4 mu = bv, is = bv, ga = bv, be = bv, al = bv;
+  if (bb.x) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = 4 * og + j;
+      mu[j] = bb.mean[cc]; is[j] = bb.invstd[cc]; ga[j] = bb.gamma[cc]; be[j] = bb.beta[cc];
+      al[j] = bb.act == SSMI_ACT_PRELU ? bb.alpha[cc] : bb.slope;
+    }
+  }
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+  for (unsigned wi = blockIdx.x * 256u + (unsigned)tid; wi < total; wi += gridDim.x * 256u) {
+    const unsigned p = wi / (unsigned)OG;
+    const unsigned t1 = p / (unsigned)ow;
+    const int ox = (int)(p - t1 * (unsigned)ow);
+    const unsigned n_ = t1 / (unsigned)oh;
+    const int oy = (int)(t1 - n_ * (unsigned)oh);
+    const unsigned img = n_ * (unsigned)(a.in_h * a.in_w);
+    f32x4 acc = bv;
+    for (int t = 0; t < ntaps; ++t) {
+      const int ky = t / g.kw, kx = t - ky * g.kw;
+      int iy, ix;
+      bool ok;
+      if (!bwd) {
+        iy = oy * g.stride + ky * g.dil - g.pad_t;
+        ix = ox * g.stride + kx * g.dil - g.pad_l;
+        ok = true;
+      } else {
+        const int ty = oy + g.pad_t - ky * g.dil, tx = ox + g.pad_l - kx * g.dil;
+        iy = ty / g.stride; ix = tx / g.stride;
+        ok = ty >= 0 && tx >= 0 && iy * g.stride == ty && ix * g.stride == tx;
+      }
+      ok = ok && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
+      const f32x4 v = Act<T>::ld4(rin, ok ? (img + (unsigned)(iy * a.in_w + ix)) * (unsigned)a.in_ld * 4u : kOOB);
+      const float* wt = wl + t * (4 * CO) + 4 * og;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + r * CO);
+        const f32x4 sv = {v[r], v[r], v[r], v[r]};
+        acc = __builtin_elementwise_fma(sv, wv, acc);
+      }
+    }
+    const int64_t oo = (int64_t)p * a.out_ld + 4 * og;
+    f32x4 res = acc;
+    if (add) {
+      const f32x4 av = Act<T>::gld4(add + oo);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) res[j] = acc[j] + av[j];
+    }
+    Act<T>::gst4(out + oo, res);
+    if (part) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { s1[j] += acc[j]; s2[j] += acc[j] * acc[j]; }
+    }
+    if (bb.x) {
+      const f32x4 xr = Act<T>::gld4(reinterpret_cast<const T*>(bb.x) + (int64_t)p * bb.ld + 4 * og);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float d = res[j];
+        if (bb.drop) d *= bb.drop[(p / bb.hw) * (unsigned)CO + (unsigned)(4 * og + j)];
+        const float xh = (xr[j] - mu[j]) * is[j];
+        const float z = ga[j] * xh + be[j];
+        const float gr = bb.act == SSMI_ACT_NONE ? 1.f : (z > 0.f ? 1.f : (z < 0.f ? al[j] : 0.f));
+        const float dz = d * gr;
+        s1[j] += dz;
+        s2[j] += dz * xh;
+        s3[j] += d * (z < 0.f ? z : 0.f);
+      }
+    }
+  }
+  if (part || bb.x) {      // uniform: the lanes that share an output-channel group, then the four waves through LDS
+    const int ns = bb.x ? 3 : 2;
+    float* dst = bb.x ? bb.part : part;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v1 = s1[j], v2 = s2[j], v3 = s3[j];
+#pragma unroll
+      for (int o = OG; o < 64; o <<= 1) {
+        v1 += __shfl_xor(v1, o, 64);
+        v2 += __shfl_xor(v2, o, 64);
+        v3 += __shfl_xor(v3, o, 64);
+      }
+      if (lane < OG) {
+        red[(wave * 3 + 0) * CO + 4 * og + j] = v1;
+        red[(wave * 3 + 1) * CO + 4 * og + j] = v2;
+        red[(wave * 3 + 2) * CO + 4 * og + j] = v3;
+      }
+    }
+    __syncthreads();
+    if (tid < CO) {
+      for (int k = 0; k < ns; ++k) {
+        float sk = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) sk += red[(wv * 3 + k) * CO + tid];
+        dst[((int64_t)blockIdx.x * ns + k) * CO + tid] = sk;
+      }
+    }
+  }
+}
+
 // conv_regw's pixel operand of one 16-channel block: float32 values, or (BF) the four bfloat16 as loaded
 template <typename T, bool BF> struct RegwOperand {
   typedef f32x4 type;
@@ -2434,6 +2567,30 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
   size_t lds = (size_t)(4 + 5 * kMaxTaps + (size_t)staged_taps * a.C_r * a.WS) * 4;
   if (lds > 64 * 1024) return false;
   if ((part || bb.x) && lds < (size_t)12 * nt * ts * 4) lds = (size_t)12 * nt * ts * 4;   // room for the column-sum combine
+
+  // Four reduction channels: the vector-arithmetic kernel (SSMI_NO_C4=1 keeps the 16-wide matrix tiles)
+  static const bool no_c4 = getenv("SSMI_NO_C4") != nullptr;
+  if (!no_c4 && force == 0 && !wpack && a.C_r == 4 && (a.C_o == 4 || a.C_o == 16) && vec && ntaps <= kC4MaxTaps &&
+      !(mode == 0 && bb.mean != nullptr && bb.x == nullptr) && a.out_ld % 4 == 0 && (!bb.x || bb.ld % 4 == 0) &&
+      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(bb.x)) & 15) == 0) {
+    const int64_t M = (int64_t)g.n * (mode == 0 ? (int64_t)g.ho * g.wo : (int64_t)g.h * g.w);
+    if (M * (a.C_o / 4) < 0x7FFFFFFFLL) {
+      int64_t bx = ceil_div64(M * (a.C_o / 4), 256);
+      if (bx > 1024) bx = 1024;
+      if (part_rows) *part_rows = (int)bx;
+      set_last_kernel("conv_c4_kernel<%d>", a.C_o / 4);
+      if (a.C_o == 4) hipLaunchKernelGGL((conv_c4_kernel<T, 1>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
+      else hipLaunchKernelGGL((conv_c4_kernel<T, 4>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) {
+        set_error("conv_c4_kernel launch: %s", hipGetErrorString(e));
+        *status = SSMI_E_HIP;
+      } else {
+        *status = SSMI_OK;
+      }
+      return true;
+    }
+  }
 
   // Register-weight kernel: narrow outputs, stride 1, the two reductions that dominate the 16-channel stages of ENet
   // (1x1 over 64 channels, 3x3 over 16 channels).  SSMI_NO_REGW=1 keeps the LDS kernel (A/B measurements).
