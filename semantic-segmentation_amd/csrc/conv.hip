@@ -1257,20 +1257,23 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 // Epilogues as conv_gemm_lds: bias, addend, BatchNormalization statistics rows (part) or BN-backward sums (bb.x), one row
 // per workgroup.
 // ---------------------------------------------------------------------------------------------------
+// RB = 4 (single tap only): sixteen reduction channels into four outputs - 1x1 16->4 and the data gradient of 1x1 4->16,
+// four operand loads per pixel; on 16-wide matrix tiles a wave walked sixteen 16-pixel groups one memory round trip at a time.
 constexpr int kC4MaxTaps = 9;
-template <typename T, int OG>
+template <typename T, int OG, int RB = 1>
 __global__ __launch_bounds__(256) void conv_c4_kernel(Geo g, Sizes sz, GemmArgs a, const T* __restrict__ in,
                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                       const T* __restrict__ add, T* __restrict__ out,
                                                       float* __restrict__ part, BnBwdArgs bb) {
-  constexpr int CO = 4 * OG;
-  __shared__ __attribute__((aligned(16))) float wl[kC4MaxTaps * 4 * CO];      // [tap][reduction channel][output channel]
+  constexpr int CO = 4 * OG, CR = 4 * RB;
+  static_assert(RB == 1 || OG == 1, "shape");
+  __shared__ __attribute__((aligned(16))) float wl[(RB == 1 ? kC4MaxTaps : 1) * CR * CO];      // [tap][reduction channel][output channel]
   __shared__ float red[4 * 3 * CO];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool bwd = a.mode == 1;
   const int ntaps = g.kh * g.kw;
-  for (int e = tid; e < ntaps * 4 * CO; e += 256) {
-    const int t = e / (4 * CO), rem = e - t * (4 * CO), r = rem / CO, o = rem - r * CO;
+  for (int e = tid; e < ntaps * CR * CO; e += 256) {
+    const int t = e / (CR * CO), rem = e - t * (CR * CO), r = rem / CO, o = rem - r * CO;
     wl[e] = bwd ? w[(t * g.cin + o) * g.cout + r] : w[(t * g.cin + r) * g.cout + o];
   }
   __syncthreads();
@@ -1312,14 +1315,19 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(Geo g, Sizes sz, GemmArgs 
         ok = ty >= 0 && tx >= 0 && iy * g.stride == ty && ix * g.stride == tx;
       }
       ok = ok && (unsigned)iy < (unsigned)a.in_h && (unsigned)ix < (unsigned)a.in_w;
-      const f32x4 v = Act<T>::ld4(rin, ok ? (img + (unsigned)(iy * a.in_w + ix)) * (unsigned)a.in_ld * 4u : kOOB);
-      const float* wt = wl + t * (4 * CO) + 4 * og;
+      const unsigned off = ok ? (img + (unsigned)(iy * a.in_w + ix)) * (unsigned)a.in_ld * 4u : kOOB;
+      f32x4 v[RB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + r * CO);
-        const f32x4 sv = {v[r], v[r], v[r], v[r]};
-        acc = __builtin_elementwise_fma(sv, wv, acc);
-      }
+      for (int rb = 0; rb < RB; ++rb) v[rb] = Act<T>::ld4(rin, off == kOOB ? kOOB : off + 16u * rb);
+      const float* wt = wl + t * (CR * CO) + 4 * og;
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + (4 * rb + r) * CO);
+          const f32x4 sv = {v[rb][r], v[rb][r], v[rb][r], v[rb][r]};
+          acc = __builtin_elementwise_fma(sv, wv, acc);
+        }
     }
     const int64_t oo = (int64_t)p * a.out_ld + 4 * og;
     f32x4 res = acc;
@@ -2464,6 +2472,8 @@ __global__ __launch_bounds__(256) void conv_pack_bf16_batch_kernel(const RotEntr
 static bool regw_pack_ok(int kh, int kw, int stride, int c_r, int c_o, int in_ld) {
   static const bool off = getenv("SSMI_NO_BF16_REGW") != nullptr;
   const int ntaps = kh * kw;
+  static const bool no_c4 = getenv("SSMI_NO_C4") != nullptr;
+  if (!no_c4 && ntaps == 1 && c_r == 16 && c_o == 4) return false;      // conv_c4_kernel's shape: no pack
   return !off && c_o <= 16 && stride == 1 && in_ld % 8 == 0 &&
          ((ntaps == 1 && (c_r == 16 || c_r == 64 || c_r == 128)) || (kh == 3 && kw == 3 && c_r == 16));
 }
@@ -2570,7 +2580,8 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
 
   // Four reduction channels: the vector-arithmetic kernel (SSMI_NO_C4=1 keeps the 16-wide matrix tiles)
   static const bool no_c4 = getenv("SSMI_NO_C4") != nullptr;
-  if (!no_c4 && force == 0 && !wpack && a.C_r == 4 && (a.C_o == 4 || a.C_o == 16) && vec && ntaps <= kC4MaxTaps &&
+  const bool c4_wide = a.C_r == 16 && a.C_o == 4 && ntaps == 1;      // sixteen reduction channels, single tap
+  if (!no_c4 && force == 0 && !wpack && ((a.C_r == 4 && (a.C_o == 4 || a.C_o == 16)) || c4_wide) && vec && ntaps <= kC4MaxTaps &&
       !(mode == 0 && bb.mean != nullptr && bb.x == nullptr) && a.out_ld % 4 == 0 && (!bb.x || bb.ld % 4 == 0) &&
       ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(bb.x)) & 15) == 0) {
     const int64_t M = (int64_t)g.n * (mode == 0 ? (int64_t)g.ho * g.wo : (int64_t)g.h * g.w);
@@ -2578,8 +2589,9 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
       int64_t bx = ceil_div64(M * (a.C_o / 4), 256);
       if (bx > 1024) bx = 1024;
       if (part_rows) *part_rows = (int)bx;
-      set_last_kernel("conv_c4_kernel<%d>", a.C_o / 4);
-      if (a.C_o == 4) hipLaunchKernelGGL((conv_c4_kernel<T, 1>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
+      set_last_kernel("conv_c4_kernel<%d, %d>", a.C_o / 4, a.C_r / 4);
+      if (c4_wide) hipLaunchKernelGGL((conv_c4_kernel<T, 1, 4>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
+      else if (a.C_o == 4) hipLaunchKernelGGL((conv_c4_kernel<T, 1>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
       else hipLaunchKernelGGL((conv_c4_kernel<T, 4>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess) {
