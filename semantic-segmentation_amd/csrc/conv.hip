@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(256) void conv_gemm_lds(Geo g, Sizes sz, GemmArgs a
 //   forward (mode 0): any stride / dilation;  data gradient (mode 1): any stride - the taps a pixel's parity excludes are
 //   masked per lane, so the stride-2 transposed convolution is one launch over the whole output.
 // Epilogues as conv_gemm_lds: bias, addend, BatchNormalization statistics rows (part) or BN-backward sums (bb.x), one row
-// per workgroup.
+// per workgroup; inference phase: BatchNormalization with fixed statistics + activation (+ skip tensor) in front of the store.
 // ---------------------------------------------------------------------------------------------------
 // RB = 4 (single tap only): sixteen reduction channels into four outputs - 1x1 16->4 and the data gradient of 1x1 4->16,
 // four operand loads per pixel; on 16-wide matrix tiles a wave walked sixteen 16-pixel groups one memory round trip at a time.
@@ -1284,7 +1284,8 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(Geo g, Sizes sz, GemmArgs 
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (bias) bv = f32x4{bias[4 * og], bias[4 * og + 1], bias[4 * og + 2], bias[4 * og + 3]};
   f32x4 mu = bv, is = bv, ga = bv, be = bv, al = bv;
-  if (bb.x) {
+  const bool infer = !bwd && bb.mean != nullptr && bb.x == nullptr;      // inference phase: BatchNormalization + activation (+ skip) in front of the store
+  if (bb.x || infer) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int cc = 4 * og + j;
@@ -1331,7 +1332,16 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(Geo g, Sizes sz, GemmArgs 
     }
     const int64_t oo = (int64_t)p * a.out_ld + 4 * og;
     f32x4 res = acc;
-    if (add) {
+    if (infer) {      // uniform
+      f32x4 sk = {0.f, 0.f, 0.f, 0.f};
+      if (bb.skip) sk = Act<T>::gld4(reinterpret_cast<const T*>(bb.skip) + (int64_t)p * bb.skip_ld + 4 * og);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float z = ga[j] * ((acc[j] - mu[j]) * is[j]) + be[j];
+        if (bb.skip) z += sk[j];
+        res[j] = (bb.act == SSMI_ACT_NONE || z > 0.f) ? z : al[j] * z;
+      }
+    } else if (add) {
       const f32x4 av = Act<T>::gld4(add + oo);
 #pragma unroll
       for (int j = 0; j < 4; ++j) res[j] = acc[j] + av[j];
@@ -2582,8 +2592,9 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
   static const bool no_c4 = getenv("SSMI_NO_C4") != nullptr;
   const bool c4_wide = a.C_r == 16 && a.C_o == 4 && ntaps == 1;      // sixteen reduction channels, single tap
   if (!no_c4 && force == 0 && !wpack && ((a.C_r == 4 && (a.C_o == 4 || a.C_o == 16)) || c4_wide) && vec && ntaps <= kC4MaxTaps &&
-      !(mode == 0 && bb.mean != nullptr && bb.x == nullptr) && a.out_ld % 4 == 0 && (!bb.x || bb.ld % 4 == 0) &&
-      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(bb.x)) & 15) == 0) {
+      a.out_ld % 4 == 0 && (!bb.x || bb.ld % 4 == 0) && (!bb.skip || bb.skip_ld % 4 == 0) &&
+      ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(add) | reinterpret_cast<uintptr_t>(bb.x) |
+        reinterpret_cast<uintptr_t>(bb.skip)) & 15) == 0) {
     const int64_t M = (int64_t)g.n * (mode == 0 ? (int64_t)g.ho * g.wo : (int64_t)g.h * g.w);
     if (M * (a.C_o / 4) < 0x7FFFFFFFLL) {
       int64_t bx = ceil_div64(M * (a.C_o / 4), 256);
