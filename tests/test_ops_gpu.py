@@ -46,6 +46,8 @@ CONV_CASES = [
     (3, 3, 4, 4, 1, 1, "same", True, 2, 8, 8),
     (1, 1, 4, 16, 1, 1, "valid", False, 1, 8, 8),
     (1, 1, 64, 4, 1, 1, "valid", False, 1, 8, 8),
+    (1, 1, 16, 4, 1, 1, "valid", False, 2, 9, 7),      # vector-arithmetic kernel, four operand loads per pixel
+    (3, 3, 4, 4, 1, 1, "same", True, 2, 384, 352),     # the same kernel past its grid cap: several pixels per thread
     (3, 3, 5, 7, 2, 1, "same", True, 1, 7, 9),         # odd everything
     (3, 3, 24, 24, 1, 1, "same", True, 1, 8, 8),       # enhanced head width
     (3, 3, 64, 64, 1, 1, "same", True, 2, 9, 11),      # wide layers: tiled weight gradient (256 x 64 tiles), ragged pixels
