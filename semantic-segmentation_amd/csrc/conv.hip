@@ -2597,8 +2597,11 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
         reinterpret_cast<uintptr_t>(bb.skip)) & 15) == 0) {
     const int64_t M = (int64_t)g.n * (mode == 0 ? (int64_t)g.ho * g.wo : (int64_t)g.h * g.w);
     if (M * (a.C_o / 4) < 0x7FFFFFFFLL) {
+      // (the statistics workspaces hold ceil(M / 128) + 1024 rows)
+      static const int c4_wgs = getenv("SSMI_C4_WGS") ? atoi(getenv("SSMI_C4_WGS")) : 1024;
       int64_t bx = ceil_div64(M * (a.C_o / 4), 256);
-      if (bx > 1024) bx = 1024;
+      const int64_t cap = std::min<int64_t>(c4_wgs > 0 ? c4_wgs : 1024, ceil_div64(M, 128) + 1024);
+      if (bx > cap) bx = cap;
       if (part_rows) *part_rows = (int)bx;
       set_last_kernel("conv_c4_kernel<%d, %d>", a.C_o / 4, a.C_r / 4);
       if (c4_wide) hipLaunchKernelGGL((conv_c4_kernel<T, 1, 4>), dim3((unsigned)bx), dim3(256), 0, st, g, sz, a, in, w, bias, add, out, part, bb);
