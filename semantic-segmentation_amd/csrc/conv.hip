@@ -1397,6 +1397,64 @@ __global__ __launch_bounds__(256) void conv_c4_kernel(Geo g, Sizes sz, GemmArgs 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Three input channels into at most sixteen outputs (the ENets' first layer: 3x3 / stride 2, 3 -> 13, written into the first
+// 13 channels of the 16-channel concatenation buffer): a thread owns one output pixel, reads the 27 input values with scalar
+// loads (RGB pixels are 12 / 6 bytes: nothing wider is aligned) and multiplies each by its 16 zero-padded kernel words, which
+// all lanes read from one LDS address.  Forward with bias only (the layer has no fused epilogue in either phase).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv_c3_kernel(Geo g, Sizes sz, const T* __restrict__ in, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, T* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float wl[kC4MaxTaps * 3 * 16 + 16];      // [tap][ci][16], then the bias row
+  const int tid = threadIdx.x;
+  const int ntaps = g.kh * g.kw;
+  for (int e = tid; e < ntaps * 3 * 16 + 16; e += 256) {
+    const int row = e >> 4, o = e & 15;
+    float v = 0.f;
+    if (o < g.cout) v = row < ntaps * 3 ? w[row * g.cout + o] : (bias ? bias[o] : 0.f);
+    wl[e] = v;
+  }
+  __syncthreads();
+  const unsigned M = (unsigned)((int64_t)g.n * g.ho * g.wo);
+  const unsigned p = blockIdx.x * 256u + (unsigned)tid;
+  if (p >= M) return;
+  const unsigned t1 = p / (unsigned)g.wo;
+  const int ox = (int)(p - t1 * (unsigned)g.wo);
+  const unsigned n_ = t1 / (unsigned)g.ho;
+  const int oy = (int)(t1 - n_ * (unsigned)g.ho);
+  const __amdgpu_buffer_rsrc_t rin = Act<T>::rsrc(in, sz.x_bytes);
+  f32x4 acc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc[q] = *reinterpret_cast<const f32x4*>(wl + ntaps * 48 + 4 * q);
+  for (int t = 0; t < ntaps; ++t) {
+    const int ky = t / g.kw, kx = t - ky * g.kw;
+    const int iy = oy * g.stride + ky * g.dil - g.pad_t, ix = ox * g.stride + kx * g.dil - g.pad_l;
+    const bool ok = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;
+    const unsigned off = (n_ * (unsigned)(g.h * g.w) + (unsigned)(iy * g.w + ix)) * (unsigned)g.x_ld * 4u;
+    float v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = Act<T>::ld(rin, ok ? off + 4u * c : kOOB);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const f32x4 sv = {v[c], v[c], v[c], v[c]};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] = __builtin_elementwise_fma(sv, *reinterpret_cast<const f32x4*>(wl + (t * 3 + c) * 16 + 4 * q), acc[q]);
+    }
+  }
+  T* op = out + (int64_t)p * g.y_ld;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (4 * q + 4 <= g.cout) {
+      Act<T>::gst4(op + 4 * q, acc[q]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (4 * q + j < g.cout) Act<T>::gst(op + 4 * q + j, acc[q][j]);
+    }
+  }
+}
+
 // conv_regw's pixel operand of one 16-channel block: float32 values, or (BF) the four bfloat16 as loaded
 template <typename T, bool BF> struct RegwOperand {
   typedef f32x4 type;
@@ -2588,8 +2646,23 @@ static bool launch_gemm_lds(const Geo& g, const Sizes& sz, int mode, const T* in
   if (lds > 64 * 1024) return false;
   if ((part || bb.x) && lds < (size_t)12 * nt * ts * 4) lds = (size_t)12 * nt * ts * 4;   // room for the column-sum combine
 
-  // Four reduction channels: the vector-arithmetic kernel (SSMI_NO_C4=1 keeps the 16-wide matrix tiles)
+  // Three input channels (the first layer): vector arithmetic as well
   static const bool no_c4 = getenv("SSMI_NO_C4") != nullptr;
+  if (!no_c4 && force == 0 && !wpack && mode == 0 && g.cin == 3 && g.cout <= 16 && ntaps <= kC4MaxTaps && !add && !part && !bb.x &&
+      !bb.mean && g.y_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (int64_t)g.n * g.ho * g.wo < 0x7FFFFFFFLL) {
+    const int64_t M = (int64_t)g.n * g.ho * g.wo;
+    set_last_kernel("conv_c3_kernel");
+    hipLaunchKernelGGL((conv_c3_kernel<T>), dim3((unsigned)ceil_div64(M, 256)), dim3(256), 0, st, g, sz, in, w, bias, out);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+      set_error("conv_c3_kernel launch: %s", hipGetErrorString(e));
+      *status = SSMI_E_HIP;
+    } else {
+      *status = SSMI_OK;
+    }
+    return true;
+  }
+  // Four reduction channels: the vector-arithmetic kernel (SSMI_NO_C4=1 keeps the 16-wide matrix tiles)
   const bool c4_wide = a.C_r == 16 && a.C_o == 4 && ntaps == 1;      // sixteen reduction channels, single tap
   if (!no_c4 && force == 0 && !wpack && ((a.C_r == 4 && (a.C_o == 4 || a.C_o == 16)) || c4_wide) && vec && ntaps <= kC4MaxTaps &&
       a.out_ld % 4 == 0 && (!bb.x || bb.ld % 4 == 0) && (!bb.skip || bb.skip_ld % 4 == 0) &&
